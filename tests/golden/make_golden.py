@@ -1,0 +1,534 @@
+#!/usr/bin/env python3
+"""Generate the golden step()-parity fixtures by running the UNMODIFIED reference.
+
+Runs ONLY in the build container (needs /root/reference, which never travels to
+the GPU box).  Output: tests/golden/*.npz -- pure data (inputs + expected
+outputs), no reference text.  Re-run with:
+
+    python tests/golden/make_golden.py
+
+How the reference is driven:
+  * /root/reference/envs/battle_env.py, envs/sprites.py and instinct/* are imported
+    as they lie, with CWD=/root/reference (sprites load assets/*.png relatively).
+  * Five third-party packages the reference imports are not installed here and
+    cannot be (no network): pygame 2.1.2, gym 0.25.0, PettingZoo 1.19.0,
+    vidmaker, cv2.  tests/golden/standins/ holds build-authored stand-ins for
+    them; only pygame.Rect carries arithmetic (restated from pygame 2.1.2, see
+    standins/pygame/__init__.py).
+  * The stdlib `random` module functions the reference calls
+    (`random.randint`, `random.random`; sprites.py:82-91,246-252,314) are
+    wrapped by a tap that records every draw, and can replay a queue of forced
+    values for the hand-scripted edge cases.  That is stdlib patching, not a
+    change to reference code.
+
+Trace schema (flat step axis S, episodes delimited by ep_ptr):
+  spawn[ep, 4+3A]  base_red x,y, base_blue x,y, then plane x,y,dir in id order
+  actions[S,A] int32 (discrete) | actions[S,A,3] float64 (continuous, pre-clip)
+  logits[S,A,4] float64 (only the ndarray-action fixture)
+  empty_call[S] bool   step({}) calls
+  u[S,A] float64       random.random() consumed by agent a's shot (NaN: none)
+  obs0[ep,A,D] f32     reset() observations
+  obs[S,A,D] f32, rew[S,A] f64, done[S,A] bool, env_done[S] bool,
+  winner[S] i8 (0 none, 1 red, 2 blue, 3 tie)
+  px,py[S,A] i32, pdir[S,A] f64, php[S,A] i32, palive[S,A] bool
+  bhp[S,2] i32, tick[S] i32 (count of time increments), total_time[S] f64
+  bl_live/bl_x/bl_y/bl_dir[S,A,12]: live bullets of shooter a; slot = birth tick % 12
+  total_games/ties/wins_red/wins_blue[S] i32 (env counters, persist across resets)
+"""
+import json
+import math
+import os
+import random
+import sys
+from collections import deque
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+K = 12  # bullet slots per shooter (a bullet lives at most 12 updates: 12*45 >= 500)
+WINNER = {"none": 0, "red": 1, "blue": 2, "tie": 3}
+
+
+# ----------------------------------------------------------------------------- RNG tap
+class RngTap:
+    """Wraps stdlib random.randint / random.random: records draws, optionally replays forced ones."""
+
+    def __init__(self):
+        self._randint = random.randint
+        self._random = random.random
+        self.ints = []
+        self.floats = []
+        self.force_ints = deque()
+        self.force_floats = deque()
+
+    def install(self):
+        random.randint = self.randint
+        random.random = self.random
+
+    def uninstall(self):
+        random.randint = self._randint
+        random.random = self._random
+
+    def randint(self, a, b):
+        if self.force_ints:
+            v = self.force_ints.popleft()
+            if v is not None:
+                if not (a <= v <= b):
+                    raise ValueError(f"forced randint {v} outside [{a},{b}]")
+                self.ints.append(v)
+                return v
+        v = self._randint(a, b)
+        self.ints.append(v)
+        return v
+
+    def random(self):
+        if self.force_floats:
+            v = self.force_floats.popleft()
+            if v is not None:
+                self.floats.append(v)
+                return v
+        v = self._random()
+        self.floats.append(v)
+        return v
+
+
+# ----------------------------------------------------------------------------- recorder
+class Recorder:
+    def __init__(self, be, tap, cfg):
+        self.be, self.tap, self.cfg = be, tap, dict(cfg)
+        self.env = be.parallel_env(**cfg)
+        env = self.env
+        self.n = env.n_agents
+        self.A = 2 * self.n
+        self.D = env.obs_size
+        self.cont = bool(env.continuous_actions)
+        self.ids = list(env.possible_agents)
+        self.rows = {k: [] for k in (
+            "actions", "logits", "empty_call", "u", "obs", "rew", "done", "env_done", "winner",
+            "px", "py", "pdir", "php", "palive", "bhp", "tick", "total_time",
+            "bl_live", "bl_x", "bl_y", "bl_dir", "total_games", "ties", "wins_red", "wins_blue")}
+        self.spawn, self.obs0, self.ep_ptr = [], [], [0]
+        self.has_logits = False
+
+    # -- episodes
+    def reset(self, forced_spawn=None):
+        """forced_spawn: list of 4+3A ints (None entries = draw normally).  Red plane dirs are
+        given post-fold (0..90 | 270..359); they are un-folded to the randint(270,450) domain here."""
+        env, tap = self.env, self.tap
+        if forced_spawn is not None:
+            f = list(forced_spawn)
+            assert len(f) == 4 + 3 * self.A
+            for i in range(self.n):  # red planes: randint(270, 450) then -360 if >= 360
+                d = f[4 + 3 * i + 2]
+                if d is not None and d < 270:
+                    f[4 + 3 * i + 2] = d + 360
+            tap.force_ints.extend(f)
+        mark = len(tap.ints)
+        obs = env.reset()
+        assert not tap.force_ints
+        draws = tap.ints[mark:]
+        assert len(draws) == 4 + 3 * self.A
+        # what the env actually holds (dir after the red fold)
+        sp = [*env.team["red"]["base"].rect.center, *env.team["blue"]["base"].rect.center]
+        for aid in self.ids:
+            p = env.team[env.team_map[aid]]["planes"][aid]
+            sp += [p.rect.centerx, p.rect.centery, p.direction]
+        for i, d in enumerate(draws):  # cross-check against the recorded draws
+            exp = sp[i]
+            if i >= 4 and (i - 4) % 3 == 2 and (i - 4) // 3 < self.n and d >= 360:
+                d -= 360
+            assert d == exp, (i, d, exp)
+        self.spawn.append(sp)
+        self.obs0.append(np.stack([obs[a] for a in self.ids]))
+        self._objs = {a: env.team[env.team_map[a]]["planes"][a] for a in self.ids}
+        if len(self.rows["obs"]) != self.ep_ptr[-1]:
+            self.ep_ptr.append(len(self.rows["obs"]))
+        return obs
+
+    def end_episode(self):
+        if self.ep_ptr[-1] != len(self.rows["obs"]):
+            self.ep_ptr.append(len(self.rows["obs"]))
+
+    # -- one step() call
+    def step(self, actions, logits=None, empty=False):
+        """actions: list per agent (ints, or 3-vectors when continuous); logits: optional [A,4]."""
+        env, tap, ids = self.env, self.tap, self.ids
+        alive_before = list(env.agents)
+        if empty:
+            call = {}
+        elif logits is not None:
+            call = {a: np.asarray(logits[i], dtype=np.float64) for i, a in enumerate(ids)}
+        elif self.cont:
+            call = {a: np.asarray(actions[i], dtype=np.float64) for i, a in enumerate(ids)}
+        else:
+            call = {a: actions[i] for i, a in enumerate(ids)}
+        mark = len(tap.floats)
+        bullets_before = len(env.bullets)
+        was_done = env.env_done
+        obs, rew, done, info = env.step(call)
+        draws = tap.floats[mark:]
+        # attribute each random() draw to the agent whose shot consumed it: alive-agent order
+        u = np.full(self.A, np.nan)
+        if not was_done and not empty and len(draws):
+            shooters = []
+            for a in alive_before:
+                i = ids.index(a)
+                if self.cont:
+                    clipped = np.clip(np.asarray(actions[i], dtype=np.float64), -1, 1)
+                    fired = clipped[2] > 0
+                elif logits is not None:
+                    fired = int(np.argmax(logits[i])) == 1
+                else:
+                    fired = actions[i] == 1
+                if fired:
+                    shooters.append(i)
+            assert len(shooters) == len(draws), (shooters, draws)
+            for i, d in zip(shooters, draws):
+                u[i] = d
+        else:
+            assert len(draws) == 0
+        r = self.rows
+        if self.cont:
+            r["actions"].append(np.asarray([np.asarray(a, dtype=np.float64) for a in actions]).reshape(self.A, 3))
+        else:
+            r["actions"].append(np.asarray(actions, dtype=np.int32).reshape(self.A))
+        if logits is not None:
+            self.has_logits = True
+            r["logits"].append(np.asarray(logits, dtype=np.float64).reshape(self.A, 4))
+        else:
+            r["logits"].append(np.zeros((self.A, 4)))
+        r["empty_call"].append(bool(empty))
+        r["u"].append(u)
+        r["obs"].append(np.stack([obs[a] for a in ids]).astype(np.float32))
+        assert all(obs[a].dtype == np.float32 for a in ids)
+        r["rew"].append(np.asarray([float(rew[a]) for a in ids]))
+        r["done"].append(np.asarray([bool(done[a]) for a in ids]))
+        assert done is env.dones
+        r["env_done"].append(bool(env.env_done))
+        r["winner"].append(WINNER[env.winner])
+        self._snapshot()
+        return obs, rew, done
+
+    def _snapshot(self):
+        env, ids, r = self.env, self.ids, self.rows
+        px, py, pdir, php, palive = [], [], [], [], []
+        for a in ids:
+            planes = env.team[env.team_map[a]]["planes"]
+            alive = a in env.agents
+            assert alive == (a in planes)
+            p = self._objs[a]  # a popped (dead) Plane object keeps its final pose and hp
+            assert alive == bool(p.alive) and (alive or p.hp <= 0)
+            palive.append(alive)
+            px.append(p.rect.centerx); py.append(p.rect.centery); pdir.append(float(p.direction)); php.append(p.hp)
+        r["px"].append(px); r["py"].append(py); r["pdir"].append(pdir); r["php"].append(php); r["palive"].append(palive)
+        r["bhp"].append([env.team["red"]["base"].hp, env.team["blue"]["base"].hp])
+        tick = int(round(env.total_time / env.time_step))
+        r["tick"].append(tick); r["total_time"].append(float(env.total_time))
+        live = np.zeros((self.A, K), bool); bx = np.zeros((self.A, K), np.int32)
+        by = np.zeros((self.A, K), np.int32); bd = np.zeros((self.A, K))
+        for b in env.bullets:
+            i = ids.index(b.agent_id)
+            age = int(round(b.dist_travelled / 45.0))
+            assert 1 <= age <= 11 and abs(b.dist_travelled - 45.0 * age) < 1e-9
+            s = (tick - age + 1) % K
+            assert not live[i, s]
+            live[i, s] = True; bx[i, s] = b.rect.centerx; by[i, s] = b.rect.centery; bd[i, s] = float(b.direction)
+        r["bl_live"].append(live); r["bl_x"].append(bx); r["bl_y"].append(by); r["bl_dir"].append(bd)
+        r["total_games"].append(env.total_games); r["ties"].append(env.ties)
+        r["wins_red"].append(env.team["red"]["wins"]); r["wins_blue"].append(env.team["blue"]["wins"])
+
+    def save(self, name, meta):
+        self.end_episode()
+        r = self.rows
+        out = {
+            "ep_ptr": np.asarray(self.ep_ptr, np.int64),
+            "spawn": np.asarray(self.spawn, np.int32),
+            "obs0": np.asarray(self.obs0, np.float32),
+            "actions": np.asarray(r["actions"], np.float64 if self.cont else np.int32),
+            "empty_call": np.asarray(r["empty_call"], bool),
+            "u": np.asarray(r["u"], np.float64),
+            "obs": np.asarray(r["obs"], np.float32),
+            "rew": np.asarray(r["rew"], np.float64),
+            "done": np.asarray(r["done"], bool),
+            "env_done": np.asarray(r["env_done"], bool),
+            "winner": np.asarray(r["winner"], np.int8),
+            "px": np.asarray(r["px"], np.int32), "py": np.asarray(r["py"], np.int32),
+            "pdir": np.asarray(r["pdir"], np.float64), "php": np.asarray(r["php"], np.int32),
+            "palive": np.asarray(r["palive"], bool), "bhp": np.asarray(r["bhp"], np.int32),
+            "tick": np.asarray(r["tick"], np.int32), "total_time": np.asarray(r["total_time"], np.float64),
+            "bl_live": np.asarray(r["bl_live"], bool), "bl_x": np.asarray(r["bl_x"], np.int16),
+            "bl_y": np.asarray(r["bl_y"], np.int16), "bl_dir": np.asarray(r["bl_dir"], np.float64),
+            "total_games": np.asarray(r["total_games"], np.int32), "ties": np.asarray(r["ties"], np.int32),
+            "wins_red": np.asarray(r["wins_red"], np.int32), "wins_blue": np.asarray(r["wins_blue"], np.int32),
+        }
+        if self.has_logits:
+            out["logits"] = np.asarray(r["logits"], np.float64)
+        m = dict(meta)
+        m.update(cfg=self.cfg, n=self.n, A=self.A, D=self.D, continuous=self.cont,
+                 python=sys.version.split()[0], numpy=np.__version__,
+                 libm="glibc " + os.confstr("CS_GNU_LIBC_VERSION").split()[-1],
+                 generator="tests/golden/make_golden.py", reference="WilliamFlinchbaugh/Deep-RL-Battlespace @ v1")
+        out["meta"] = np.asarray(json.dumps(m))
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        ne = len(self.ep_ptr) - 1
+        w = np.asarray(r["winner"])[np.asarray(self.ep_ptr[1:]) - 1] if ne else []
+        print(f"{name}: {ne} episodes, {len(r['obs'])} steps, {os.path.getsize(path)/1024:.0f} kB, "
+              f"final winners red/blue/tie/none = {[int((np.asarray(w)==c).sum()) for c in (1,2,3,0)]}, "
+              f"deaths = {int((~np.asarray(r['palive'])[np.asarray(self.ep_ptr[1:])-1]).sum()) if ne else 0}")
+
+
+# ----------------------------------------------------------------------------- drivers
+def play(rec, policy, episodes, max_calls=400, extra_calls_after_done=0, forced_spawn=None):
+    for ep in range(episodes):
+        obs = rec.reset(forced_spawn[ep] if forced_spawn else None)
+        calls = 0
+        while not rec.env.env_done and calls < max_calls:
+            obs, _, _ = rec.step(policy(obs))
+            calls += 1
+        for _ in range(extra_calls_after_done):
+            obs, _, _ = rec.step(policy(obs))
+        rec.end_episode()
+
+
+def make_instinct(rec, instinct_mod):
+    env = rec.env
+    red = instinct_mod.Team(env.possible_red, env.possible_blue, env)
+    blue = instinct_mod.Team(env.possible_blue, env.possible_red, env)
+
+    def policy(obs):
+        acts = dict(blue.choose_actions({a: obs[a] for a in env.possible_blue}))
+        acts.update(red.choose_actions({a: obs[a] for a in env.possible_red}))
+        return [acts[a] for a in rec.ids]
+    return policy
+
+
+def main():
+    os.chdir(REF)
+    sys.dont_write_bytecode = True
+    sys.path[:0] = [os.path.join(HERE, "standins"), REF]
+    import envs.battle_env as be  # the reference, unmodified
+    import instinct.team as instinct_mod
+    tap = RngTap()
+    tap.install()
+    try:
+        generate(be, instinct_mod, tap)
+    finally:
+        tap.uninstall()
+
+
+def generate(be, instinct_mod, tap):
+    rcfg = dict(hit_base_reward=1.0, hit_plane_reward=0.9, miss_punishment=-0.02,
+                die_punishment=-0.03, lose_punishment=-0.05)  # main.py:29-39 (the trained config)
+
+    # ---- G1: 1v1 discrete, instinct vs instinct (wins / deaths / ties)
+    random.seed(101)
+    rec = Recorder(be, tap, dict(n_agents=1))
+    play(rec, make_instinct(rec, instinct_mod), 24, extra_calls_after_done=2)
+    rec.save("g1_1v1_instinct", dict(driver="instinct-vs-instinct", seed=101))
+
+    # ---- G2: 1v1 discrete, uniform random actions, 1000 steps across resets (config C1 itself)
+    random.seed(1234)
+    rng = np.random.default_rng(1234)
+    rec = Recorder(be, tap, dict(n_agents=1))
+    calls = 0
+    while calls < 1000:
+        rec.reset()
+        while not rec.env.env_done and calls < 1000:
+            rec.step([int(v) for v in rng.integers(0, 4, size=rec.A)]); calls += 1
+        rec.end_episode()
+    rec.save("g2_1v1_random", dict(driver="uniform-random", seed=1234, np_seed=1234))
+
+    # ---- G3: 2v2 / 3v3 / 4v4 instinct and random; float rewards of main.py on the 2v2 case
+    for n, eps, cfg, tag in ((2, 10, rcfg, "2v2_instinct_floatrew"), (4, 6, {}, "4v4_instinct"), (3, 4, {}, "3v3_instinct")):
+        random.seed(300 + n)
+        rec = Recorder(be, tap, dict(n_agents=n, **cfg))
+        play(rec, make_instinct(rec, instinct_mod), eps, extra_calls_after_done=1)
+        rec.save("g3_" + tag, dict(driver="instinct-vs-instinct", seed=300 + n))
+    random.seed(344)
+    rng = np.random.default_rng(344)
+    rec = Recorder(be, tap, dict(n_agents=4))
+    play(rec, lambda obs: [int(v) for v in rng.integers(0, 4, size=8)], 3)
+    rec.save("g3_4v4_random", dict(driver="uniform-random", seed=344, np_seed=344))
+    # all-shoot stress: every slot of every ring in use, frequent same-step multi-hits
+    random.seed(345)
+    rng = np.random.default_rng(345)
+    rec = Recorder(be, tap, dict(n_agents=2))
+    play(rec, lambda obs: [1 if rng.random() < 0.8 else int(rng.integers(0, 4)) for _ in range(4)], 6)
+    rec.save("g3_2v2_mostly_shoot", dict(driver="80% shoot", seed=345, np_seed=345))
+
+    # ---- G4: continuous actions (float64 arrays: the pinned numpy 1.23.1 promotes float32 action
+    #      scalars to float64 on the first Python-number op, so float64 arithmetic IS the reference's)
+    random.seed(401); np.random.seed(401)
+    rec = Recorder(be, tap, dict(n_agents=1, continuous_actions=True))
+    play(rec, make_instinct(rec, instinct_mod), 12, extra_calls_after_done=1)
+    rec.save("g4_1v1_cont_instinct", dict(driver="instinct-vs-instinct", seed=401, np_seed=401))
+    random.seed(402); np.random.seed(402)
+    rec = Recorder(be, tap, dict(n_agents=2, continuous_actions=True, **rcfg))
+    play(rec, make_instinct(rec, instinct_mod), 8)
+    rec.save("g4_2v2_cont_instinct_floatrew", dict(driver="instinct-vs-instinct", seed=402, np_seed=402))
+    random.seed(403)
+    rng = np.random.default_rng(403)
+    rec = Recorder(be, tap, dict(n_agents=1, continuous_actions=True))
+    # float32-representable values, incl. out-of-range ones that step() must clip (battle_env.py:295-297)
+    play(rec, lambda obs: [rng.uniform(-1.3, 1.3, size=3).astype(np.float32).astype(np.float64) for _ in range(2)], 4)
+    rec.save("g4_1v1_cont_random_f32vals", dict(driver="uniform(-1.3,1.3) float32-representable", seed=403, np_seed=403))
+
+    # ---- G5: hand-scripted edge cases
+    scripted(be, tap)
+
+    # ---- G6: rel_angle / dist table on the integer lattice, incl. exact +-180 / 0 cases
+    pts = []
+    rng = np.random.default_rng(6)
+    for dx in (-300, -45, -1, 0, 1, 45, 300):
+        for dy in (-300, -45, -1, 0, 1, 45, 300):
+            if dx or dy:
+                pts.append((600, 400, 600 - dx, 400 - dy))
+    for _ in range(300):
+        pts.append(tuple(int(v) for v in (rng.integers(25, 1176), rng.integers(24, 777), rng.integers(25, 1176), rng.integers(24, 777))))
+    dirs = list(range(0, 361, 15)) + [1, 44, 46, 89, 91, 179, 181, 359] + [float(v) for v in rng.uniform(0, 360, 12)]
+    rows = []
+    for (x0, y0, x1, y1) in pts:
+        for a0 in dirs:
+            rows.append((x0, y0, x1, y1, a0, be.rel_angle((x0, y0), a0, (x1, y1)), be.dist((x0, y0), (x1, y1))))
+    rows = np.asarray(rows, np.float64)
+    np.savez_compressed(os.path.join(HERE, "g6_rel_angle_table.npz"), table=rows,
+                        meta=np.asarray(json.dumps(dict(cols="x0,y0,x1,y1,a0,rel_angle,dist", fn="battle_env.py:38-58"))))
+    print(f"g6_rel_angle_table: {len(rows)} rows")
+
+    # ---- G7: spawn ranges from 20000 resets per team size (min/max/histogram support)
+    random.seed(7)
+    env = be.parallel_env(n_agents=2)
+    mark = len(tap.ints)
+    for _ in range(20000):
+        env.reset()
+    d = np.asarray(tap.ints[mark:], np.int32).reshape(20000, 4 + 3 * 4)
+    # fold red dirs as Plane.reset does
+    for i in range(2):
+        c = 4 + 3 * i + 2
+        d[:, c] = np.where(d[:, c] >= 360, d[:, c] - 360, d[:, c])
+    np.savez_compressed(os.path.join(HERE, "g7_spawn_stats.npz"), lo=d.min(0), hi=d.max(0),
+                        mean=d.mean(0), n=np.asarray(20000),
+                        red_dir_hist=np.bincount(d[:, 6], minlength=361), blue_dir_hist=np.bincount(d[:, 12], minlength=361),
+                        meta=np.asarray(json.dumps(dict(cols="base_red x,y, base_blue x,y, plane0..3 x,y,dir (2v2)", seed=7))))
+    print("g7_spawn_stats: lo", d.min(0).tolist(), "hi", d.max(0).tolist())
+
+
+def report(rec, left):
+    """One line per scripted episode so the author can see that the scenario did what it was written for."""
+    a, b = rec.ep_ptr[-2], rec.ep_ptr[-1]
+    r = rec.rows
+    rew = np.asarray(r["rew"][a:b]).sum(0)
+    print(f"   ep{len(rec.ep_ptr)-2:3d}: calls={b-a:3d} winner={r['winner'][b-1]} tick={r['tick'][b-1]:3d} "
+          f"rew={rew.tolist()} hp={r['php'][b-1]} bhp={r['bhp'][b-1]} alive={[int(v) for v in r['palive'][b-1]]} "
+          f"pos={list(zip(r['px'][b-1], r['py'][b-1]))} dir={r['pdir'][b-1]} unused_u={left}")
+
+
+def scripted(be, tap):
+    """G5: every episode forces its spawn; planes far apart unless the case needs contact."""
+    FAR = [100, 700, 1100, 100]  # base_red (100,700), base_blue (1100,100)
+
+    def sp(p0, p1, bases=FAR):
+        return [*bases, *p0, *p1]
+
+    rec = Recorder(be, tap, dict(n_agents=1))
+
+    def run(spawn, script, us=None, post=0):
+        """script: list of [a0, a1] per call; us: forced random() values in draw order."""
+        rec.reset(spawn)
+        if us:
+            tap.force_floats.extend(us)
+        for acts in script:
+            rec.step(list(acts))
+        for _ in range(post):
+            rec.step([0, 0])
+        left = len(tap.force_floats); tap.force_floats.clear()
+        rec.end_episode()
+        report(rec, left)
+
+    # (1) truncation / clamp lattice: dirs 0/90/180/270 (and 360 reached by turning) at x in {50,63,64,100,383}
+    for d0 in (0, 90, 270, 285, 345):
+        for x in (50, 63, 64, 100, 383):
+            run(sp((x, 400, d0), (1100, 400, 180)), [[0, 0]] * 6)
+    # blue side incl. right/top/bottom clamps
+    for d1, y in ((90, 48), (270, 752), (180, 400), (105, 60), (255, 740)):
+        run(sp((100, 400, 0), (1150, y, d1)), [[0, 0]] * 5)
+    # (2) direction wrap: 350 -> +15 -> 365 -> 5 ; 5 -> -15 -> -10 -> 350 ; 345+15 = 360 stays 360 ; 360+15 -> 15
+    run(sp((200, 400, 350), (1000, 400, 100)), [[2, 3]] * 3 + [[3, 2]] * 4)
+    run(sp((200, 400, 345), (1000, 400, 90)), [[2, 0], [0, 0], [1, 0], [2, 0], [3, 0], [3, 0]], us=[0.5])
+    # (3) invalid discrete actions: no movement, no shot (battle_env.py:399-417)
+    run(sp((200, 400, 0), (1000, 400, 180)), [[4, -1], [7, 100], [0, 0], [5, 1]], us=[0.25])
+    # (4) bullet exactly axis-aligned with zero jitter (u = 0.5 -> jitter 0): dir 270 from x=40 cannot
+    #     happen for a plane (x>=25 ok): shooter at x=63, dir 270 / 90 / 180 / 0
+    for d0 in (0, 90, 180, 270):
+        run(sp((63, 400, d0 if d0 in (0, 90, 270) else 0), (1100, 400, 180 if d0 != 180 else 180)),
+            [[1, 1]] + [[0, 0]] * 12, us=[0.5, 0.5])
+    # (5) range miss on the 12th update (bullet flies along the field, nothing in the way)
+    run(sp((50, 48, 0), (1150, 752, 180), bases=[62, 738, 1138, 62]), [[1, 1]] + [[0, 0]] * 13, us=[0.5, 0.5])
+    # (6) off-screen miss incl. truncation toward zero near the left/top edge
+    run(sp((50, 48, 90), (1150, 752, 270), bases=[379, 400, 758, 400]), [[1, 1]] + [[0, 0]] * 4, us=[0.5, 0.5])
+    run(sp((50, 400, 0), (766, 400, 180), bases=[379, 700, 1138, 700]), [[3, 2]] * 6 + [[1, 1]] + [[0, 0]] * 6, us=[0.4375, 0.5625])
+    # (7) base hits: blue plane next to red base shoots it repeatedly -> red base dies -> blue wins
+    run(sp((383, 100, 0), (766, 400, 180), bases=[300, 400, 1138, 700]),
+        [[0, 0]] * 14 + [[0, 1]] * 14, us=[0.5] * 14, post=3)
+    # (8) red kills blue base; winner receives lose_punishment
+    run(sp((383, 400, 0), (1150, 60, 90), bases=[62, 62, 800, 400]), [[0, 0]] * 12 + [[1, 0]] * 12, us=[0.5] * 12, post=2)
+    # (9) plane kill: head-on planes, both shooting (4 hp each); the first to lose 4 hp dies, its bullets fly on
+    run(sp((383, 400, 0), (766, 400, 180), bases=[62, 62, 1138, 738]), [[1, 1]] * 14 + [[0, 0]] * 6,
+        us=[0.5] * 28, post=0)
+    run(sp((383, 400, 0), (766, 400, 180), bases=[62, 62, 1138, 738]), [[1, 0]] * 16 + [[0, 0]] * 6, us=[0.5] * 16)
+    # (10) empty-action call -> tie (battle_env.py:309-313), then inert calls
+    rec.reset(sp((200, 400, 0), (1000, 400, 180)))
+    rec.step([0, 1]); tap.force_floats.clear()
+    rec.step([0, 0], empty=True)
+    rec.step([0, 0]); rec.step([1, 1])
+    rec.end_episode()
+    # (11) time-limit tie on call #121 with nothing happening, then two inert calls
+    run(sp((200, 400, 90), (1000, 400, 90)), [[2, 3]] * 121, post=2)
+    rec.save("g5_scripted_1v1", dict(driver="hand-scripted edge cases"))
+
+    # (12) ndarray actions -> flat argmax (battle_env.py:327-328)
+    rec = Recorder(be, tap, dict(n_agents=1))
+    rng = np.random.default_rng(512)
+    random.seed(512)
+    rec.reset()
+    for _ in range(60):
+        lg = rng.normal(size=(2, 4))
+        if rng.random() < 0.2:
+            lg[0, 1] = lg[0, 2] = lg[0].max() + 1.0  # tie -> first index wins
+        rec.step([int(np.argmax(l)) for l in lg], logits=lg)
+        if rec.env.env_done:
+            break
+    rec.save("g5_ndarray_actions_1v1", dict(driver="random logits, argmax", seed=512, np_seed=512))
+
+    # (13) 2v2 scripted: both bases dying in ONE step; same-step kill chain; shot whose first target died
+    rec = Recorder(be, tap, dict(n_agents=2))
+
+    def run2(spawn, script, us=None, post=0):
+        rec.reset(spawn)
+        if us:
+            tap.force_floats.extend(us)
+        for acts in script:
+            rec.step(list(acts))
+        for _ in range(post):
+            rec.step([0] * 4)
+        left = len(tap.force_floats); tap.force_floats.clear()
+        rec.end_episode()
+        report(rec, left)
+
+    # both teams hammer the other's base symmetrically (base hp 10): mirrored geometry -> same-step double kill
+    run2([200, 400, 1000, 400, 383, 380, 0, 383, 420, 0, 817, 380, 180, 817, 420, 180],
+         [[0] * 4] * 11 + [[1, 1, 1, 1]] * 12, us=[0.5] * 48, post=2)
+    # two red planes stacked on the same line firing at one blue plane: kill chain + pass-through to the 2nd blue
+    run2([62, 62, 1138, 738, 300, 400, 0, 383, 400, 0, 766, 400, 180, 900, 400, 180],
+         [[1, 1, 0, 0]] * 14 + [[0] * 4] * 8, us=[0.5] * 28)
+    rec.save("g5_scripted_2v2", dict(driver="hand-scripted 2v2 edge cases"))
+
+
+if __name__ == "__main__":
+    cwd = os.getcwd()
+    try:
+        main()
+    finally:
+        os.chdir(cwd)
