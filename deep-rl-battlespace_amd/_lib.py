@@ -1,0 +1,82 @@
+"""ctypes binding of include/battlespace_hip.h.  No fallback: a missing library is an error."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbattlespace_hip.so")
+
+ABI_VERSION = 1
+BULLET_SLOTS = 12
+MAX_N = 16
+F_AUTO_RESET = 1
+F_EMPTY_CALL = 2
+ACT_I32, ACT_LOGITS_F32 = 0, 1
+ACT_F32, ACT_F64 = 0, 1
+WINNER_NAMES = ("none", "red", "blue", "tie")
+
+c_void_p, c_int, c_int64, c_uint32, c_uint64, c_size_t = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                                          ctypes.c_uint32, ctypes.c_uint64, ctypes.c_size_t)
+
+
+class BsxRewards(ctypes.Structure):
+    _fields_ = [("hit_base_reward", ctypes.c_double), ("hit_plane_reward", ctypes.c_double),
+                ("miss_punishment", ctypes.c_double), ("die_punishment", ctypes.c_double),
+                ("lose_punishment", ctypes.c_double)]
+
+
+EXPORT_FIELDS = ("px", "py", "pdir", "php", "palive", "base_xy", "bhp", "tick", "env_done", "winner",
+                 "bl_live", "bl_x", "bl_y", "bl_dir", "counters")
+
+
+class BsxExport(ctypes.Structure):
+    _fields_ = [(f, c_void_p) for f in EXPORT_FIELDS]
+
+
+# name -> (restype, argtypes): every symbol include/battlespace_hip.h declares
+SIGNATURES = {
+    "bsx_abi_version": (c_int, []),
+    "bsx_state_bytes": (c_int, [c_int64, c_int, ctypes.POINTER(c_size_t)]),
+    "bsx_state_init": (c_int, [c_void_p, c_int64, c_int, c_void_p]),
+    "bsx_reset": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_uint64, c_uint64, c_int64, c_void_p, c_void_p]),
+    "bsx_step_discrete": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, ctypes.POINTER(BsxRewards), c_uint32, c_uint64, c_int64, c_void_p]),
+    "bsx_step_continuous": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, ctypes.POINTER(BsxRewards), c_uint32, c_uint64, c_int64, c_void_p]),
+    "bsx_observe": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "bsx_export_state": (c_int, [c_void_p, c_int64, c_int, ctypes.POINTER(BsxExport), c_void_p]),
+    "bsx_tie_tick": (c_int, [c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree HIP library and type its entry points.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built.  Run "
+            f"`python deep-rl-battlespace_amd/build.py` (needs hipcc; cross-compiles for gfx950 without a GPU). "
+            f"There is no CPU fallback for the step() path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.bsx_abi_version()
+    if v != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {v}, binding expects {ABI_VERSION}; rebuild the extension")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc == -1:
+        raise ValueError(f"{what}: invalid argument (BSX_E_ARG)")
+    if rc == -2:
+        raise ValueError(f"{what}: misaligned pointer (BSX_E_ALIGN)")
+    raise RuntimeError(f"{what}: HIP error {rc}")

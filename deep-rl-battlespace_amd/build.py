@@ -1,0 +1,42 @@
+"""Build recipe for the HIP extension: csrc/*.hip -> csrc/libbattlespace_hip.so (in-tree, gfx950 only).
+
+    python deep-rl-battlespace_amd/build.py [--force]
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off is load-bearing: plane and bullet positions are float64
+add-then-truncate in the reference (envs/sprites.py:130-131,332-333) and a fused multiply-add would round differently.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIB = os.path.join(CSRC, "libbattlespace_hip.so")
+SOURCES = [os.path.join(CSRC, "bsx_kernels.hip")]
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+               "-Wall", "-Wno-unused-function"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = SOURCES + [os.path.join(INCLUDE, "battlespace_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile the extension if it is missing or older than its sources.  Returns the library path."""
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, *HIPCC_FLAGS, "-I", INCLUDE, *SOURCES, "-o", LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,693 @@
+// bsx_kernels.hip -- the batched Battlespace step() path for MI355X (gfx950 / CDNA4), behind include/battlespace_hip.h.
+//
+// One thread per agent, one fused launch per step(): plane kinematics -> bullet spawn -> bullet flight / miss / base
+// hit / plane-overlap classification -> ordered plane-hit resolve -> win / tie -> rewards, dones -> observations.
+// Reference behaviour followed (paths relative to the reference repo): envs/battle_env.py:281-381 (step),
+// :383-424 (process_action), :202-244 (observe), :38-58 (rel_angle, dist), :246-279 (reset), :469-496 (tie/win);
+// envs/sprites.py:35-42 (calc_new_xy), :74-153 (Plane), :238-263 (Base), :293-351 (Bullet).
+//
+// Mapping to the hardware
+//   * lane = agent, lanes of one env are adjacent (group width G = next pow2 >= 2n, G <= 32), so an env never
+//     straddles a 64-wide wavefront; every per-agent array is struct-of-arrays indexed e*A + a: consecutive lanes
+//     touch consecutive 16-byte records -> dwordx4 loads/stores, fully coalesced.
+//   * post-move plane poses and hit points of the workgroup's envs are staged in LDS; each lane reads the opposing
+//     team's block from there for bullet overlap tests, the ordered hit resolve and the all-pairs range / angle-off
+//     observations.
+//   * the ordered plane-hit resolve walks the 12 bullet ages oldest-first; a wavefront ballot skips ages at which no
+//     lane of the wave has a candidate (almost all of them), and group ballots give the "nobody left alive" test.
+//   * HBM-bound integer/fp64 work, no dense contraction: no MFMA.
+// Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off   (no FMA contraction: positions are float64 add-then-
+// truncate in the reference, sprites.py:130-131,332-333, and must round exactly as CPython rounds them).
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "battlespace_hip.h"
+
+namespace {
+
+constexpr int K = BSX_BULLET_SLOTS;
+constexpr int TPB = 256;
+
+constexpr int FIELD_W = 1200, FIELD_H = 800;      // sprites.py:9-10
+constexpr int PLANE_HW = 25, PLANE_HH = 24;        // 50x48 sprite, half sizes (w>>1, h>>1)
+constexpr int BASE_HALF = 31;                      // 62x62
+constexpr int PLANE_HP = 4;                        // battle_env.py:92
+constexpr double DEG2RAD = 3.141592653589793238462643383279502884 / 180.0;  // CPython math.radians
+constexpr double RAD2DEG = 180.0 / 3.141592653589793238462643383279502884;  // CPython math.degrees
+constexpr double TWO_PI = 2.0 * 3.141592653589793;                            // 2*math.pi
+constexpr double FIELD_DIAG = 1442.2205101855957;  // sqrt(1200^2 + 800^2), battle_env.py:230
+constexpr double BULLET_STEP = 45.0;               // 450 * 0.1 in binary64
+constexpr double TIME_STEP = 0.1;
+
+// ---------------------------------------------------------------------------------------------- state layout
+struct __align__(16) PlaneRec {   // 16 B per agent
+    int16_t x, y;                 // sprite centre (pygame Rect ints)
+    uint16_t live;                // bit k: bullet slot k in flight
+    int8_t hp;                    // alive <=> hp > 0 (sprites.py:143-153)
+    uint8_t pad;
+    double dir;                   // degrees, [0, 360]
+};
+struct __align__(16) EnvRec {     // 16 B per env
+    int16_t brx, bry, bbx, bby;   // base centres
+    int16_t bhp_r, bhp_b;         // may go negative within a step (sprites.py:260-262)
+    uint16_t tick;                // number of time increments this game (total_time == tick * 0.1 accumulated)
+    uint8_t done;                 // env_done
+    uint8_t winner;               // BSX_WINNER_*
+};
+struct Layout { size_t lut, env, cnt, plane, bxy, bd, bdir, total; };
+
+__host__ __device__ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+
+__host__ __device__ inline Layout make_layout(int64_t E, int n) {
+    Layout L;
+    const size_t EA = size_t(E) * size_t(2 * n);
+    size_t o = 0;
+    L.lut = o;   o = align256(o + 361 * sizeof(double2));
+    L.env = o;   o = align256(o + size_t(E) * sizeof(EnvRec));
+    L.cnt = o;   o = align256(o + size_t(E) * sizeof(int4));
+    L.plane = o; o = align256(o + EA * sizeof(PlaneRec));
+    L.bxy = o;   o = align256(o + 3 * EA * sizeof(uint4));       // [3][EA]: slot k -> chunk k>>2, word k&3, x | y<<16
+    L.bd = o;    o = align256(o + size_t(K) * EA * sizeof(double2)); // [K][EA]: per-update displacement (45cos, 45sin)
+    L.bdir = o;  o = align256(o + size_t(K) * EA * sizeof(double));  // [K][EA]: bullet heading (written at spawn only)
+    L.total = o;
+    return L;
+}
+
+struct StatePtrs {
+    const double2* lut; EnvRec* env; int4* cnt; PlaneRec* plane; uint4* bxy; double2* bd; double* bdir;
+};
+inline StatePtrs state_ptrs(void* base, int64_t E, int n) {
+    Layout L = make_layout(E, n);
+    char* b = static_cast<char*>(base);
+    return StatePtrs{reinterpret_cast<const double2*>(b + L.lut), reinterpret_cast<EnvRec*>(b + L.env),
+                     reinterpret_cast<int4*>(b + L.cnt), reinterpret_cast<PlaneRec*>(b + L.plane),
+                     reinterpret_cast<uint4*>(b + L.bxy), reinterpret_cast<double2*>(b + L.bd),
+                     reinterpret_cast<double*>(b + L.bdir)};
+}
+
+// ---------------------------------------------------------------------------------------------- Philox4x32-10
+__device__ inline uint4 philox4x32_10(uint4 ctr, uint2 key) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, ctr.x), lo0 = 0xD2511F53u * ctr.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, ctr.z), lo1 = 0xCD9E8D57u * ctr.z;
+        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+        key.x += 0x9E3779B9u; key.y += 0xBB67AE85u;
+    }
+    return ctr;
+}
+enum : uint32_t { STREAM_RESET = 0, STREAM_AUTORESET = 1, STREAM_JITTER = 2 };
+__device__ inline uint4 draw4(uint64_t seed, int64_t genv, uint32_t stream, uint32_t seq, uint32_t who) {
+    return philox4x32_10(make_uint4(uint32_t(genv), uint32_t(uint64_t(genv) >> 32) ^ (stream << 28), seq, who),
+                         make_uint2(uint32_t(seed), uint32_t(seed >> 32)));
+}
+// inclusive integer range, multiply-shift
+__device__ inline int randint(uint32_t r, int lo, int hi) { return lo + int(__umulhi(r, uint32_t(hi - lo + 1))); }
+// 53-bit uniform in [0,1), the construction CPython's random.random() uses on two 32-bit words
+__device__ inline double uniform53(uint32_t a, uint32_t b) {
+    return (double(a >> 5) * 67108864.0 + double(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+// ---------------------------------------------------------------------------------------------- game arithmetic
+// Plane.forward clamp on the un-rotated 50x48 rect (sprites.py:134-141)
+__device__ inline void clamp_plane(int& x, int& y) {
+    if (x - PLANE_HW < 0) x = PLANE_HW;
+    if (x + PLANE_HW > FIELD_W) x = FIELD_W - PLANE_HW;
+    if (y - PLANE_HH <= 0) y = PLANE_HH;
+    if (y + PLANE_HH >= FIELD_H) y = FIELD_H - PLANE_HH;
+}
+// Plane.rotate (sprites.py:99-103): [0, 360] inclusive
+__device__ inline double rotate_dir(double d, double ang) {
+    d += ang;
+    while (d > 360.0) d -= 360.0;
+    while (d < 0.0) d += 360.0;
+    return d;
+}
+// rel_angle (battle_env.py:38-52), p0 = observer, p1 = target
+__device__ inline double rel_angle(int x0, int y0, double a0, int x1, int y1) {
+    double rads = atan2(double(y0 - y1), double(x0 - x1));
+    if (rads < 0.0) rads += TWO_PI;   // Python float %: fmod is exact for |rads| <= pi; -0.0 -> +0.0
+    else if (rads == 0.0) rads = 0.0;
+    const double degs = rads * RAD2DEG;
+    double r = (180.0 + a0) - (360.0 - degs);
+    if (r < -180.0) r += 360.0;
+    if (r > 180.0) r -= 360.0;
+    return r;
+}
+__device__ inline float obs_dist(int x0, int y0, int x1, int y1) {
+    const int dx = x0 - x1, dy = y0 - y1;
+    return float(sqrt(double(dx * dx + dy * dy)) / FIELD_DIAG * 2.0 - 1.0);
+}
+__device__ inline float obs_angle(int x0, int y0, double a0, int x1, int y1) {
+    return float(rel_angle(x0, y0, a0, x1, y1) / 360.0);
+}
+__device__ inline uint32_t rotl12(uint32_t v, int s) {  // rotate a 12-bit mask left by s in [0, 12)
+    return ((v << s) | (v >> (12 - s))) & 0xFFFu;
+}
+__device__ inline int sx16(uint32_t w) { return int(int16_t(w & 0xFFFFu)); }
+__device__ inline int sy16(uint32_t w) { return int(int16_t(w >> 16)); }
+__device__ inline uint32_t pack_xy(int x, int y) { return (uint32_t(x) & 0xFFFFu) | (uint32_t(y) << 16); }
+
+__host__ __device__ constexpr int group_width(int n) {
+    int g = 2;
+    while (g < 2 * n) g <<= 1;
+    return g;
+}
+
+struct StepArgs {
+    StatePtrs st;
+    int64_t E; int n;
+    const void* actions; int action_kind;
+    const double* u;
+    float* obs; float* rew; uint8_t* done; uint8_t* env_done; uint8_t* winner;
+    BsxRewards cfg;
+    uint32_t flags; uint64_t seed; int64_t env_offset; int tie_tick;
+};
+
+// Observation row for one agent from the LDS-staged block (battle_env.py:202-244).
+// s_* are indexed by thread id; `gl` = first thread of this env's group.
+template <int N>
+__device__ inline void write_obs(float* __restrict__ out, int n, bool alive, int x, int y, double dir, int a,
+                                 int ebx, int eby, int gl, const volatile int* s_x, const volatile int* s_y,
+                                 const volatile int* s_hp) {
+    const int D = 3 * n + 2;
+    if (!alive) {
+        for (int i = 0; i < D; ++i) out[i] = -1.0f;
+        return;
+    }
+    out[0] = obs_dist(x, y, ebx, eby);
+    out[1] = obs_angle(x, y, dir, ebx, eby);
+    const int eb = gl + (a < n ? n : 0);
+    for (int j = 0; j < n; ++j) {
+        if (s_hp[eb + j] > 0) {
+            const int qx = s_x[eb + j], qy = s_y[eb + j];
+            out[2 + 3 * j] = 1.0f;
+            out[3 + 3 * j] = obs_dist(x, y, qx, qy);
+            out[4 + 3 * j] = obs_angle(x, y, dir, qx, qy);
+        } else {
+            out[2 + 3 * j] = -1.0f; out[3 + 3 * j] = -1.0f; out[4 + 3 * j] = -1.0f;
+        }
+    }
+}
+
+// Spawn draws (sprites.py:74-91,238-252).  Every lane of an env computes the same base draws.
+__device__ inline void spawn_bases(uint64_t seed, int64_t genv, uint32_t stream, uint32_t seq, EnvRec& er) {
+    const uint4 r = draw4(seed, genv, stream, seq, 0xFFFFu);
+    er.brx = int16_t(randint(r.x, 62, 379));     // randint(w, (W-w)//3)
+    er.bry = int16_t(randint(r.y, 62, 738));
+    er.bbx = int16_t(randint(r.z, 758, 1138));   // randint((W-w)//3*2, W-w)
+    er.bby = int16_t(randint(r.w, 62, 738));
+}
+__device__ inline void spawn_plane(uint64_t seed, int64_t genv, uint32_t stream, uint32_t seq, int a, int n,
+                                   int& x, int& y, double& dir) {
+    const uint4 r = draw4(seed, genv, stream, seq, uint32_t(a));
+    if (a < n) {
+        x = randint(r.x, 50, 383); y = randint(r.y, 48, 752);
+        int d = randint(r.z, 270, 450);
+        if (d >= 360) d -= 360;
+        dir = double(d);
+    } else {
+        x = randint(r.x, 766, 1150); y = randint(r.y, 48, 752);
+        dir = double(randint(r.z, 90, 270));
+    }
+}
+
+enum Mode : int { M_INERT = 0, M_TIE = 1, M_PHYS = 2, M_RESET = 3 };
+
+// ---------------------------------------------------------------------------------------------- the step kernel
+template <int N, bool CONT>
+__global__ __launch_bounds__(TPB) void bsx_step_kernel(const StepArgs p) {
+    const int n = (N > 0) ? N : p.n;
+    const int A = 2 * n;
+    const int G = group_width(n);
+    const int EPB = TPB / G;
+    const int tid = threadIdx.x;
+    const int a = tid & (G - 1);
+    const int gl = tid & ~(G - 1);                       // first thread of my env's group
+    const int64_t e = int64_t(blockIdx.x) * EPB + (tid / G);
+    const bool env_ok = e < p.E;
+    const bool valid = env_ok && a < A;
+    const size_t EA = size_t(p.E) * size_t(A);
+    const size_t g = valid ? size_t(e) * A + a : 0;
+    const int lane = tid & 63;
+
+    __shared__ volatile int s_x[TPB], s_y[TPB], s_hp[TPB];
+    __shared__ int s_bhit[TPB];                          // [group*?]: index gl + team
+
+    // ---- load
+    EnvRec er; memset(&er, 0, sizeof(er));
+    PlaneRec pr; memset(&pr, 0, sizeof(pr));
+    if (env_ok) er = p.st.env[e];
+    if (valid) pr = p.st.plane[g];
+    int x = pr.x, y = pr.y, hp = pr.hp;
+    double dir = pr.dir;
+    uint32_t live = pr.live;
+    const bool alive0 = valid && hp > 0;
+
+    // "no agents left" (battle_env.py:309): group ballot over the alive flags
+    const unsigned long long bal = __ballot(alive0);
+    const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << (lane & ~(G - 1)));
+    const bool any_alive = (bal & gmask) != 0ull;
+
+    // ---- what kind of call is this for my env (battle_env.py:303-323)
+    int mode;
+    int tick = er.tick;
+    if (er.done) mode = (p.flags & BSX_F_AUTO_RESET) ? M_RESET : M_INERT;
+    else if ((p.flags & BSX_F_EMPTY_CALL) || !any_alive) mode = M_TIE;
+    else {
+        tick += 1;
+        mode = (tick >= p.tie_tick) ? M_TIE : M_PHYS;
+    }
+    if (!env_ok) mode = M_INERT;
+
+    double rew = 0.0;
+    int4 cnt_delta = make_int4(0, 0, 0, 0);              // games, ties, red wins, blue wins
+    bool spawn = false;
+    int x0 = x, y0 = y;
+    double d0 = dir;
+
+    if (mode == M_RESET) {
+        // re-spawn in place of the inert call; episode id = games played so far
+        const int games = p.st.cnt[e].x;
+        const int64_t genv = p.env_offset + e;
+        spawn_bases(p.seed, genv, STREAM_AUTORESET, uint32_t(games), er);
+        er.bhp_r = er.bhp_b = int16_t(5 * n);
+        er.tick = 0; er.done = 0; er.winner = BSX_WINNER_NONE;
+        tick = 0;
+        if (valid) { spawn_plane(p.seed, genv, STREAM_AUTORESET, uint32_t(games), a, n, x, y, dir); hp = PLANE_HP; live = 0; }
+    } else if (mode == M_PHYS && alive0) {
+        // ---- process_action (battle_env.py:383-424)
+        if (!CONT) {
+            int act;
+            if (p.action_kind == BSX_ACT_I32) act = static_cast<const int32_t*>(p.actions)[g];
+            else {   // np.argmax: first maximum; a NaN compares as the maximum
+                const float4 lg = static_cast<const float4*>(p.actions)[g];
+                const float v[4] = {lg.x, lg.y, lg.z, lg.w};
+                act = 0;
+                for (int i = 1; i < 4; ++i)
+                    if (!(v[act] != v[act]) && (v[i] > v[act] || v[i] != v[i])) act = i;
+            }
+            if (act == 2) dir = rotate_dir(dir, 15.0);
+            else if (act == 3) dir = rotate_dir(dir, -15.0);
+            if (act >= 0 && act <= 3) {
+                const double2 dl = p.st.lut[int(dir)];   // 21.5*cos(-radians(d)), 21.5*sin(-radians(d)) from host libm
+                x = int(double(x) + dl.x);               // Rect.center store truncates toward zero
+                y = int(double(y) + dl.y);
+                clamp_plane(x, y);
+            }
+            spawn = (act == 1);
+        } else {
+            double a0, a1, a2;
+            if (p.action_kind == BSX_ACT_F32) {
+                const float* ap = static_cast<const float*>(p.actions) + 3 * g;
+                a0 = double(ap[0]); a1 = double(ap[1]); a2 = double(ap[2]);
+            } else {
+                const double* ap = static_cast<const double*>(p.actions) + 3 * g;
+                a0 = ap[0]; a1 = ap[1]; a2 = ap[2];
+            }
+            a0 = fmin(fmax(a0, -1.0), 1.0); a1 = fmin(fmax(a1, -1.0), 1.0); a2 = fmin(fmax(a2, -1.0), 1.0);
+            const double speed = ((a0 + 1.0) / 2.0) * 75.0 + 200.0;    // battle_env.py:419
+            double sn, cs;
+            sincos(-(dir * DEG2RAD), &sn, &cs);
+            const double st = speed * TIME_STEP;
+            x = int(double(x) + (st * cs));
+            y = int(double(y) + (st * sn));
+            clamp_plane(x, y);
+            dir = rotate_dir(dir, a1 * 35.0);                          // :421-422
+            spawn = a2 > 0.0;                                          // :423
+        }
+    }
+
+    // ---- stage the post-move block in LDS
+    s_x[tid] = x; s_y[tid] = y; s_hp[tid] = valid ? hp : 0;
+    s_bhit[tid] = 0;
+    __syncthreads();
+
+    const int team = (a < n) ? 0 : 1;                    // 0 red, 1 blue
+    const int eb = gl + (team == 0 ? n : 0);             // first enemy lane (thread index)
+    uint32_t consumed_rank = 0;
+    uint64_t ovl[3] = {0, 0, 0};                         // rank-ordered 16-bit overlap fields, 4 ranks per word
+    const int k0 = (tick + 1) % K;                       // slot of the oldest possible bullet
+    const uint32_t live0 = live;
+
+    if (mode == M_PHYS && valid) {
+        // ---- Bullet.__init__ (sprites.py:293-318) for this call's shot
+        const int ks = tick % K;
+        double2 nd = make_double2(0.0, 0.0);
+        if (spawn) {
+            double uu;
+            if (p.u) uu = p.u[g];
+            else {
+                const int games = p.st.cnt[e].x;
+                const uint4 r = draw4(p.seed, p.env_offset + e, STREAM_JITTER, uint32_t(games),
+                                      (uint32_t(tick) << 8) | uint32_t(a));
+                uu = uniform53(r.x, r.y);
+            }
+            const double bdir = d0 + (uu * 8.0 - 4.0);
+            double sn, cs;
+            sincos(-(bdir * DEG2RAD), &sn, &cs);
+            nd = make_double2(BULLET_STEP * cs, BULLET_STEP * sn);
+            p.st.bd[size_t(ks) * EA + g] = nd;
+            p.st.bdir[size_t(ks) * EA + g] = bdir;
+            live |= 1u << ks;
+        }
+        if (live) {
+            // ---- Bullet.update for each of my bullets (sprites.py:321-351)
+            uint4 c[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) c[q] = p.st.bxy[size_t(q) * EA + g];
+            uint32_t* w = reinterpret_cast<uint32_t*>(c);
+            const int ebx = team == 0 ? er.bbx : er.brx, eby = team == 0 ? er.bby : er.bry;
+            int nbase = 0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (!((live >> k) & 1u)) continue;
+                const bool newb = spawn && k == ks;
+                int bx, by;
+                double2 d;
+                if (newb) { bx = x0; by = y0; d = nd; }
+                else { bx = sx16(w[k]); by = sy16(w[k]); d = p.st.bd[size_t(k) * EA + g]; }
+                bx = int(double(bx) + d.x);
+                by = int(double(by) + d.y);
+                int age = tick - k; age %= K; if (age < 0) age += K; age += 1;      // updates so far, 1..12
+                bool gone = false;
+                if (age >= 12 || bx > FIELD_W || bx < 0 || by > FIELD_H || by < 0) {      // 45*age >= 500 <=> age >= 12
+                    rew += p.cfg.miss_punishment; gone = true;
+                } else {
+                    const int bl = bx - 3, br = bx + 3, bt = by - 1, bb = by + 2;           // 6x3 rect
+                    if (bl < ebx + BASE_HALF && bt < eby + BASE_HALF && br > ebx - BASE_HALF && bb > eby - BASE_HALF) {
+                        rew += p.cfg.hit_base_reward; nbase += 1; gone = true;              // Base.hit, even if already dead
+                    } else {
+                        uint32_t m = 0;
+                        for (int j = 0; j < n; ++j) {
+                            const int qx = s_x[eb + j], qy = s_y[eb + j];
+                            if (s_hp[eb + j] > 0 && bl < qx + PLANE_HW && bt < qy + PLANE_HH && br > qx - PLANE_HW &&
+                                bb > qy - PLANE_HH) m |= 1u << j;
+                        }
+                        if (m) {
+                            const int r = 12 - age;                                         // oldest first
+                            const uint64_t f = uint64_t(m) << ((r & 3) * 16);
+                            ovl[0] |= (r >> 2) == 0 ? f : 0; ovl[1] |= (r >> 2) == 1 ? f : 0; ovl[2] |= (r >> 2) == 2 ? f : 0;
+                        }
+                    }
+                }
+                if (gone) live &= ~(1u << k);
+                else w[k] = pack_xy(bx, by);
+            }
+            if (nbase) atomicAdd(&s_bhit[gl + team], nbase);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if (((live | live0) >> (4 * q)) & 0xFu) p.st.bxy[size_t(q) * EA + g] = c[q];
+        }
+    }
+
+    // ---- ordered plane-hit resolve (battle_env.py:332-360 with sprites.py:348-350): creation order = oldest age
+    //      first, then shooter id; a plane killed earlier in the walk no longer stops later bullets.
+#pragma unroll
+    for (int r = 1; r < K; ++r) {            // rank 0 = age 12 = always a range miss
+        const uint32_t m = uint32_t(ovl[r >> 2] >> ((r & 3) * 16)) & 0xFFFFu;
+        if (__ballot(m != 0) == 0ull) continue;          // wave-uniform: nobody has a candidate of this age
+        for (int i = 0; i < n; ++i) {
+            if (m != 0 && (a - (team ? n : 0)) == i) {
+                for (int j = 0; j < n; ++j) {
+                    if (((m >> j) & 1u) && s_hp[eb + j] > 0) {
+                        s_hp[eb + j] = s_hp[eb + j] - 1;                                     // Plane.hit
+                        rew += p.cfg.hit_plane_reward;
+                        consumed_rank |= 1u << r;
+                        break;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (consumed_rank) live &= ~rotl12(consumed_rank, k0);
+    __syncthreads();
+
+    // ---- deaths, bases, win / tie (battle_env.py:353-372, :469-496)
+    bool alive = valid && hp > 0;
+    if (mode == M_PHYS && valid) {
+        const int hp_new = s_hp[tid];
+        if (alive0 && hp_new <= 0) rew += p.cfg.die_punishment;                              // :359
+        hp = hp_new;
+        alive = hp > 0;
+        er.tick = uint16_t(tick);
+        er.bhp_b = int16_t(er.bhp_b - s_bhit[gl + 0]);   // red shooters damage the blue base
+        er.bhp_r = int16_t(er.bhp_r - s_bhit[gl + 1]);
+        if (er.bhp_b <= 0) {                             // blue base dead: every red plane gets lose_punishment; red wins
+            if (team == 0) rew += p.cfg.lose_punishment;
+            er.winner = BSX_WINNER_RED; er.done = 1; cnt_delta.x += 1; cnt_delta.z += 1;
+        }
+        if (er.bhp_r <= 0) {
+            if (team == 1) rew += p.cfg.lose_punishment;
+            er.winner = BSX_WINNER_BLUE; er.done = 1; cnt_delta.x += 1; cnt_delta.w += 1;
+        }
+    } else if (mode == M_TIE) {
+        er.tick = uint16_t(tick);
+        er.winner = BSX_WINNER_TIE; er.done = 1; cnt_delta.x += 1; cnt_delta.y += 1;
+    }
+
+    // ---- write back
+    if (valid) {
+        if (mode == M_PHYS || mode == M_RESET) {
+            pr.x = int16_t(x); pr.y = int16_t(y); pr.live = uint16_t(live); pr.hp = int8_t(hp); pr.dir = dir;
+            p.st.plane[g] = pr;
+        }
+        p.rew[g] = float(rew);
+        p.done[g] = er.done ? uint8_t(1) : uint8_t(alive ? 0 : 1);
+        write_obs<N>(p.obs + g * size_t(3 * n + 2), n, alive, x, y, dir, a,
+                     team == 0 ? er.bbx : er.brx, team == 0 ? er.bby : er.bry, gl, s_x, s_y, s_hp);
+        if (a == 0) {
+            if (mode != M_INERT) p.st.env[e] = er;
+            if (cnt_delta.x) {
+                int4 c = p.st.cnt[e];
+                c.x += cnt_delta.x; c.y += cnt_delta.y; c.z += cnt_delta.z; c.w += cnt_delta.w;
+                p.st.cnt[e] = c;
+            }
+            if (p.env_done) p.env_done[e] = er.done;
+            if (p.winner) p.winner[e] = er.winner;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- reset / observe
+struct ResetArgs {
+    StatePtrs st; int64_t E; int n; const uint8_t* mask; const int32_t* spawn; uint64_t seed; uint64_t nonce;
+    int64_t env_offset; float* obs; int observe_only;
+};
+
+__global__ __launch_bounds__(TPB) void bsx_reset_kernel(const ResetArgs p) {
+    const int n = p.n, A = 2 * n, G = group_width(n), EPB = TPB / G;
+    const int tid = threadIdx.x, a = tid & (G - 1), gl = tid & ~(G - 1);
+    const int64_t e = int64_t(blockIdx.x) * EPB + (tid / G);
+    const bool env_ok = e < p.E, valid = env_ok && a < A;
+    const size_t g = valid ? size_t(e) * A + a : 0;
+    __shared__ volatile int s_x[TPB], s_y[TPB], s_hp[TPB];
+
+    EnvRec er; memset(&er, 0, sizeof(er));
+    PlaneRec pr; memset(&pr, 0, sizeof(pr));
+    if (env_ok) er = p.st.env[e];
+    if (valid) pr = p.st.plane[g];
+    const bool doit = env_ok && !p.observe_only && (!p.mask || p.mask[e]);
+    if (doit) {
+        const int64_t genv = p.env_offset + e;
+        if (p.spawn) {
+            const int32_t* s = p.spawn + size_t(e) * (4 + 3 * A);
+            er.brx = int16_t(s[0]); er.bry = int16_t(s[1]); er.bbx = int16_t(s[2]); er.bby = int16_t(s[3]);
+            if (valid) { pr.x = int16_t(s[4 + 3 * a]); pr.y = int16_t(s[5 + 3 * a]); pr.dir = double(s[6 + 3 * a]); }
+        } else {
+            spawn_bases(p.seed, genv, STREAM_RESET, uint32_t(p.nonce), er);
+            if (valid) {
+                int x, y; double d;
+                spawn_plane(p.seed, genv, STREAM_RESET, uint32_t(p.nonce), a, n, x, y, d);
+                pr.x = int16_t(x); pr.y = int16_t(y); pr.dir = d;
+            }
+        }
+        er.bhp_r = er.bhp_b = int16_t(5 * n);
+        er.tick = 0; er.done = 0; er.winner = BSX_WINNER_NONE;
+        pr.hp = PLANE_HP; pr.live = 0;
+        if (valid) p.st.plane[g] = pr;
+        if (valid && a == 0) p.st.env[e] = er;
+    }
+    s_x[tid] = pr.x; s_y[tid] = pr.y; s_hp[tid] = valid ? pr.hp : 0;
+    __syncthreads();
+    if (valid && p.obs) {
+        const int team = a < n ? 0 : 1;
+        write_obs<0>(p.obs + g * size_t(3 * n + 2), n, pr.hp > 0, pr.x, pr.y, pr.dir, a,
+                     team == 0 ? er.bbx : er.brx, team == 0 ? er.bby : er.bry, gl, s_x, s_y, s_hp);
+    }
+}
+
+__global__ void bsx_mark_done_kernel(EnvRec* env, int64_t E) {
+    const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (e < E) { EnvRec r; memset(&r, 0, sizeof(r)); r.done = 1; env[e] = r; }
+}
+
+struct ExportArgs { StatePtrs st; int64_t E; int n; BsxExport out; };
+
+__global__ __launch_bounds__(TPB) void bsx_export_kernel(const ExportArgs p) {
+    const int A = 2 * p.n;
+    const size_t EA = size_t(p.E) * A;
+    const size_t g = size_t(blockIdx.x) * TPB + threadIdx.x;
+    if (g >= EA) return;
+    const int64_t e = int64_t(g / A);
+    const int a = int(g % A);
+    const PlaneRec pr = p.st.plane[g];
+    const BsxExport& o = p.out;
+    if (o.px) o.px[g] = pr.x;
+    if (o.py) o.py[g] = pr.y;
+    if (o.pdir) o.pdir[g] = pr.dir;
+    if (o.php) o.php[g] = pr.hp;
+    if (o.palive) o.palive[g] = pr.hp > 0;
+    uint4 c[3];
+    for (int q = 0; q < 3; ++q) c[q] = p.st.bxy[size_t(q) * EA + g];
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(c);
+    for (int k = 0; k < K; ++k) {
+        const bool lv = (pr.live >> k) & 1u;
+        const size_t i = g * K + k;
+        if (o.bl_live) o.bl_live[i] = lv;
+        if (o.bl_x) o.bl_x[i] = lv ? sx16(w[k]) : 0;
+        if (o.bl_y) o.bl_y[i] = lv ? sy16(w[k]) : 0;
+        if (o.bl_dir) o.bl_dir[i] = lv ? p.st.bdir[size_t(k) * EA + g] : 0.0;
+    }
+    if (a == 0) {
+        const EnvRec er = p.st.env[e];
+        if (o.base_xy) { o.base_xy[4 * e] = er.brx; o.base_xy[4 * e + 1] = er.bry; o.base_xy[4 * e + 2] = er.bbx; o.base_xy[4 * e + 3] = er.bby; }
+        if (o.bhp) { o.bhp[2 * e] = er.bhp_r; o.bhp[2 * e + 1] = er.bhp_b; }
+        if (o.tick) o.tick[e] = er.tick;
+        if (o.env_done) o.env_done[e] = er.done;
+        if (o.winner) o.winner[e] = er.winner;
+        if (o.counters) {
+            const int4 c4 = p.st.cnt[e];
+            o.counters[4 * e] = c4.x; o.counters[4 * e + 1] = c4.y; o.counters[4 * e + 2] = c4.z; o.counters[4 * e + 3] = c4.w;
+        }
+    }
+}
+
+inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+inline int grid_for(int64_t E, int n) {
+    const int epb = TPB / group_width(n);
+    return int((E + epb - 1) / epb);
+}
+
+template <bool CONT>
+int launch_step(void* state, int64_t E, int n, const void* actions, int action_kind, const double* u, float* obs,
+                float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner, const BsxRewards* cfg, uint32_t flags,
+                uint64_t seed, int64_t env_offset, void* stream) {
+    if (!state || E <= 0 || n < 1 || n > BSX_MAX_N || !obs || !rew || !done || !cfg) return BSX_E_ARG;
+    if (!actions && !(flags & BSX_F_EMPTY_CALL)) return BSX_E_ARG;
+    if (!aligned(state, 256) || !aligned(obs, 4) || !aligned(rew, 4) || (u && !aligned(u, 8))) return BSX_E_ALIGN;
+    if (!CONT && action_kind == BSX_ACT_LOGITS_F32 && !aligned(actions, 16)) return BSX_E_ALIGN;
+    if (!CONT && action_kind != BSX_ACT_I32 && action_kind != BSX_ACT_LOGITS_F32) return BSX_E_ARG;
+    if (CONT && action_kind != BSX_ACT_F32 && action_kind != BSX_ACT_F64) return BSX_E_ARG;
+    StepArgs a;
+    a.st = state_ptrs(state, E, n);
+    a.E = E; a.n = n; a.actions = actions; a.action_kind = action_kind; a.u = u;
+    a.obs = obs; a.rew = rew; a.done = done; a.env_done = env_done; a.winner = winner;
+    a.cfg = *cfg; a.flags = flags; a.seed = seed; a.env_offset = env_offset; a.tie_tick = bsx_tie_tick(n);
+    const dim3 grid(grid_for(E, n)), block(TPB);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (n) {
+        case 1: hipLaunchKernelGGL((bsx_step_kernel<1, CONT>), grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((bsx_step_kernel<2, CONT>), grid, block, 0, s, a); break;
+        case 3: hipLaunchKernelGGL((bsx_step_kernel<3, CONT>), grid, block, 0, s, a); break;
+        case 4: hipLaunchKernelGGL((bsx_step_kernel<4, CONT>), grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL((bsx_step_kernel<0, CONT>), grid, block, 0, s, a); break;
+    }
+    return int(hipGetLastError());
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" {
+
+int bsx_abi_version(void) { return BSX_ABI_VERSION; }
+
+int bsx_tie_tick(int n) {
+    // battle_env.py:168,316-319: total_time += 0.1 (binary64) until >= 10 + 2n
+    const double max_time = double(10 + n * 2);
+    volatile double t = 0.0;
+    int k = 0;
+    for (;;) {
+        t = t + 0.1;
+        ++k;
+        if (t >= max_time) return k;
+    }
+}
+
+int bsx_state_bytes(int64_t E, int n, size_t* bytes) {
+    if (E <= 0 || n < 1 || n > BSX_MAX_N || !bytes) return BSX_E_ARG;
+    *bytes = make_layout(E, n).total;
+    return 0;
+}
+
+int bsx_state_init(void* state, int64_t E, int n, void* stream) {
+    if (!state || E <= 0 || n < 1 || n > BSX_MAX_N) return BSX_E_ARG;
+    if (!aligned(state, 256)) return BSX_E_ALIGN;
+    const Layout L = make_layout(E, n);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t err = hipMemsetAsync(state, 0, L.total, s);
+    if (err != hipSuccess) return int(err);
+    // heading table through the host libm, exactly as calc_new_xy evaluates it (sprites.py:40-41) with speed*time = 215*0.1
+    static double2 lut[361];
+    const double st = 215 * 0.1;
+    for (int d = 0; d <= 360; ++d) {
+        const double ang = -(double(d) * DEG2RAD);
+        lut[d].x = st * cos(ang);
+        lut[d].y = st * sin(ang);
+    }
+    err = hipMemcpyAsync(static_cast<char*>(state) + L.lut, lut, sizeof(lut), hipMemcpyHostToDevice, s);
+    if (err != hipSuccess) return int(err);
+    // every env starts finished (done = 1), so a step before the first reset is the inert call of battle_env.py:303-306
+    hipLaunchKernelGGL(bsx_mark_done_kernel, dim3(unsigned((E + TPB - 1) / TPB)), dim3(TPB), 0, s,
+                       reinterpret_cast<EnvRec*>(static_cast<char*>(state) + L.env), E);
+    return int(hipGetLastError());
+}
+
+int bsx_reset(void* state, int64_t E, int n, const uint8_t* reset_mask, const int32_t* spawn, uint64_t seed,
+              uint64_t nonce, int64_t env_offset, float* obs, void* stream) {
+    if (!state || E <= 0 || n < 1 || n > BSX_MAX_N) return BSX_E_ARG;
+    if (!aligned(state, 256) || (spawn && !aligned(spawn, 4)) || (obs && !aligned(obs, 4))) return BSX_E_ALIGN;
+    ResetArgs a{state_ptrs(state, E, n), E, n, reset_mask, spawn, seed, nonce, env_offset, obs, 0};
+    hipLaunchKernelGGL(bsx_reset_kernel, dim3(grid_for(E, n)), dim3(TPB), 0, static_cast<hipStream_t>(stream), a);
+    return int(hipGetLastError());
+}
+
+int bsx_step_discrete(void* state, int64_t E, int n, const void* actions, int action_kind, const double* u, float* obs,
+                      float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner, const BsxRewards* cfg,
+                      uint32_t flags, uint64_t seed, int64_t env_offset, void* stream) {
+    return launch_step<false>(state, E, n, actions, action_kind, u, obs, rew, done, env_done, winner, cfg, flags, seed,
+                              env_offset, stream);
+}
+
+int bsx_step_continuous(void* state, int64_t E, int n, const void* actions, int action_kind, const double* u,
+                        float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner,
+                        const BsxRewards* cfg, uint32_t flags, uint64_t seed, int64_t env_offset, void* stream) {
+    return launch_step<true>(state, E, n, actions, action_kind, u, obs, rew, done, env_done, winner, cfg, flags, seed,
+                             env_offset, stream);
+}
+
+int bsx_observe(void* state, int64_t E, int n, float* obs, void* stream) {
+    if (!state || E <= 0 || n < 1 || n > BSX_MAX_N || !obs) return BSX_E_ARG;
+    if (!aligned(state, 256) || !aligned(obs, 4)) return BSX_E_ALIGN;
+    // same kernel as reset with nothing selected: it only stages the poses and writes the rows (battle_env.py:202-244)
+    ResetArgs a{state_ptrs(state, E, n), E, n, nullptr, nullptr, 0, 0, 0, obs, 1};
+    hipLaunchKernelGGL(bsx_reset_kernel, dim3(grid_for(E, n)), dim3(TPB), 0, static_cast<hipStream_t>(stream), a);
+    return int(hipGetLastError());
+}
+
+int bsx_export_state(const void* state, int64_t E, int n, const BsxExport* out, void* stream) {
+    if (!state || E <= 0 || n < 1 || n > BSX_MAX_N || !out) return BSX_E_ARG;
+    if (!aligned(state, 256)) return BSX_E_ALIGN;
+    ExportArgs a{state_ptrs(const_cast<void*>(state), E, n), E, n, *out};
+    const size_t EA = size_t(E) * 2 * n;
+    hipLaunchKernelGGL(bsx_export_kernel, dim3(unsigned((EA + TPB - 1) / TPB)), dim3(TPB), 0,
+                       static_cast<hipStream_t>(stream), a);
+    return int(hipGetLastError());
+}
+
+}  // extern "C"

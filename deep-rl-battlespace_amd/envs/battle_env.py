@@ -1,0 +1,464 @@
+"""`parallel_env`: the reference's PettingZoo/Gym ParallelEnv surface (reference envs/battle_env.py:61-496), with the
+whole step() path -- kinematics, bullets, hits, rewards, dones, observations -- executed for `n_envs` independent
+games by one fused HIP kernel launch on an MI355X (csrc/bsx_kernels.hip through the C ABI of
+include/battlespace_hip.h).  Game state lives in one device buffer owned by this object; nothing on the step path
+runs on the CPU and there is no CPU fallback.
+
+Two ways to use it
+
+  * drop-in (``n_envs=None``, the default): one game, and every return value has the reference's type -- observation
+    dicts of float32 numpy rows, Python-number rewards, bool dones, ``env_done`` a bool, ``winner`` a str, ``agents``
+    the list of live ids.  Randomness comes from the stdlib ``random`` module in the reference's draw order
+    (sprites.py:82-91,246-252,314), so after ``random.seed(s)`` the game is the reference's game.  Each call
+    synchronises with the device; this mode is for parity and for callers that cannot batch.
+
+  * batched (``n_envs=E``): every per-agent value gains a leading E axis and stays on the device:
+    ``step(actions) -> (obs, rewards, dones, infos)`` with dicts ``{"plane{i}": tensor[E, ...]}`` that are views of
+    column i of the env-owned output tensors (overwritten by the next call), or ``step_batch(actions[E, A])`` which
+    returns the ``[E, A, ...]`` tensors themselves and builds no dicts.  Randomness is in-kernel Philox4x32-10 keyed
+    by (seed, global env index, game number, tick, agent): results do not depend on how envs are sharded over GPUs.
+
+Reference quirks are reproduced, not fixed: observation Box has low=+1/high=-1; the winning
+team receives ``lose_punishment``; headings live in [0, 360] inclusive; a discrete action outside 0..3 means "do not
+move"; the time-limit tie fires on call number 10*max_time + 1; a finished game ignores step() until reset().
+"""
+import ctypes
+import random as _stdlib_random
+import warnings
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..spaces import Box, Discrete
+
+DISP_WIDTH = 1200    # reference envs/sprites.py:9
+DISP_HEIGHT = 800    # reference envs/sprites.py:10
+
+
+class _TeamCounters:
+    """`env.team[colour]['wins']` (reference battle_env.py:102-103,492) backed by the device counters."""
+
+    def __init__(self, env, col):
+        self._env, self._col = env, col
+
+    def __getitem__(self, key):
+        if key != "wins":
+            raise KeyError(key)
+        c = self._env.counters()
+        v = c[:, self._col]
+        return int(v[0]) if self._env._compat else v
+
+
+class parallel_env:
+    metadata = {"render_modes": ["human"], "name": "battle_env_v1"}   # battle_env.py:68-71
+
+    def __init__(self, n_agents=1, show=False, hit_base_reward=100, hit_plane_reward=10, miss_punishment=-1,
+                 die_punishment=-5, lose_punishment=-20, fps=20, continuous_actions=False,
+                 n_envs=None, device=None, seed=0, auto_reset=False, env_offset=0, rng=None):
+        """First nine arguments: exactly the reference constructor (battle_env.py:73).
+
+        n_envs      None = drop-in single game (reference return types); int = batched on-device tensors
+        device      torch device of the MI355X to run on (default: current cuda device)
+        seed        Philox key for in-kernel spawn / bullet-jitter draws
+        auto_reset  batched mode: a step() on a finished game re-spawns it instead of the reference's inert call
+        env_offset  global index of this object's env 0 (sharding: rank r owns [r*E, (r+1)*E))
+        rng         "python" (stdlib random, reference draw order; default when n_envs is None) or "philox"
+        """
+        if not isinstance(n_agents, (int, np.integer)) or not 1 <= n_agents <= _lib.MAX_N:
+            raise ValueError(f"n_agents must be an int in 1..{_lib.MAX_N}, got {n_agents!r}")
+        self._lib = _lib.load()                       # raises if the HIP extension has not been built
+        if not torch.cuda.is_available():
+            raise RuntimeError("parallel_env needs an MI355X visible to torch (torch.cuda.is_available() is False); "
+                               "the step() path has no CPU implementation")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if self.device.type != "cuda":
+            raise ValueError(f"device must be a cuda (HIP) device, got {self.device}")
+        self._compat = n_envs is None
+        self.n_envs = E = 1 if n_envs is None else int(n_envs)
+        if E < 1:
+            raise ValueError("n_envs must be >= 1")
+        self.n_agents = n = int(n_agents)
+        self._A = A = 2 * n
+        self.base_hp = 5 * n
+        self.plane_hp = 4
+        self.possible_agents = [f"plane{r}" for r in range(A)]          # battle_env.py:106-109
+        self.possible_red = self.possible_agents[:n]
+        self.possible_blue = self.possible_agents[n:]
+        self.team_map = {a: ("red" if i < n else "blue") for i, a in enumerate(self.possible_agents)}
+        self._idx = {a: i for i, a in enumerate(self.possible_agents)}
+        self.team = {"red": _TeamCounters(self, 2), "blue": _TeamCounters(self, 3)}
+        self.obs_size = D = 3 * n + 2                                   # battle_env.py:132
+        high = np.ones(D, dtype=np.float32)
+        obs_space = Box(high, -high)                                    # battle_env.py:134 (low=+1, high=-1: as there)
+        self.observation_spaces = {a: obs_space for a in self.possible_agents}
+        self.continuous_actions = bool(continuous_actions)
+        if self.continuous_actions:                                     # battle_env.py:145-155
+            self.n_actions, self.max_turn, self.max_speed, self.min_speed = 3, 35, 275, 200
+            action_space = Box(-1.0, 1.0, shape=(3,), dtype=np.float32)
+        else:                                                           # battle_env.py:156-160
+            self.n_actions, self.step_turn, self.speed = 4, 15, 215
+            action_space = Discrete(4)
+        self.action_spaces = {a: action_space for a in self.possible_agents}
+        self.width, self.height = DISP_WIDTH, DISP_HEIGHT
+        self.max_time = 10 + n * 2
+        self.bullet_speed, self.shot_dist, self.time_step = 450, 500, 0.1
+        self.show = show
+        self.hit_base_reward, self.hit_plane_reward = hit_base_reward, hit_plane_reward
+        self.miss_punishment, self.die_punishment, self.lose_punishment = miss_punishment, die_punishment, lose_punishment
+        self.fps = fps
+        self.recording = False
+        self._int_rewards = all(isinstance(v, (int, np.integer)) and not isinstance(v, bool) for v in
+                                (hit_base_reward, hit_plane_reward, miss_punishment, die_punishment, lose_punishment))
+        self._cfg = _lib.BsxRewards(float(hit_base_reward), float(hit_plane_reward), float(miss_punishment),
+                                    float(die_punishment), float(lose_punishment))
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.auto_reset = bool(auto_reset)
+        self.env_offset = int(env_offset)
+        self.rng = rng if rng is not None else ("python" if self._compat else "philox")
+        if self.rng not in ("python", "philox"):
+            raise ValueError("rng must be 'python' or 'philox'")
+        if self.auto_reset and self.rng == "python":
+            raise ValueError("auto_reset draws spawns in-kernel: use rng='philox'")
+        self.tie_tick = int(self._lib.bsx_tie_tick(n))
+
+        # ---- device buffers
+        nbytes = ctypes.c_size_t()
+        _lib.check(self._lib.bsx_state_bytes(E, n, ctypes.byref(nbytes)), "bsx_state_bytes")
+        dev = self.device
+        self._state = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        self._obs = torch.empty((E, A, D), dtype=torch.float32, device=dev)
+        self._rew = torch.empty((E, A), dtype=torch.float32, device=dev)
+        self._done = torch.empty((E, A), dtype=torch.uint8, device=dev)
+        self._env_done = torch.empty(E, dtype=torch.uint8, device=dev)
+        self._winner = torch.empty(E, dtype=torch.uint8, device=dev)
+        self._u = None
+        self._reset_nonce = 0
+        _lib.check(self._lib.bsx_state_init(self._state.data_ptr(), E, n, self._stream()), "bsx_state_init")
+        self._env_done.fill_(1)
+        self._winner.zero_()
+        self._done.fill_(1)
+        self._rew.zero_()
+        # host mirrors (only maintained when rng == "python" or in drop-in mode)
+        self._mirror = self._compat or self.rng == "python"
+        self._h_alive = np.ones((E, A), bool)
+        self._h_done = np.ones(E, bool)
+        self._h_tick = np.zeros(E, np.int64)
+        self.dones = {a: False for a in self.possible_agents} if self._compat else None
+        self._winner_name = "none"
+        # the reference constructor builds bases and planes once, consuming 4 + 3A draws (battle_env.py:98-118)
+        if self.rng == "python":
+            for _ in range(E):
+                self._draw_spawn()
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _draw_spawn(self):
+        """4 + 3A stdlib draws in the reference's order (sprites.py:238-252 bases, :74-91 planes; battle_env.py:257-268)."""
+        n, ri = self.n_agents, _stdlib_random.randint
+        out = [ri(62, 1138 // 3), ri(62, 738), ri(1138 // 3 * 2, 1138), ri(62, 738)]
+        for i in range(2 * n):
+            if i < n:
+                x, y, d = ri(50, 1150 // 3), ri(48, 752), ri(270, 450)
+                if d >= 360:
+                    d -= 360
+            else:
+                x, y, d = ri(1150 // 3 * 2, 1150), ri(48, 752), ri(90, 270)
+            out += [x, y, d]
+        return out
+
+    def _agent_views(self, t):
+        return {a: t[:, i] for i, a in enumerate(self.possible_agents)}
+
+    # ------------------------------------------------------------------ spaces (battle_env.py:186-200)
+    def observation_space(self, agent):
+        return self.observation_spaces[agent]
+
+    def action_space(self, agent):
+        return self.action_spaces[agent]
+
+    # ------------------------------------------------------------------ reset (battle_env.py:246-279)
+    def reset(self, seed=None, return_info=False, options=None, spawn=None, mask=None):
+        """`seed`, `return_info`, `options` are accepted and ignored, as in the reference.
+        spawn: optional int32 [E, 4+3A] (base_red x,y, base_blue x,y, then x,y,dir per plane): forced spawn states.
+        mask:  optional bool/uint8 [E]: reset only these games (batched mode)."""
+        E, A = self.n_envs, self._A
+        mask_t = None
+        if mask is not None:
+            mask_t = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+            if mask_t.shape != (E,):
+                raise ValueError(f"mask must have shape ({E},)")
+        if spawn is None and self.rng == "python":
+            sel = range(E) if mask is None else [i for i in range(E) if bool(mask_t[i])]
+            rows = np.zeros((E, 4 + 3 * A), np.int32)
+            for i in sel:
+                rows[i] = self._draw_spawn()
+            spawn = rows
+        spawn_t = None
+        if spawn is not None:
+            spawn_t = torch.as_tensor(np.asarray(spawn) if not torch.is_tensor(spawn) else spawn)
+            spawn_t = spawn_t.to(device=self.device, dtype=torch.int32).contiguous()
+            if spawn_t.shape != (E, 4 + 3 * A):
+                raise ValueError(f"spawn must have shape ({E}, {4 + 3 * A}), got {tuple(spawn_t.shape)}")
+        self._reset_nonce += 1
+        _lib.check(self._lib.bsx_reset(self._state.data_ptr(), E, self.n_agents,
+                                       mask_t.data_ptr() if mask_t is not None else None,
+                                       spawn_t.data_ptr() if spawn_t is not None else None,
+                                       self.seed, self._reset_nonce, self.env_offset, self._obs.data_ptr(),
+                                       self._stream()), "bsx_reset")
+        if mask_t is None:
+            self._env_done.zero_(); self._winner.zero_(); self._done.zero_()
+        else:
+            m = mask_t.bool()
+            self._env_done[m] = 0; self._winner[m] = 0; self._done[m] = 0
+        if self._mirror:
+            self._sync_mirror()
+        if self._compat:
+            self.dones = {a: False for a in self.possible_agents}
+            self._winner_name = "none"
+            o = self._obs[0].cpu().numpy()
+            return {a: o[i].copy() for i, a in enumerate(self.possible_agents)}
+        return self._agent_views(self._obs)
+
+    # ------------------------------------------------------------------ step (battle_env.py:281-381)
+    def _pack_actions(self, actions):
+        """-> (tensor or None, kind, empty).  Accepts a dict {agent: per-env values} or one [E, A(, k)] tensor."""
+        E, A, dev = self.n_envs, self._A, self.device
+        if isinstance(actions, dict):
+            if len(actions) == 0:
+                return None, 0, True
+            cols = []
+            for a in self.possible_agents:
+                v = actions.get(a)
+                if v is None:       # the reference only reads actions of live agents; absent = "no movement"
+                    v = torch.zeros((E, 3)) if self.continuous_actions else torch.full((E,), -1)
+                if not torch.is_tensor(v):
+                    v = torch.as_tensor(np.asarray(v))
+                if v.dim() == 0:
+                    v = v.reshape(1)
+                if v.shape[0] != E:
+                    raise ValueError(f"action for {a}: leading dimension must be n_envs={E}, got shape {tuple(v.shape)}")
+                cols.append(v.to(dev))
+            if len({c.dim() for c in cols}) != 1:
+                # mixed per-agent encodings (indices and score vectors): arg-max the vectors (battle_env.py:327-328)
+                cols = [c.argmax(-1) if c.dim() == 2 else c for c in cols]
+            t = torch.stack(cols, dim=1)
+        else:
+            t = actions if torch.is_tensor(actions) else torch.as_tensor(np.asarray(actions))
+            t = t.to(dev)
+        if self.continuous_actions:
+            if t.shape != (E, A, 3):
+                raise ValueError(f"continuous actions must have shape ({E}, {A}, 3), got {tuple(t.shape)}")
+            if t.dtype == torch.float64:
+                return t.contiguous(), _lib.ACT_F64, False
+            return t.to(torch.float32).contiguous(), _lib.ACT_F32, False
+        if t.dim() == 3:
+            if t.shape != (E, A, 4):
+                raise ValueError(f"discrete action vectors must have shape ({E}, {A}, 4), got {tuple(t.shape)}")
+            return t.to(torch.float32).contiguous(), _lib.ACT_LOGITS_F32, False
+        if t.shape != (E, A):
+            raise ValueError(f"discrete actions must have shape ({E}, {A}), got {tuple(t.shape)}")
+        if t.is_floating_point():
+            raise TypeError("discrete actions must be integers (or [E, A, 4] score vectors)")
+        return t.to(torch.int32).contiguous(), _lib.ACT_I32, False
+
+    def _draw_jitter(self, act_t, kind, empty):
+        """rng='python': one stdlib random() per shot, live agents in id order, only on calls that reach the physics
+        (battle_env.py:303-329, sprites.py:314).  Returns a float64 [E, A] tensor (NaN = no shot)."""
+        E, A = self.n_envs, self._A
+        u = np.full((E, A), np.nan)
+        if empty:
+            return u
+        a = act_t.detach().cpu().numpy()
+        if self.continuous_actions:
+            shoot = np.clip(a[..., 2].astype(np.float64), -1, 1) > 0
+        elif kind == _lib.ACT_LOGITS_F32:
+            shoot = a.argmax(-1) == 1
+        else:
+            shoot = a == 1
+        for e in range(E):
+            if self._h_done[e] or not self._h_alive[e].any() or self._h_tick[e] + 1 >= self.tie_tick:
+                continue
+            for i in range(A):
+                if self._h_alive[e, i] and shoot[e, i]:
+                    u[e, i] = _stdlib_random.random()
+        return u
+
+    def step_batch(self, actions, u=None):
+        """One tick for all games.  actions: int [E, A] | float [E, A, 4] score vectors (arg-maxed in-kernel) |
+        float [E, A, 3] when continuous | {} (every running game ties).  u: optional float64 [E, A] of random()
+        values to use for this call's shots instead of the generator.  Returns the env-owned tensors
+        (obs [E, A, D] f32, rew [E, A] f32, done [E, A] bool), overwritten by the next call."""
+        act_t, kind, empty = self._pack_actions(actions)
+        if u is None and self.rng == "python":
+            u = self._draw_jitter(act_t, kind, empty)
+        u_ptr = None
+        if u is not None:
+            ut = torch.as_tensor(np.asarray(u, dtype=np.float64) if not torch.is_tensor(u) else u)
+            self._u = ut.to(device=self.device, dtype=torch.float64).contiguous()
+            if self._u.shape != (self.n_envs, self._A):
+                raise ValueError(f"u must have shape ({self.n_envs}, {self._A})")
+            u_ptr = self._u.data_ptr()
+        flags = (_lib.F_AUTO_RESET if self.auto_reset else 0) | (_lib.F_EMPTY_CALL if empty else 0)
+        fn = self._lib.bsx_step_continuous if self.continuous_actions else self._lib.bsx_step_discrete
+        _lib.check(fn(self._state.data_ptr(), self.n_envs, self.n_agents,
+                      act_t.data_ptr() if act_t is not None else None, kind, u_ptr,
+                      self._obs.data_ptr(), self._rew.data_ptr(), self._done.data_ptr(),
+                      self._env_done.data_ptr(), self._winner.data_ptr(), ctypes.byref(self._cfg),
+                      flags, self.seed, self.env_offset, self._stream()), "bsx_step")
+        if self._mirror:
+            self._sync_mirror()
+        return self._obs, self._rew, self._done.view(torch.bool)
+
+    def _sync_mirror(self):
+        st = self.export_state(("palive", "tick", "env_done"))
+        self._h_alive = st["palive"].cpu().numpy().astype(bool)
+        self._h_tick = st["tick"].cpu().numpy().astype(np.int64)
+        self._h_done = st["env_done"].cpu().numpy().astype(bool)
+
+    def step(self, actions, u=None):
+        """The reference's 4-tuple: (observations, rewards, dones, infos), each a dict keyed by agent id."""
+        if self._compat:
+            return self._step_compat(actions, u)
+        obs, rew, done = self.step_batch(actions, u)
+        return (self._agent_views(obs), self._agent_views(rew), self._agent_views(done),
+                {a: {} for a in self.possible_agents})
+
+    def _step_compat(self, actions, u):
+        ids = self.possible_agents
+        if self.continuous_actions and isinstance(actions, dict):      # battle_env.py:295-297 clips the caller's dict
+            for k, v in actions.items():
+                actions[k] = np.clip(v, -1.0, 1.0)
+        was_done = bool(self._h_done[0])
+        alive_before = self._h_alive[0].copy()
+        if isinstance(actions, dict) and len(actions) and not was_done:
+            missing = [a for i, a in enumerate(ids) if alive_before[i] and a not in actions]
+            if missing and alive_before.any() and self._h_tick[0] + 1 < self.tie_tick:
+                raise KeyError(missing[0])                              # battle_env.py:326
+        if isinstance(actions, dict) and len(actions):
+            # normalise per-agent values: ints, 0-d arrays, 4-vectors (arg-maxed, battle_env.py:327-328), 3-vectors
+            norm = {}
+            for a in ids:
+                v = actions.get(a)
+                if v is None:
+                    v = np.zeros(3) if self.continuous_actions else -1
+                v = np.asarray(v)
+                if self.continuous_actions:
+                    v = v.astype(np.float64).reshape(1, 3)
+                elif v.ndim >= 1 and v.size > 1:
+                    v = np.asarray([int(np.argmax(v))])
+                else:
+                    v = v.reshape(1).astype(np.int64)
+                norm[a] = v
+            actions = norm
+        obs, rew, done = self.step_batch(actions, None if u is None else np.asarray(u, np.float64).reshape(1, -1))
+        o = obs[0].cpu().numpy()
+        r = rew[0].cpu().numpy()
+        d = self._done[0].cpu().numpy().astype(bool)
+        ed = bool(self._h_done[0])
+        if ed and not was_done:
+            self.dones = {a: True for a in ids}                          # win()/tie() rebind the dict (:478,:494)
+            self._winner_name = _lib.WINNER_NAMES[int(self._winner[0])]
+        elif not was_done:
+            for i, a in enumerate(ids):
+                if d[i]:
+                    self.dones[a] = True
+        rewards = {a: (int(round(float(r[i]))) if self._int_rewards else float(r[i])) for i, a in enumerate(ids)}
+        return ({a: o[i].copy() for i, a in enumerate(ids)}, rewards, self.dones, {a: {} for a in ids})
+
+    # ------------------------------------------------------------------ observe (battle_env.py:202-244)
+    def observe(self, agent):
+        _lib.check(self._lib.bsx_observe(self._state.data_ptr(), self.n_envs, self.n_agents, self._obs.data_ptr(),
+                                         self._stream()), "bsx_observe")
+        i = self._idx[agent]
+        if self._compat:
+            return self._obs[0, i].cpu().numpy().copy()
+        return self._obs[:, i]
+
+    # ------------------------------------------------------------------ public attributes callers read
+    @property
+    def agents(self):
+        """Drop-in mode: ids of the planes still alive, in id order (battle_env.py:109,274,357).  Batched: all ids."""
+        if self._compat:
+            return [a for i, a in enumerate(self.possible_agents) if self._h_alive[0, i]]
+        return self.possible_agents[:]
+
+    @property
+    def env_done(self):
+        return bool(self._h_done[0]) if self._compat else self._env_done.view(torch.bool)
+
+    @property
+    def winner(self):
+        """Drop-in: 'none' | 'red' | 'blue' | 'tie'.  Batched: uint8 codes 0..3 in that order."""
+        return self._winner_name if self._compat else self._winner
+
+    def counters(self):
+        """int32 [E, 4] host array: games finished, ties, red wins, blue wins (battle_env.py:169-170,102-103)."""
+        return self.export_state(("counters",))["counters"].cpu().numpy().reshape(self.n_envs, 4)
+
+    @property
+    def total_games(self):
+        c = self.counters()[:, 0]
+        return int(c[0]) if self._compat else c
+
+    @property
+    def ties(self):
+        c = self.counters()[:, 1]
+        return int(c[0]) if self._compat else c
+
+    def wins(self):
+        """battle_env.py:449-455 (summed over games when batched)."""
+        c = self.counters().sum(0)
+        return "Wins by red: {}\nWins by blue: {}\nTied games: {}\nWin rate: {}".format(c[2], c[3], c[1], c[2] / c[0])
+
+    def make_discrete(self, actions_dict):
+        return {a: np.argmax(v) for a, v in actions_dict.items()}        # battle_env.py:463-467
+
+    # ------------------------------------------------------------------ state export / checkpoint
+    _EXPORT_SPEC = {  # name -> (dtype, per-env shape builder)
+        "px": (torch.int32, lambda A: (A,)), "py": (torch.int32, lambda A: (A,)), "pdir": (torch.float64, lambda A: (A,)),
+        "php": (torch.int32, lambda A: (A,)), "palive": (torch.uint8, lambda A: (A,)),
+        "base_xy": (torch.int32, lambda A: (4,)), "bhp": (torch.int32, lambda A: (2,)), "tick": (torch.int32, lambda A: ()),
+        "env_done": (torch.uint8, lambda A: ()), "winner": (torch.uint8, lambda A: ()),
+        "bl_live": (torch.uint8, lambda A: (A, 12)), "bl_x": (torch.int32, lambda A: (A, 12)),
+        "bl_y": (torch.int32, lambda A: (A, 12)), "bl_dir": (torch.float64, lambda A: (A, 12)),
+        "counters": (torch.int32, lambda A: (4,)),
+    }
+
+    def export_state(self, fields=None):
+        """Unpacked copy of the game state as device tensors (bsx_export_state): planes, bases, bullets, flags, counters."""
+        fields = tuple(fields) if fields is not None else _lib.EXPORT_FIELDS
+        out, ex = {}, _lib.BsxExport()
+        for f in fields:
+            dt, shp = self._EXPORT_SPEC[f]
+            out[f] = torch.empty((self.n_envs, *shp(self._A)), dtype=dt, device=self.device)
+            setattr(ex, f, out[f].data_ptr())
+        _lib.check(self._lib.bsx_export_state(self._state.data_ptr(), self.n_envs, self.n_agents, ctypes.byref(ex),
+                                              self._stream()), "bsx_export_state")
+        return out
+
+    def state_dict(self):
+        """Snapshot of the raw device state (the reference never checkpoints env state; here it is one tensor)."""
+        return {"state": self._state.clone(), "env_done": self._env_done.clone(), "winner": self._winner.clone(),
+                "done": self._done.clone(), "reset_nonce": self._reset_nonce}
+
+    def load_state_dict(self, sd):
+        self._state.copy_(sd["state"]); self._env_done.copy_(sd["env_done"]); self._winner.copy_(sd["winner"])
+        self._done.copy_(sd["done"]); self._reset_nonce = int(sd["reset_nonce"])
+
+    # ------------------------------------------------------------------ rendering: out of scope
+    def render(self, mode="human"):
+        if self.show:
+            warnings.warn("rendering is out of scope for the MI355X step() path; export_state() gives the poses", stacklevel=2)
+            self.show = False
+
+    def start_recording(self, path):
+        warnings.warn("video recording is out of scope for the MI355X step() path", stacklevel=2)
+
+    def export_video(self):
+        pass
+
+    def close(self):
+        pass

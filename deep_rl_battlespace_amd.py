@@ -1,0 +1,16 @@
+"""Import shim: the package directory is named `deep-rl-battlespace_amd` (not a Python identifier), so this module
+loads it under the importable name `deep_rl_battlespace_amd` and replaces itself with it in sys.modules.
+
+    import deep_rl_battlespace_amd as bsx
+    env = bsx.envs.battle_env.parallel_env(n_envs=65536)
+"""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "deep-rl-battlespace_amd")
+_spec = importlib.util.spec_from_file_location(__name__, os.path.join(_dir, "__init__.py"),
+                                               submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules[__name__] = _mod
+_spec.loader.exec_module(_mod)

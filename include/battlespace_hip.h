@@ -1,0 +1,120 @@
+/* battlespace_hip.h -- C ABI of libbattlespace_hip.so: the batched Battlespace step() path on MI355X (gfx950).
+ *
+ * The reference (WilliamFlinchbaugh/Deep-RL-Battlespace) has no FFI: its hot path is the Python class
+ * `parallel_env` (envs/battle_env.py:61).  This header is the boundary a maintainer binds instead (ctypes stub in
+ * INTEGRATION.md); each entry point names the reference code it replaces.  Everything is plain C: device pointers,
+ * sizes, a hipStream_t passed as void*.  No torch types.
+ *
+ * Conventions
+ *   - E = number of independent games (envs), n = planes per team, A = 2n agents per env, D = 3n+2 observation floats.
+ *   - Agent a of env e is row e*A + a of every per-agent array; a < n is red ("plane{a}"), a >= n blue -- the order
+ *     of `possible_agents` (battle_env.py:106-108).
+ *   - All pointers are DEVICE memory owned by the caller.  Calls only enqueue work on `stream` and return; they never
+ *     synchronise and never allocate.  Return value: 0 = ok, <0 = argument error (BSX_E_*), >0 = a hipError_t.
+ *   - Outputs are overwritten by the next call; inputs are read-only for the duration of the kernel.
+ *   - Supported n: 1..16.
+ */
+#ifndef BATTLESPACE_HIP_H
+#define BATTLESPACE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSX_ABI_VERSION 1
+#define BSX_BULLET_SLOTS 12 /* a bullet is removed at the latest on its 12th update (sprites.py:334-337: 12*45 >= 500) */
+#define BSX_MAX_N 16
+
+#define BSX_E_ARG (-1)     /* null pointer / bad size / unsupported n */
+#define BSX_E_ALIGN (-2)   /* a pointer is not aligned as documented */
+
+/* winner codes (battle_env.py:254,474,490: 'none' | 'red' | 'blue' | 'tie') */
+#define BSX_WINNER_NONE 0
+#define BSX_WINNER_RED 1
+#define BSX_WINNER_BLUE 2
+#define BSX_WINNER_TIE 3
+
+/* Constructor kwargs of parallel_env that reach step() (battle_env.py:73, :178-182). */
+typedef struct BsxRewards {
+    double hit_base_reward;   /* default 100 */
+    double hit_plane_reward;  /* default 10  */
+    double miss_punishment;   /* default -1  */
+    double die_punishment;    /* default -5  */
+    double lose_punishment;   /* default -20 */
+} BsxRewards;
+
+/* Flags for bsx_step_* */
+#define BSX_F_AUTO_RESET 1u  /* a call on a finished env re-spawns it (Philox) instead of the inert step of battle_env.py:303-306 */
+#define BSX_F_EMPTY_CALL 2u  /* step({}) : every running env ties (battle_env.py:309-313) */
+
+/* Action encodings for bsx_step_discrete */
+#define BSX_ACT_I32 0        /* int32 [E*A]: 0 fwd, 1 shoot, 2 left, 3 right, anything else = no movement (battle_env.py:399-417) */
+#define BSX_ACT_LOGITS_F32 1 /* float32 [E*A*4]: flat argmax, first maximum wins (battle_env.py:327-328) */
+/* Action encodings for bsx_step_continuous: [E*A*3] = speed, turn, shoot in [-1,1], clipped in-kernel (battle_env.py:295-297) */
+#define BSX_ACT_F32 0
+#define BSX_ACT_F64 1
+
+int bsx_abi_version(void);
+
+/* Size in bytes of the opaque per-job state block for E envs of n-per-team (256-byte aligned base required).
+ * Holds what parallel_env holds between calls (battle_env.py:165-184,254-276): planes, bases, bullets, time, flags,
+ * win/tie counters, plus the 361-entry discrete-heading displacement table. */
+int bsx_state_bytes(int64_t E, int n, size_t* bytes);
+
+/* One-time initialisation of a state block: zeroes it and uploads the heading table
+ * (21.5*cos(-radians(d)), 21.5*sin(-radians(d)), d = 0..360, host libm: sprites.py:35-42 with speed*time = 215*0.1).
+ * Counters start at 0.  Every env starts "finished"; call bsx_reset before stepping. */
+int bsx_state_init(void* state, int64_t E, int n, void* stream);
+
+/* parallel_env.reset (battle_env.py:246-279; Plane.reset sprites.py:74-91; Base.reset sprites.py:238-252).
+ *   reset_mask  nullable uint8[E]: only envs with a non-zero byte are reset (null = all).
+ *   spawn       nullable int32[E][4+3A]: base_red x,y, base_blue x,y, then x,y,dir per plane in id order (parity runs
+ *               inject what the reference drew); null = draw in-kernel from Philox4x32-10 keyed by
+ *               (seed, env_offset+e, nonce) with the reference's inclusive ranges.
+ *   obs         nullable float32[E*A*D]: reset observations (written for every env, reset or not).
+ * Counters (games, ties, wins) persist across resets as in the reference. */
+int bsx_reset(void* state, int64_t E, int n, const uint8_t* reset_mask, const int32_t* spawn,
+              uint64_t seed, uint64_t nonce, int64_t env_offset, float* obs, void* stream);
+
+/* parallel_env.step, discrete actions (battle_env.py:281-381, process_action :383-417).
+ *   actions     per `action_kind`
+ *   u           nullable float64[E*A]: the random.random() value for agent a's shot this call (sprites.py:314);
+ *               null = Philox keyed by (seed, env_offset+e, games played, tick, agent).
+ *   obs, rew, done  float32[E*A*D], float32[E*A], uint8[E*A]
+ *   env_done, winner nullable uint8[E] copies of the per-env flags (battle_env.py:276,254)
+ */
+int bsx_step_discrete(void* state, int64_t E, int n, const void* actions, int action_kind, const double* u,
+                      float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner,
+                      const BsxRewards* cfg, uint32_t flags, uint64_t seed, int64_t env_offset, void* stream);
+
+/* parallel_env.step, continuous actions (battle_env.py:295-297, :418-424). */
+int bsx_step_continuous(void* state, int64_t E, int n, const void* actions, int action_kind, const double* u,
+                        float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner,
+                        const BsxRewards* cfg, uint32_t flags, uint64_t seed, int64_t env_offset, void* stream);
+
+/* parallel_env.observe for every agent (battle_env.py:202-244): obs float32[E*A*D].  No state change. */
+int bsx_observe(void* state, int64_t E, int n, float* obs, void* stream);
+
+/* Unpacked copy of the game state, for tests / checkpointing / rendering one env on the host.
+ * Any pointer may be null.  Shapes: px,py,php int32[E*A]; pdir float64[E*A]; palive uint8[E*A];
+ * base_xy int32[E*4] (red x,y, blue x,y); bhp int32[E*2]; tick int32[E]; env_done,winner uint8[E];
+ * bl_live uint8[E*A*12]; bl_x,bl_y int32[E*A*12]; bl_dir float64[E*A*12] (slot = birth tick % 12);
+ * counters int32[E*4] = games, ties, red wins, blue wins (battle_env.py:169-170,102-103). */
+typedef struct BsxExport {
+    int32_t* px; int32_t* py; double* pdir; int32_t* php; uint8_t* palive;
+    int32_t* base_xy; int32_t* bhp; int32_t* tick; uint8_t* env_done; uint8_t* winner;
+    uint8_t* bl_live; int32_t* bl_x; int32_t* bl_y; double* bl_dir; int32_t* counters;
+} BsxExport;
+int bsx_export_state(const void* state, int64_t E, int n, const BsxExport* out, void* stream);
+
+/* Host helper: the call number on which the time-limit tie fires for n-per-team -- the reference accumulates
+ * total_time += 0.1 in binary64 and compares >= 10+2n (battle_env.py:168,316-319): 121, 141, 161, 181, 200 ... */
+int bsx_tie_tick(int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BATTLESPACE_HIP_H */

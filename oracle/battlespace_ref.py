@@ -416,8 +416,10 @@ class RefEnv:
         bx = np.zeros((A, BULLET_SLOTS), np.int32)
         by = np.zeros((A, BULLET_SLOTS), np.int32)
         bd = np.zeros((A, BULLET_SLOTS), np.float64)
+        # the time-limit tie call advances the clock but not the bullets: label slots by physics ticks
+        ptick = self.tick - 1 if (self.env_done and self.winner == "tie" and self.total_time >= self.max_time) else self.tick
         for sh, x, y, d, age in self.bullets:
-            s = (self.tick - age + 1) % BULLET_SLOTS
+            s = (ptick - age + 1) % BULLET_SLOTS
             assert not live[sh, s]
             live[sh, s] = True; bx[sh, s] = x; by[sh, s] = y; bd[sh, s] = d
         return dict(px=np.asarray(self.px, np.int32), py=np.asarray(self.py, np.int32),

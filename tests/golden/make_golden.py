@@ -32,7 +32,8 @@ Trace schema (flat step axis S, episodes delimited by ep_ptr):
   winner[S] i8 (0 none, 1 red, 2 blue, 3 tie)
   px,py[S,A] i32, pdir[S,A] f64, php[S,A] i32, palive[S,A] bool
   bhp[S,2] i32, tick[S] i32 (count of time increments), total_time[S] f64
-  bl_live/bl_x/bl_y/bl_dir[S,A,12]: live bullets of shooter a; slot = birth tick % 12
+  bl_live/bl_x/bl_y/bl_dir[S,A,12]: live bullets of shooter a; slot = birth tick % 12 (birth tick = the
+                       1-based count of physics ticks at which the shot was fired)
   total_games/ties/wins_red/wins_blue[S] i32 (env counters, persist across resets)
 """
 import json
@@ -225,13 +226,16 @@ class Recorder:
         r["bhp"].append([env.team["red"]["base"].hp, env.team["blue"]["base"].hp])
         tick = int(round(env.total_time / env.time_step))
         r["tick"].append(tick); r["total_time"].append(float(env.total_time))
+        # the time-limit tie call advances the clock but not the bullets (battle_env.py:316-323): label slots by
+        # the number of ticks on which bullets were actually updated
+        ptick = tick - 1 if (env.env_done and env.winner == "tie" and env.total_time >= env.max_time) else tick
         live = np.zeros((self.A, K), bool); bx = np.zeros((self.A, K), np.int32)
         by = np.zeros((self.A, K), np.int32); bd = np.zeros((self.A, K))
         for b in env.bullets:
             i = ids.index(b.agent_id)
             age = int(round(b.dist_travelled / 45.0))
             assert 1 <= age <= 11 and abs(b.dist_travelled - 45.0 * age) < 1e-9
-            s = (tick - age + 1) % K
+            s = (ptick - age + 1) % K
             assert not live[i, s]
             live[i, s] = True; bx[i, s] = b.rect.centerx; by[i, s] = b.rect.centery; bd[i, s] = float(b.direction)
         r["bl_live"].append(live); r["bl_x"].append(bx); r["bl_y"].append(by); r["bl_dir"].append(bd)
