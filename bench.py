@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- agent-steps/sec of the fused Battlespace step() on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: ONE step() of every game a rank owns (65 536 games of 1v1 per
+GPU = BASELINE.json configs[1]; N GPUs = N independent shards of 65 536, configs[3] at N=8; no collective on the
+step path).  Actions are i.i.d. uniform over {0,1,2,3} (torch Philox generator, seed 1234+rank), generated before
+the timed region and resident in HBM; bullet jitter and auto-reset spawns are drawn in-kernel (Philox4x32-10).
+Finished games are re-spawned by the next step() call (auto_reset), so resets are inside the measurement.
+
+The K timed steps are launched as replays of a HIP graph holding `--graph-len` consecutive step() launches (the
+launch-bound inner loop of a rollout; `--mode eager` times one Python call per step instead).  Timing: barrier +
+synchronize on both sides, max over ranks.  Rank 0 prints ONE JSON line.
+
+roofline: the step kernel is HBM-bound integer/fp64 work.  achieved = ALGORITHMIC bytes per launch (SURVEY.md
+section 8d: 260 B per agent-step at 1v1, 289.3 B at 4v4, x E*A agent-steps per launch) / the kernel's average launch
+duration, measured here with HIP events on the launch stream over the timed region.  peak = 8 TB/s.
+cpu_baseline: the CPU oracle (oracle/battlespace_ref.py, the scalar Python restatement of the reference's step()) on
+configs[0] -- 1 game of 1v1, the same uniform random actions, reset on done -- timed on one host core of this box.
+"""
+import argparse
+import json
+import os
+import platform
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+B_ALG = {1: 260.0, 2: 279.25, 3: 285.67, 4: 289.3}   # algorithmic bytes per agent-step (SURVEY.md section 8d formula)
+HBM_PEAK_GBS = 8000.0                                 # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def b_alg(n):
+    """[13 + 146 + 13/A] + [13 + 50 + 5/A] + [4 + 4(3n+2) + 4 + 1] bytes per agent-step."""
+    A = 2 * n
+    return (13 + 146 + 13 / A) + (13 + 50 + 5 / A) + (4 + 4 * (3 * n + 2) + 4 + 1)
+
+
+def cpu_baseline(seconds_target=12.0):
+    """configs[0]: the oracle's step() on 1 game of 1v1, uniform random actions (seed 1234), reset on done; 1 core."""
+    import random
+    import numpy as np
+    from oracle import battlespace_ref as ref
+    random.seed(1234)
+    env = ref.RefEnv(n_agents=1)
+    ids = env.possible_agents
+    acts = np.random.default_rng(1234).integers(0, 4, size=(200_000, 2)).tolist()
+    env.reset()
+    for k in range(2000):                                   # warm-up
+        if env.env_done:
+            env.reset()
+        env.step({ids[0]: acts[k][0], ids[1]: acts[k][1]})
+    calls = 0
+    t0 = time.perf_counter()
+    while True:
+        for k in range(10_000):
+            if env.env_done:
+                env.reset()
+            a = acts[(calls + k) % 200_000]
+            env.step({ids[0]: a[0], ids[1]: a[1]})
+        calls += 10_000
+        dt = time.perf_counter() - t0
+        if dt >= seconds_target:
+            break
+    return {"value": round(calls * 2 / dt, 1), "unit": "agent-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{calls} step() calls of 1 game x 1v1 (configs[0]), uniform random actions seed 1234, "
+                      f"reset on done, {dt:.1f} s on 1 of {os.cpu_count()} host cores ({platform.processor() or platform.machine()}, "
+                      f"CPython {platform.python_version()}); oracle/battlespace_ref.py"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--envs-per-gpu", type=int, default=65536)
+    ap.add_argument("--n-agents", type=int, default=1, help="planes per team (1 = configs[1], 4 = configs[2])")
+    ap.add_argument("--mode", choices=("graph", "eager"), default="graph")
+    ap.add_argument("--graph-len", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import deep_rl_battlespace_amd as bsx
+    from deep_rl_battlespace_amd import sharding
+
+    rank, world, local_rank = sharding.rank_world()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)      # RCCL; used for the barrier / max-time reduction only
+
+    n, E = args.n_agents, args.envs_per_gpu
+    A = 2 * n
+    env = sharding.make_shard(E * world, rank, world, n_agents=n, device=dev, seed=1234, auto_reset=True)
+    env.reset()
+    K, W = args.steps, args.warmup
+    G = max(1, min(args.graph_len, K))
+    while K % G:
+        G -= 1
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    actions = torch.randint(0, 4, (G, E, A), generator=gen, device=dev, dtype=torch.int32)
+
+    if args.mode == "graph":
+        graph, _ = env.capture_steps(actions)
+
+        def run(steps):
+            for _ in range(steps // G):
+                graph.replay()
+            for t in range(steps % G):
+                env.step_batch(actions[t])
+    else:
+        def run(steps):
+            for t in range(steps):
+                env.step_batch(actions[t % G])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    run(W)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run(K)
+    ev1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / K                  # average launch-to-launch duration on the launch stream
+    if world > 1:
+        t = torch.tensor([dt, kernel_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, kernel_ms = float(t[0]), float(t[1])
+
+    games = sharding.reduce_counters(sharding.local_counter_sums(env))   # logging only, after the timed region
+    if rank == 0:
+        agent_steps = E * world * A * K
+        bytes_per_launch = b_alg(n) * E * A
+        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = f"E{E}_n{n}"
+                if key in tj:
+                    traffic = tj[key]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "agent-steps/sec", "value": round(agent_steps / dt, 1), "unit": "agent-steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 6),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64/i16", "data": "synthetic",
+            "config": {"workload": f"{E} games x {n}v{n} per GPU, uniform random discrete actions, fused HIP step(), auto-reset "
+                                   f"(BASELINE.json configs[{1 if n == 1 else 2}]{' x ' + str(world) + ' shards' if world > 1 else ''})",
+                       "envs_per_gpu": E, "n_agents_per_team": n, "agents_per_env": A, "launch": args.mode,
+                       "graph_len": G if args.mode == "graph" else None, "parallelism": f"{world} independent env shards, no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel": f"bsx_step_kernel<{n if n <= 4 else 0},false>", "avg_launch_us": round(kernel_ms * 1e3, 3),
+                         "algorithmic_bytes_per_launch": round(bytes_per_launch), "bytes_per_agent_step": round(b_alg(n), 2)},
+            "games_finished": int(games[0]), "ties": int(games[1]), "red_wins": int(games[2]), "blue_wins": int(games[3]),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

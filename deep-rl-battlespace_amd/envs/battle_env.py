@@ -301,16 +301,64 @@ class parallel_env:
             if self._u.shape != (self.n_envs, self._A):
                 raise ValueError(f"u must have shape ({self.n_envs}, {self._A})")
             u_ptr = self._u.data_ptr()
-        flags = (_lib.F_AUTO_RESET if self.auto_reset else 0) | (_lib.F_EMPTY_CALL if empty else 0)
-        fn = self._lib.bsx_step_continuous if self.continuous_actions else self._lib.bsx_step_discrete
-        _lib.check(fn(self._state.data_ptr(), self.n_envs, self.n_agents,
-                      act_t.data_ptr() if act_t is not None else None, kind, u_ptr,
-                      self._obs.data_ptr(), self._rew.data_ptr(), self._done.data_ptr(),
-                      self._env_done.data_ptr(), self._winner.data_ptr(), ctypes.byref(self._cfg),
-                      flags, self.seed, self.env_offset, self._stream()), "bsx_step")
+        self._launch(act_t.data_ptr() if act_t is not None else None, kind, empty, u_ptr,
+                     self._obs.data_ptr(), self._rew.data_ptr(), self._done.data_ptr())
         if self._mirror:
             self._sync_mirror()
         return self._obs, self._rew, self._done.view(torch.bool)
+
+    def _launch(self, act_ptr, kind, empty, u_ptr, obs_ptr, rew_ptr, done_ptr):
+        """Enqueue one fused step kernel on the current stream (no sync, no allocation: graph-capturable)."""
+        flags = (_lib.F_AUTO_RESET if self.auto_reset else 0) | (_lib.F_EMPTY_CALL if empty else 0)
+        fn = self._lib.bsx_step_continuous if self.continuous_actions else self._lib.bsx_step_discrete
+        _lib.check(fn(self._state.data_ptr(), self.n_envs, self.n_agents, act_ptr, kind, u_ptr,
+                      obs_ptr, rew_ptr, done_ptr, self._env_done.data_ptr(), self._winner.data_ptr(),
+                      ctypes.byref(self._cfg), flags, self.seed, self.env_offset, self._stream()), "bsx_step")
+
+    def capture_steps(self, actions, store=False):
+        """Capture T consecutive step() launches into ONE HIP graph (the launch-bound inner loop of a rollout).
+
+        actions: static device tensor [T, E, A] int32 (discrete), [T, E, A, 4] float32 score vectors, or
+                 [T, E, A, 3] float32/float64 (continuous); step t of every replay reads actions[t] -- refill the
+                 tensor in place between replays.
+        store:   False = every step overwrites the env-owned obs/rew/done tensors (as step_batch does);
+                 True  = step t writes slice t of new [T, E, A, ...] tensors (a rollout buffer in HBM).
+        Returns (graph, outputs): graph.replay() runs the T steps; outputs = (obs, rew, done) tensors.
+        Needs rng='philox' (no host draws inside a graph)."""
+        if self.rng != "philox":
+            raise ValueError("capture_steps needs rng='philox'")
+        E, A, D = self.n_envs, self._A, self.obs_size
+        if not torch.is_tensor(actions) or actions.device != self.device or not actions.is_contiguous():
+            raise ValueError("actions must be a contiguous tensor on the env's device")
+        T = actions.shape[0]
+        if self.continuous_actions:
+            ok, kind = actions.shape == (T, E, A, 3) and actions.dtype in (torch.float32, torch.float64), \
+                (_lib.ACT_F64 if actions.dtype == torch.float64 else _lib.ACT_F32)
+        elif actions.dim() == 4:
+            ok, kind = actions.shape == (T, E, A, 4) and actions.dtype == torch.float32, _lib.ACT_LOGITS_F32
+        else:
+            ok, kind = actions.shape == (T, E, A) and actions.dtype == torch.int32, _lib.ACT_I32
+        if not ok:
+            raise ValueError(f"bad actions tensor for capture: shape {tuple(actions.shape)}, dtype {actions.dtype}")
+        if store:
+            obs = torch.empty((T, E, A, D), dtype=torch.float32, device=self.device)
+            rew = torch.empty((T, E, A), dtype=torch.float32, device=self.device)
+            done = torch.empty((T, E, A), dtype=torch.uint8, device=self.device)
+        else:
+            obs, rew, done = self._obs, self._rew, self._done
+        step_bytes = actions[0].numel() * actions.element_size()
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize(self.device)
+        with torch.cuda.graph(graph):
+            for t in range(T):
+                if store:
+                    self._launch(actions.data_ptr() + t * step_bytes, kind, False, None,
+                                 obs[t].data_ptr(), rew[t].data_ptr(), done[t].data_ptr())
+                else:
+                    self._launch(actions.data_ptr() + t * step_bytes, kind, False, None,
+                                 obs.data_ptr(), rew.data_ptr(), done.data_ptr())
+        self._graph_keepalive = (actions, obs, rew, done)
+        return graph, (obs, rew, done.view(torch.bool))
 
     def _sync_mirror(self):
         st = self.export_state(("palive", "tick", "env_done"))
