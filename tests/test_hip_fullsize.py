@@ -1,0 +1,143 @@
+"""Full-size checks of the HIP step() path on the MI355X (BASELINE.json configs[1] and [2] sizes): bit-exact against
+the C oracle in the PRODUCTION configuration (auto-reset, in-kernel Philox jitter and spawns), plus size-independent
+properties: determinism, shard invariance, state invariants, counter conservation."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref
+from trace_util import OBS_ATOL, OBS_RTOL
+
+pytestmark = pytest.mark.gpu
+
+
+def _env(**kw):
+    import deep_rl_battlespace_amd as bsx
+    return bsx.parallel_env(**kw)
+
+
+def _actions(T, E, A, seed, p_shoot=0.25, device="cuda"):
+    g = torch.Generator(device=device); g.manual_seed(seed)
+    a = torch.randint(0, 4, (T, E, A), generator=g, device=device, dtype=torch.int32)
+    if p_shoot != 0.25:
+        m = torch.rand((T, E, A), generator=g, device=device) < p_shoot
+        a = torch.where(m, torch.ones_like(a), a)
+    return a
+
+
+def _compare_with_c_oracle(E, n, T, seed, p_shoot, check_every, env_offset=0):
+    A = 2 * n
+    env = _env(n_agents=n, n_envs=E, seed=seed, auto_reset=True, env_offset=env_offset)
+    c = cref.CRefBatch(E, n_agents=n, seed=seed, auto_reset=True, env_offset=env_offset)
+    o_h = env.reset()
+    o_c = c.reset()
+    np.testing.assert_allclose(torch.stack([o_h[a] for a in env.possible_agents], 1).cpu().numpy(), o_c, rtol=OBS_RTOL, atol=OBS_ATOL)
+    acts = _actions(T, E, A, seed + 1, p_shoot)
+    acts_h = acts.cpu().numpy()
+    n_exact = n_vals = 0
+    for t in range(T):
+        obs, rew, done = env.step_batch(acts[t])
+        co, cr, cd = c.step(acts_h[t])
+        o = obs.cpu().numpy()
+        assert np.array_equal(done.cpu().numpy(), cd), f"step {t}: done"
+        assert np.array_equal(rew.cpu().numpy().astype(np.float64), cr), f"step {t}: rew"
+        assert np.array_equal(env.env_done.cpu().numpy(), c.env_done.astype(bool)) and np.array_equal(env.winner.cpu().numpy(), c.winner)
+        np.testing.assert_allclose(o, co, rtol=OBS_RTOL, atol=OBS_ATOL, err_msg=f"step {t}: obs")
+        n_exact += int((o == co).sum()); n_vals += o.size
+        if t % check_every == check_every - 1 or t == T - 1:
+            sh = {k: v.cpu().numpy() for k, v in env.export_state().items()}
+            sc = c.export_state()
+            for f in ("px", "py", "pdir", "php", "palive", "base_xy", "bhp", "tick", "env_done", "winner", "bl_live", "counters"):
+                assert np.array_equal(sh[f], sc[f]), f"step {t}: {f}"
+            m = sc["bl_live"].astype(bool)
+            for f in ("bl_x", "bl_y", "bl_dir"):
+                assert np.array_equal(sh[f][m], sc[f][m]), f"step {t}: {f}"
+    assert n_exact >= n_vals * (1 - 1e-3), f"only {n_exact}/{n_vals} observation values bit-identical"
+    return env
+
+
+def test_C2_65536x1v1_bit_exact_vs_c_oracle():
+    """configs[1]: 65 536 games of 1v1, uniform random actions, 260 calls (two full games + auto-resets)."""
+    env = _compare_with_c_oracle(65536, 1, 260, seed=1234, p_shoot=0.25, check_every=65)
+    c = env.counters().sum(0)
+    assert c[0] == c[1] + c[2] + c[3] and c[0] >= 2 * 65536      # every finished game is a tie or a win
+
+
+def test_C3_65536x4v4_bit_exact_vs_c_oracle():
+    """configs[2]: 65 536 games of 4v4 (8 agents, all-pairs staged in LDS), 200 calls across the 181-call tie."""
+    _compare_with_c_oracle(65536, 4, 200, seed=99, p_shoot=0.25, check_every=100)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 6])
+def test_shoot_heavy_play_bit_exact_vs_c_oracle(n):
+    """Every ring slot in use, same-step multi-hits and kill chains, wins by base kill; incl. the generic-n kernel (6)."""
+    _compare_with_c_oracle(4096, n, 190 + 20 * n, seed=5 + n, p_shoot=0.8, check_every=50)
+
+
+def test_deterministic_and_shard_invariant():
+    """Same seed -> same games; and a job split into shards (env_offset) plays the same games as one batch:
+    the in-kernel generator is keyed by the GLOBAL env index (what makes the 8-GPU layout a pure partition)."""
+    E, n, T = 8192, 2, 170
+    A = 2 * n
+    acts = _actions(T, E, A, 77, p_shoot=0.6)
+    outs = []
+    for parts in (1, 1, 4):
+        q = E // parts
+        envs = [_env(n_agents=n, n_envs=q, seed=42, auto_reset=True, env_offset=i * q) for i in range(parts)]
+        for v in envs:
+            v.reset()
+        trace = []
+        for t in range(T):
+            o = [v.step_batch(acts[t, i * q:(i + 1) * q].contiguous()) for i, v in enumerate(envs)]
+            trace.append(tuple(torch.cat([x[k] for x in o]).clone() for k in range(3)))
+        outs.append((trace, torch.cat([v.export_state(("px", "py", "bl_live", "counters"))["px"] for v in envs])))
+    for other in outs[1:]:
+        for (o0, r0, d0), (o1, r1, d1) in zip(outs[0][0], other[0]):
+            assert torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(d0, d1)
+        assert torch.equal(outs[0][1], other[1])
+
+
+def test_state_invariants_at_full_size():
+    """Properties that hold for any number of games: poses inside the clamp box, headings in [0, 360], hit points in
+    range, live bullets inside the field and younger than 12 updates, observation ranges, done/alive consistency."""
+    E, n = 65536, 1
+    env = _env(n_agents=n, n_envs=E, seed=3, auto_reset=True)
+    env.reset()
+    acts = _actions(50, E, 2, 11, p_shoot=0.7)
+    for rep in range(5):
+        for t in range(50):
+            obs, rew, done = env.step_batch(acts[t])
+        st = env.export_state()
+        assert int(st["px"].min()) >= 25 and int(st["px"].max()) <= 1175
+        assert int(st["py"].min()) >= 24 and int(st["py"].max()) <= 776
+        assert float(st["pdir"].min()) >= 0 and float(st["pdir"].max()) <= 360
+        assert int(st["php"].min()) >= 0 and int(st["php"].max()) <= 4
+        assert torch.equal(st["palive"].bool(), st["php"] > 0)
+        live = st["bl_live"].bool()
+        assert int(st["bl_x"][live].min()) >= 0 and int(st["bl_x"][live].max()) <= 1200
+        assert int(st["bl_y"][live].min()) >= 0 and int(st["bl_y"][live].max()) <= 800
+        assert int(live.sum(-1).max()) <= 11
+        assert int(st["tick"].max()) <= env.tie_tick
+        running = ~st["env_done"].bool()
+        assert torch.equal(done[running], ~st["palive"].bool()[running]) and bool(done[~running].all())
+        o = obs[st["palive"].bool() & running[:, None]]
+        assert float(o[:, 0].min()) >= -1 and float(o[:, 0].max()) <= 1 and float(o[:, 1].abs().max()) <= 0.5
+        c = st["counters"].sum(0)
+        assert int(c[0]) == int(c[1] + c[2] + c[3])
+
+
+def test_graph_replay_equals_eager_steps():
+    """capture_steps(): T launches in one HIP graph play the same games as T step_batch() calls."""
+    E, n, T = 4096, 1, 40
+    acts = _actions(T, E, 2, 5, p_shoot=0.5)
+    a = _env(n_agents=n, n_envs=E, seed=8, auto_reset=True); a.reset()
+    b = _env(n_agents=n, n_envs=E, seed=8, auto_reset=True); b.reset()
+    graph, (go, gr, gd) = b.capture_steps(acts, store=True)
+    for rep in range(4):
+        graph.replay()
+        torch.cuda.synchronize()
+        for t in range(T):
+            o, r, d = a.step_batch(acts[t])
+            assert torch.equal(o, go[t]) and torch.equal(r, gr[t]) and torch.equal(d, gd[t]), (rep, t)
+    sa, sb = a.export_state(), b.export_state()
+    assert all(torch.equal(sa[k], sb[k]) for k in ("px", "py", "php", "tick", "counters", "bl_live"))

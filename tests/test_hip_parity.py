@@ -9,11 +9,11 @@ import random
 import numpy as np
 import pytest
 
-from trace_util import episodes, load_trace, trace_names, WINNER_CODE
+from trace_util import (OBS_ATOL, OBS_RTOL, WINNER_CODE, episode_groups, episodes, load_trace, replay_batched,
+                        trace_names)
 
 pytestmark = pytest.mark.gpu
 
-OBS_RTOL, OBS_ATOL = 1e-5, 1e-7
 
 
 def _env(**kw):
@@ -21,66 +21,29 @@ def _env(**kw):
     return bsx.parallel_env(**kw)
 
 
-def _cmp_state(name, st, t, rows, envs, base_cnt, s_desc):
-    """st: exported tensors (numpy) for all envs; rows: flat fixture step per env in `envs`."""
-    for f, g in (("px", "px"), ("py", "py"), ("php", "php"), ("tick", "tick")):
-        got, exp = st[g][envs], t[f][rows]
-        assert np.array_equal(got, exp), f"{name} {s_desc}: {f}\n got {got}\n exp {exp}"
-    assert np.array_equal(st["palive"][envs].astype(bool), t["palive"][rows]), f"{name} {s_desc}: palive"
-    assert np.array_equal(st["pdir"][envs], t["pdir"][rows]), f"{name} {s_desc}: pdir\n{st['pdir'][envs]}\n{t['pdir'][rows]}"
-    assert np.array_equal(st["bhp"][envs], t["bhp"][rows]), f"{name} {s_desc}: bhp"
-    assert np.array_equal(st["env_done"][envs].astype(bool), t["env_done"][rows]), f"{name} {s_desc}: env_done"
-    assert np.array_equal(st["winner"][envs], t["winner"][rows]), f"{name} {s_desc}: winner"
-    live = st["bl_live"][envs].astype(bool)
-    assert np.array_equal(live, t["bl_live"][rows]), f"{name} {s_desc}: bl_live\n got {live.astype(int)}\n exp {t['bl_live'][rows].astype(int)}"
-    for f in ("bl_x", "bl_y", "bl_dir"):
-        a, b = st[f][envs][live], t[f][rows][live]
-        assert np.array_equal(a, b), f"{name} {s_desc}: {f}\n got {a}\n exp {b}"
-    cnt = np.stack([t["total_games"][rows], t["ties"][rows], t["wins_red"][rows], t["wins_blue"][rows]], 1)
-    assert np.array_equal(st["counters"][envs], cnt - base_cnt), f"{name} {s_desc}: counters"
+class HipAdapter:
+    """Batched parallel_env behind the adapter interface of trace_util.replay_batched (everything through the C ABI)."""
 
+    def __init__(self, E, cfg):
+        self.env = _env(n_envs=E, rng="philox", **cfg)
 
-def _replay_batched(t, ep_ids):
-    """All listed episodes side by side as one batch; shorter ones idle (inert or no-op) once their trace ends."""
-    meta = t["meta"]
-    cfg = dict(meta["cfg"])
-    A, cont = meta["A"], meta["continuous"]
-    ptr = t["ep_ptr"]
-    E = len(ep_ids)
-    env = _env(n_envs=E, rng="philox", **cfg)
-    obs0 = env.reset(spawn=t["spawn"][ep_ids])
-    got0 = np.stack([obs0[a].cpu().numpy() for a in env.possible_agents], 1)
-    np.testing.assert_allclose(got0, t["obs0"][ep_ids], rtol=OBS_RTOL, atol=OBS_ATOL)
-    starts = np.asarray([ptr[e] for e in ep_ids]); lens = np.asarray([ptr[e + 1] - ptr[e] for e in ep_ids])
-    base_cnt = np.zeros((E, 4), np.int64)
-    for i, s0 in enumerate(starts):
-        if s0 > 0:
-            base_cnt[i] = [t[f][s0 - 1] for f in ("total_games", "ties", "wins_red", "wins_blue")]
-    n_exact = n_vals = 0
-    has_logits = "logits" in t
-    for k in range(int(lens.max())):
-        on = np.nonzero(k < lens)[0]
-        rows = starts[on] + k
-        if has_logits:
-            act = np.zeros((E, A, 4), np.float32); act[on] = t["logits"][rows]
-        elif cont:
-            act = np.zeros((E, A, 3), np.float64); act[on] = t["actions"][rows]
-        else:
-            act = np.zeros((E, A), np.int64); act[on] = t["actions"][rows]
-        u = np.full((E, A), np.nan); u[on] = t["u"][rows]
+    def reset(self, spawn):
+        obs = self.env.reset(spawn=spawn)
+        return np.stack([obs[a].cpu().numpy() for a in self.env.possible_agents], 1)
+
+    def step(self, act, u, empty):
         import torch
-        obs, rew, done = env.step_batch(torch.as_tensor(act), u=u)
-        st = {f: v.cpu().numpy() for f, v in env.export_state().items()}
-        desc = f"batch step {k} (flat rows {rows.tolist()[:4]}...)"
-        _cmp_state(t["name"], st, t, rows, on, base_cnt[on], desc)
-        o = obs.cpu().numpy()[on]
-        np.testing.assert_allclose(o, t["obs"][rows], rtol=OBS_RTOL, atol=OBS_ATOL, err_msg=f"{t['name']} {desc}: obs")
-        n_exact += int((o == t["obs"][rows]).sum()); n_vals += o.size
-        np.testing.assert_allclose(rew.cpu().numpy()[on], t["rew"][rows], rtol=1e-6, atol=1e-6, err_msg=f"{t['name']} {desc}: rew")
-        assert np.array_equal(done.cpu().numpy()[on], t["done"][rows]), f"{t['name']} {desc}: done"
-        assert np.array_equal(env.env_done.cpu().numpy()[on], t["env_done"][rows])
-        assert np.array_equal(env.winner.cpu().numpy()[on], t["winner"][rows])
-    return n_exact, n_vals
+        obs, rew, done = self.env.step_batch({} if empty else torch.as_tensor(act), u=u)
+        return obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+
+    def export(self):
+        return {f: v.cpu().numpy() for f, v in self.env.export_state().items()}
+
+    def env_done(self):
+        return self.env.env_done.cpu().numpy()
+
+    def winner(self):
+        return self.env.winner.cpu().numpy()
 
 
 def _replay_single(t, e):
@@ -110,15 +73,22 @@ def _replay_single(t, e):
 
 @pytest.mark.parametrize("name", trace_names())
 def test_hip_reproduces_reference_trace(name):
+    """All episodes of a golden trace side by side as one batch (heterogeneous games in one launch)."""
     t = load_trace(name)
-    eps = [e for e, a, b in episodes(t)]
-    with_empty = [e for e, a, b in episodes(t) if t["empty_call"][a:b].any()]
-    plain = [e for e in eps if e not in with_empty]
-    n_exact, n_vals = _replay_batched(t, plain)
-    for e in with_empty:
-        _replay_single(t, e)
+    n_exact = n_vals = 0
+    for group in episode_groups(t):
+        a, b = replay_batched(HipAdapter, t, group)
+        n_exact += a; n_vals += b
     # libm differences (device atan2 vs glibc) may flip the last float32 bit of a few observations, no more
     assert n_exact >= n_vals * (1 - 1e-3), f"{name}: only {n_exact}/{n_vals} observation values bit-identical"
+
+
+@pytest.mark.parametrize("name", ["g5_scripted_1v1", "g1_1v1_instinct", "g4_1v1_cont_instinct"])
+def test_dropin_surface_reproduces_reference_trace(name):
+    """Episode by episode through the drop-in (n_envs=None) surface: reference return types, step({}), dones identity."""
+    t = load_trace(name)
+    for e, a, b in list(episodes(t))[:46]:
+        _replay_single(t, e)
 
 
 def test_dropin_same_seed_same_game_as_reference():

@@ -69,3 +69,82 @@ def step_actions(t, s, ids):
     if t["meta"]["continuous"]:
         return {a: t["actions"][s, i].copy() for i, a in enumerate(ids)}
     return {a: int(t["actions"][s, i]) for i, a in enumerate(ids)}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Batched replay shared by the C-oracle test (CPU) and the HIP parity test (GPU).  `env` is an adapter with
+#   reset(spawn[E,4+3A]) -> obs[E,A,D];  step(actions, u, empty) -> (obs[E,A,D], rew[E,A], done[E,A]);
+#   export() -> dict of numpy arrays in the bsx_export_state schema;  env_done() / winner() -> [E]
+OBS_RTOL, OBS_ATOL = 1e-5, 1e-7     # north_star: 1e-5 relative on float outputs
+
+
+def episode_groups(t):
+    """Episodes that can run side by side as one batch; an episode containing a step({}) call runs alone
+    (the empty call is a whole-batch flag)."""
+    eps = [e for e, a, b in episodes(t)]
+    alone = [e for e, a, b in episodes(t) if t["empty_call"][a:b].any()]
+    plain = [e for e in eps if e not in alone]
+    return ([plain] if plain else []) + [[e] for e in alone]
+
+
+def cmp_state(name, st, t, rows, envs, base_cnt, desc):
+    for f in ("px", "py", "php", "tick"):
+        got, exp = st[f][envs], t[f][rows]
+        assert np.array_equal(got, exp), f"{name} {desc}: {f}\n got {got}\n exp {exp}"
+    assert np.array_equal(st["palive"][envs].astype(bool), t["palive"][rows]), f"{name} {desc}: palive"
+    assert np.array_equal(st["pdir"][envs], t["pdir"][rows]), f"{name} {desc}: pdir\n{st['pdir'][envs]}\n{t['pdir'][rows]}"
+    assert np.array_equal(st["bhp"][envs], t["bhp"][rows]), f"{name} {desc}: bhp"
+    assert np.array_equal(st["env_done"][envs].astype(bool), t["env_done"][rows]), f"{name} {desc}: env_done"
+    assert np.array_equal(st["winner"][envs], t["winner"][rows]), f"{name} {desc}: winner"
+    live = st["bl_live"][envs].astype(bool)
+    assert np.array_equal(live, t["bl_live"][rows]), \
+        f"{name} {desc}: bl_live\n got {live.astype(int)}\n exp {t['bl_live'][rows].astype(int)}"
+    for f in ("bl_x", "bl_y", "bl_dir"):
+        a, b = st[f][envs][live], t[f][rows][live]
+        assert np.array_equal(a, b), f"{name} {desc}: {f}\n got {a}\n exp {b}"
+    cnt = np.stack([t["total_games"][rows], t["ties"][rows], t["wins_red"][rows], t["wins_blue"][rows]], 1)
+    assert np.array_equal(st["counters"][envs], cnt - base_cnt), f"{name} {desc}: counters"
+
+
+def replay_batched(make_env, t, ep_ids, exact_obs=False):
+    """Run the listed episodes side by side; shorter ones idle with no-op actions once their trace ends.
+    Returns (#observation values bit-identical, #observation values)."""
+    meta = t["meta"]
+    A, cont = meta["A"], meta["continuous"]
+    ptr = t["ep_ptr"]
+    E = len(ep_ids)
+    env = make_env(E, dict(meta["cfg"]))
+    obs0 = env.reset(t["spawn"][ep_ids])
+    np.testing.assert_allclose(obs0, t["obs0"][ep_ids], rtol=OBS_RTOL, atol=OBS_ATOL)
+    starts = np.asarray([ptr[e] for e in ep_ids])
+    lens = np.asarray([ptr[e + 1] - ptr[e] for e in ep_ids])
+    base_cnt = np.zeros((E, 4), np.int64)
+    for i, s0 in enumerate(starts):
+        if s0 > 0:
+            base_cnt[i] = [t[f][s0 - 1] for f in ("total_games", "ties", "wins_red", "wins_blue")]
+    n_exact = n_vals = 0
+    for k in range(int(lens.max())):
+        on = np.nonzero(k < lens)[0]
+        rows = starts[on] + k
+        empty = bool(t["empty_call"][rows].any())
+        assert not empty or E == 1
+        if "logits" in t:
+            act = np.zeros((E, A, 4), np.float32); act[on] = t["logits"][rows]
+        elif cont:
+            act = np.zeros((E, A, 3), np.float64); act[on] = t["actions"][rows]
+        else:
+            act = np.zeros((E, A), np.int32); act[on] = t["actions"][rows]
+        u = np.full((E, A), np.nan); u[on] = t["u"][rows]
+        obs, rew, done = env.step(act, u, empty)
+        desc = f"batch step {k} (flat rows {rows.tolist()[:4]}..)"
+        cmp_state(t["name"], env.export(), t, rows, on, base_cnt[on], desc)
+        o = np.asarray(obs)[on]
+        if exact_obs:
+            assert np.array_equal(o, t["obs"][rows]), f"{t['name']} {desc}: obs"
+        np.testing.assert_allclose(o, t["obs"][rows], rtol=OBS_RTOL, atol=OBS_ATOL, err_msg=f"{t['name']} {desc}: obs")
+        n_exact += int((o == t["obs"][rows]).sum()); n_vals += o.size
+        np.testing.assert_allclose(np.asarray(rew)[on], t["rew"][rows], rtol=1e-6, atol=1e-6, err_msg=f"{t['name']} {desc}: rew")
+        assert np.array_equal(np.asarray(done)[on].astype(bool), t["done"][rows]), f"{t['name']} {desc}: done"
+        assert np.array_equal(np.asarray(env.env_done())[on].astype(bool), t["env_done"][rows])
+        assert np.array_equal(np.asarray(env.winner())[on], t["winner"][rows])
+    return n_exact, n_vals
