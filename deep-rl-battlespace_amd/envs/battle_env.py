@@ -36,6 +36,22 @@ DISP_WIDTH = 1200    # reference envs/sprites.py:9
 DISP_HEIGHT = 800    # reference envs/sprites.py:10
 
 
+def draw_spawn(n_agents, randint=None):
+    """4 + 3A stdlib draws in the reference's order: base red x,y, base blue x,y (sprites.py:238-252), then x,y,dir per
+    plane, red ids first (sprites.py:74-91; battle_env.py:257-268).  Red headings are randint(270,450) folded."""
+    n, ri = n_agents, (randint if randint is not None else _stdlib_random.randint)
+    out = [ri(62, 1138 // 3), ri(62, 738), ri(1138 // 3 * 2, 1138), ri(62, 738)]
+    for i in range(2 * n):
+        if i < n:
+            x, y, d = ri(50, 1150 // 3), ri(48, 752), ri(270, 450)
+            if d >= 360:
+                d -= 360
+        else:
+            x, y, d = ri(1150 // 3 * 2, 1150), ri(48, 752), ri(90, 270)
+        out += [x, y, d]
+    return out
+
+
 class _TeamCounters:
     """`env.team[colour]['wins']` (reference battle_env.py:102-103,492) backed by the device counters."""
 
@@ -156,18 +172,7 @@ class parallel_env:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def _draw_spawn(self):
-        """4 + 3A stdlib draws in the reference's order (sprites.py:238-252 bases, :74-91 planes; battle_env.py:257-268)."""
-        n, ri = self.n_agents, _stdlib_random.randint
-        out = [ri(62, 1138 // 3), ri(62, 738), ri(1138 // 3 * 2, 1138), ri(62, 738)]
-        for i in range(2 * n):
-            if i < n:
-                x, y, d = ri(50, 1150 // 3), ri(48, 752), ri(270, 450)
-                if d >= 360:
-                    d -= 360
-            else:
-                x, y, d = ri(1150 // 3 * 2, 1150), ri(48, 752), ri(90, 270)
-            out += [x, y, d]
-        return out
+        return draw_spawn(self.n_agents)
 
     def _agent_views(self, t):
         return {a: t[:, i] for i, a in enumerate(self.possible_agents)}

@@ -1,0 +1,135 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every symbol the header declares, argument
+validation happens before any device work, host-side draw order equals the reference's, sharding partitions exactly,
+and the multi-rank path (world_size 2, gloo) reduces counters correctly.  No kernel is launched here."""
+import ctypes
+import os
+import random
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+    from deep_rl_battlespace_amd import _lib
+    return _lib
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "battlespace_hip.h")).read()
+    declared = sorted(set(re.findall(r"^\s*int\s+(bsx_\w+)\s*\(", hdr, flags=re.M)))
+    assert declared == sorted(_lib().SIGNATURES), "binding and header disagree on the entry points"
+    lib = _lib().load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.bsx_abi_version() == int(re.search(r"#define BSX_ABI_VERSION (\d+)", hdr).group(1))
+
+
+def test_state_bytes_and_tie_tick_need_no_gpu():
+    L = _lib(); lib = L.load()
+    sz = ctypes.c_size_t()
+    assert lib.bsx_state_bytes(65536, 1, ctypes.byref(sz)) == 0
+    per_agent = sz.value / (65536 * 2)
+    assert 300 < per_agent < 420                      # 16 plane + 48 bullet xy + 192 displacement + 96 heading + env share
+    assert lib.bsx_state_bytes(0, 1, ctypes.byref(sz)) == -1 and lib.bsx_state_bytes(8, 17, ctypes.byref(sz)) == -1
+    assert [lib.bsx_tie_tick(n) for n in (1, 2, 3, 4, 5, 8)] == [121, 141, 161, 181, 200, 260]
+
+
+def test_bad_arguments_are_rejected_before_any_launch():
+    L = _lib(); lib = L.load()
+    cfg = L.BsxRewards(100, 10, -1, -5, -20)
+    assert lib.bsx_step_discrete(None, 4, 1, None, 0, None, None, None, None, None, None, ctypes.byref(cfg), 0, 0, 0, None) == -1
+    assert lib.bsx_reset(None, 4, 1, None, None, 0, 0, 0, None, None) == -1
+    assert lib.bsx_observe(None, 4, 1, None, None) == -1
+    assert lib.bsx_state_init(ctypes.c_void_p(4096 + 8), 4, 1, None) == -2      # misaligned state base
+
+
+def test_env_refuses_to_run_without_gpu_or_library():
+    import torch
+    import deep_rl_battlespace_amd as bsx
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        bsx.parallel_env()
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: no file of the product imports, loads or links anything under oracle/."""
+    pat = re.compile(r"^\s*(from\s+oracle|import\s+oracle)|libbattlespace_ref|oracle/|oracle\.", re.M)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "deep-rl-battlespace_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                assert not pat.search(open(os.path.join(dirpath, f)).read()), os.path.join(dirpath, f)
+
+
+def test_host_spawn_draw_order_is_the_references():
+    """rng='python': the host draws spawns from the stdlib generator exactly as the oracle (hence the reference) does."""
+    from deep_rl_battlespace_amd.envs.battle_env import draw_spawn
+    from oracle import battlespace_ref as ref
+    for n in (1, 2, 4):
+        random.seed(50 + n)
+        env = ref.RefEnv(n_agents=n)            # constructor draws once
+        env.reset()
+        want = [env.base_x[0], env.base_y[0], env.base_x[1], env.base_y[1]] + \
+               [v for i in range(2 * n) for v in (env.px[i], env.py[i], env.pdir[i])]
+        random.seed(50 + n)
+        draw_spawn(n)
+        assert draw_spawn(n) == want
+
+
+def test_env_range_partitions_exactly():
+    from deep_rl_battlespace_amd.sharding import env_range
+    for total, world in ((524288, 8), (65536, 1), (10, 3), (7, 8), (0, 2)):
+        spans = [env_range(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+    assert [env_range(524288, r, 8) for r in (0, 7)] == [(0, 65536), (458752, 524288)]
+    with pytest.raises(ValueError):
+        env_range(8, 2, 2)
+
+
+def test_spaces_metadata():
+    from deep_rl_battlespace_amd.spaces import Box, Discrete
+    b = Box(np.ones(5, np.float32), -np.ones(5, np.float32))
+    assert b.shape == (5,) and b.dtype == np.float32 and (b.low == 1).all() and (b.high == -1).all()
+    assert b.sample().shape == (5,)
+    d = Discrete(4)
+    assert d.n == 4 and 0 <= d.sample() < 4
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from deep_rl_battlespace_amd import sharding
+rank, world, _ = sharding.rank_world()
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=rank, world_size=world)
+lo, hi = sharding.env_range(1000, rank, world)
+mine = torch.tensor([hi - lo, rank + 1, 10 * (rank + 1), lo], dtype=torch.int64)
+tot = sharding.reduce_counters(mine)
+assert tot.tolist() == [1000, 3, 30, 500], tot.tolist()
+assert mine.tolist() == [500, rank + 1, 10 * (rank + 1), lo]       # input untouched
+dist.barrier(); dist.destroy_process_group()
+print("ok", rank)
+'''
+
+
+def test_two_rank_counter_reduction_over_gloo(tmp_path):
+    """world_size 2 on CPU (gloo): each rank owns a contiguous env range; the only collective is the logging all-reduce."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    port = 29500 + os.getpid() % 2000
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(port)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert all(f"ok {r}" in outs[r] for r in range(2))
