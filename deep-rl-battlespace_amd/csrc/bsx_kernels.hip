@@ -29,11 +29,34 @@
 namespace {
 
 constexpr int K = BSX_BULLET_SLOTS;
-constexpr int TPB = 256;
+constexpr int TPB = 256;   // reset / export kernels
+constexpr int SPB = 64;    // step kernel: ONE wavefront per workgroup -- a game never spans a wave, so no block barrier is needed
+
+// Timing-only ablation mask for profiling builds (hipcc -DBSX_DIAG=<bits>; results are WRONG with any bit set):
+// 1 = skip observation math, 2 = skip the bullet loop, 4 = skip the ordered resolve.  The product build has 0.
+#ifndef BSX_DIAG
+#define BSX_DIAG 0
+#endif
+constexpr unsigned DIAG = BSX_DIAG;
+
+// In-kernel phase stamps (hipcc -DBSX_STAMPS): lane 0 of every wave stores s_memtime at 8 points into a debug buffer
+// that nothing else reads.  Never defined in the product build; a stamped build is for reading SHARES, not run time.
+#ifdef BSX_STAMPS
+__device__ unsigned long long* g_stamps = nullptr;
+#define STAMP(i)                                                                                   \
+    do {                                                                                           \
+        unsigned long long t_;                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (g_stamps && (threadIdx.x & 63) == 0) g_stamps[size_t(blockIdx.x) * 8 + (i)] = t_; \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 constexpr int FIELD_W = 1200, FIELD_H = 800;      // sprites.py:9-10
 constexpr int PLANE_HW = 25, PLANE_HH = 24;        // 50x48 sprite, half sizes (w>>1, h>>1)
-constexpr int BASE_HALF = 31;                      // 62x62
 constexpr int PLANE_HP = 4;                        // battle_env.py:92
 constexpr double DEG2RAD = 3.141592653589793238462643383279502884 / 180.0;  // CPython math.radians
 constexpr double RAD2DEG = 180.0 / 3.141592653589793238462643383279502884;  // CPython math.degrees
@@ -137,12 +160,14 @@ __device__ inline double rel_angle(int x0, int y0, double a0, int x1, int y1) {
     if (r > 180.0) r -= 360.0;
     return r;
 }
+// The two divisions by constants (battle_env.py:230-231) are multiplications by the float64 reciprocal here: the
+// float64 result can differ in its last bit, which survives the single rounding to float32 with probability ~2^-29.
 __device__ inline float obs_dist(int x0, int y0, int x1, int y1) {
     const int dx = x0 - x1, dy = y0 - y1;
-    return float(sqrt(double(dx * dx + dy * dy)) / FIELD_DIAG * 2.0 - 1.0);
+    return float(sqrt(double(dx * dx + dy * dy)) * (2.0 / FIELD_DIAG) - 1.0);
 }
 __device__ inline float obs_angle(int x0, int y0, double a0, int x1, int y1) {
-    return float(rel_angle(x0, y0, a0, x1, y1) / 360.0);
+    return float(rel_angle(x0, y0, a0, x1, y1) * (1.0 / 360.0));
 }
 __device__ inline uint32_t rotl12(uint32_t v, int s) {  // rotate a 12-bit mask left by s in [0, 12)
     return ((v << s) | (v >> (12 - s))) & 0xFFFu;
@@ -174,7 +199,7 @@ __device__ inline void write_obs(float* __restrict__ out, int n, bool alive, int
                                  int ebx, int eby, int gl, const volatile int* s_x, const volatile int* s_y,
                                  const volatile int* s_hp) {
     const int D = 3 * n + 2;
-    if (!alive) {
+    if (!alive || (DIAG & 1u)) {
         for (int i = 0; i < D; ++i) out[i] = -1.0f;
         return;
     }
@@ -218,12 +243,41 @@ __device__ inline void spawn_plane(uint64_t seed, int64_t genv, uint32_t stream,
 enum Mode : int { M_INERT = 0, M_TIE = 1, M_PHYS = 2, M_RESET = 3 };
 
 // ---------------------------------------------------------------------------------------------- the step kernel
+// Record (un)packing on raw 16-byte words: keeps the loads as single dwordx4 instructions with no byte shuffling.
+__device__ inline void unpack_plane(const uint4 w, int& x, int& y, uint32_t& live, int& hp, double& dir) {
+    x = sx16(w.x); y = sy16(w.x); live = w.y & 0xFFFFu; hp = int(int8_t((w.y >> 16) & 0xFFu));
+    dir = __hiloint2double(int(w.w), int(w.z));
+}
+__device__ inline uint4 pack_plane(int x, int y, uint32_t live, int hp, double dir) {
+    return make_uint4(pack_xy(x, y), (live & 0xFFFFu) | ((uint32_t(hp) & 0xFFu) << 16), uint32_t(__double2loint(dir)),
+                      uint32_t(__double2hiint(dir)));
+}
+struct EnvU {   // EnvRec fields in registers
+    int brx, bry, bbx, bby, bhp_r, bhp_b, tick, done, winner;
+};
+__device__ inline EnvU unpack_env(const uint4 w) {
+    EnvU e;
+    e.brx = sx16(w.x); e.bry = sy16(w.x); e.bbx = sx16(w.y); e.bby = sy16(w.y);
+    e.bhp_r = sx16(w.z); e.bhp_b = sy16(w.z); e.tick = int(w.w & 0xFFFFu); e.done = int((w.w >> 16) & 0xFFu); e.winner = int(w.w >> 24);
+    return e;
+}
+__device__ inline uint4 pack_env(const EnvU& e) {
+    return make_uint4(pack_xy(e.brx, e.bry), pack_xy(e.bbx, e.bby), pack_xy(e.bhp_r, e.bhp_b),
+                      (uint32_t(e.tick) & 0xFFFFu) | (uint32_t(e.done) << 16) | (uint32_t(e.winner) << 24));
+}
+
+// Range / angle-off pair of one observer->target (battle_env.py:230-231,240-241)
+__device__ inline void obs_pair(int x, int y, double dir, int tx, int ty, float& od, float& oa) {
+    od = obs_dist(x, y, tx, ty);
+    oa = obs_angle(x, y, dir, tx, ty);
+}
+
 template <int N, bool CONT>
-__global__ __launch_bounds__(TPB) void bsx_step_kernel(const StepArgs p) {
+__global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     const int n = (N > 0) ? N : p.n;
     const int A = 2 * n;
     const int G = group_width(n);
-    const int EPB = TPB / G;
+    const int EPB = SPB / G;
     const int tid = threadIdx.x;
     const int a = tid & (G - 1);
     const int gl = tid & ~(G - 1);                       // first thread of my env's group
@@ -231,21 +285,82 @@ __global__ __launch_bounds__(TPB) void bsx_step_kernel(const StepArgs p) {
     const bool env_ok = e < p.E;
     const bool valid = env_ok && a < A;
     const size_t EA = size_t(p.E) * size_t(A);
-    const size_t g = valid ? size_t(e) * A + a : 0;
-    const int lane = tid & 63;
+    // out-of-range lanes read a valid row (the last one) and never store: loads stay unconditional
+    const int64_t ec = env_ok ? e : p.E - 1;
+    const size_t g = size_t(ec) * A + (a < A ? a : A - 1);
+    const int lane = tid;
+    const int team = (a < n) ? 0 : 1;                    // 0 red, 1 blue
+    const int eb = gl + (team == 0 ? n : 0);             // first enemy lane (thread index)
+    constexpr int NE = (N > 0) ? N : 1;                  // compile-time enemy count (runtime-n build reads LDS in loops)
 
-    __shared__ volatile int s_x[TPB], s_y[TPB], s_hp[TPB];
-    __shared__ int s_bhit[TPB];                          // [group*?]: index gl + team
+    // LDS is private to this wavefront: accesses are volatile (program order) and the hardware runs one wave's LDS
+    // operations in order, so cross-lane hand-offs need no s_barrier -- only a compiler scheduling fence.
+    __shared__ volatile int s_x[SPB], s_y[SPB], s_hp[SPB];
+    __shared__ volatile int s_bhit[SPB];                 // base hits, index gl + shooter team
+    __shared__ double2 s_lut[CONT ? 1 : 384];            // heading table (361 entries) staged per wave (discrete only)
+    __shared__ volatile float s_obs[SPB * ((N > 0) ? 3 * N + 2 : 3 * BSX_MAX_N + 2)];   // observation rows of the wave
 
-    // ---- load
-    EnvRec er; memset(&er, 0, sizeof(er));
-    PlaneRec pr; memset(&pr, 0, sizeof(pr));
-    if (env_ok) er = p.st.env[e];
-    if (valid) pr = p.st.plane[g];
-    int x = pr.x, y = pr.y, hp = pr.hp;
-    double dir = pr.dir;
-    uint32_t live = pr.live;
+    STAMP(0);
+    // ================= T0: every load that depends on no other load, issued back to back, raw 16-byte words ========
+    // (the kernel is latency-bound at 65 536 games -- 2 waves per SIMD -- so memory-level parallelism is what pays)
+    const uint4 erw = reinterpret_cast<const uint4*>(p.st.env)[ec];
+    const int games = reinterpret_cast<const int*>(p.st.cnt)[4 * ec];   // games finished so far = episode id of the RNG streams
+    const uint4 prw = reinterpret_cast<const uint4*>(p.st.plane)[g];
+    // heading table: 361 entries = 6 per lane (L2-resident); stored to LDS after the next load batch is out
+    double2 lt[6];
+    if (!CONT) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) lt[q] = p.st.lut[min(tid + SPB * q, 360)];
+    }
+    int act = -1;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, uu_in = 0.0;
+    if (p.actions) {                                     // uniform branch
+        if (!CONT) {
+            if (p.action_kind == BSX_ACT_I32) act = static_cast<const int32_t*>(p.actions)[g];
+            else {   // np.argmax: first maximum; a NaN compares as the maximum
+                const float4 lg = static_cast<const float4*>(p.actions)[g];
+                const float v[4] = {lg.x, lg.y, lg.z, lg.w};
+                act = 0;
+#pragma unroll
+                for (int i = 1; i < 4; ++i)
+                    if (!(v[act] != v[act]) && (v[i] > v[act] || v[i] != v[i])) act = i;
+            }
+        } else if (p.action_kind == BSX_ACT_F32) {
+            const float* ap = static_cast<const float*>(p.actions) + 3 * g;
+            a0 = double(ap[0]); a1 = double(ap[1]); a2 = double(ap[2]);
+        } else {
+            const double* ap = static_cast<const double*>(p.actions) + 3 * g;
+            a0 = ap[0]; a1 = ap[1]; a2 = ap[2];
+        }
+    }
+    if (p.u) uu_in = p.u[g];                             // uniform branch
+
+    // ================= T1: the one dependent round trip: per-update steps of my LIVE bullets ========================
+    int x, y, hp;
+    uint32_t live;
+    double dir;
+    unpack_plane(prw, x, y, live, hp, dir);
+    EnvU er = unpack_env(erw);
+    const uint32_t live0 = live;
+    // dead slots / empty chunks read the heading table's first entry instead (one shared cache line, no DRAM traffic)
+    uint4 c[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const uint4* src = ((live0 >> (4 * q)) & 0xFu) ? &p.st.bxy[size_t(q) * EA + g] : reinterpret_cast<const uint4*>(p.st.lut);
+        c[q] = *src;
+    }
+    double2 d[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const double2* src = ((live0 >> k) & 1u) ? &p.st.bd[size_t(k) * EA + g] : p.st.lut;
+        d[k] = (DIAG & 2u) ? make_double2(0.0, 0.0) : *src;
+    }
+    if (!CONT) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) s_lut[tid + SPB * q] = lt[q];   // 384 slots: the clamped tail is never read
+    }
     const bool alive0 = valid && hp > 0;
+    STAMP(1);
 
     // "no agents left" (battle_env.py:309): group ballot over the alive flags
     const unsigned long long bal = __ballot(alive0);
@@ -263,51 +378,38 @@ __global__ __launch_bounds__(TPB) void bsx_step_kernel(const StepArgs p) {
     }
     if (!env_ok) mode = M_INERT;
 
-    double rew = 0.0;
     int4 cnt_delta = make_int4(0, 0, 0, 0);              // games, ties, red wins, blue wins
     bool spawn = false;
-    int x0 = x, y0 = y;
-    double d0 = dir;
+    const int x0 = x, y0 = y;
+    const double d0 = dir;
+    const int64_t genv = p.env_offset + ec;
+
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // heading table is in LDS (wave-private: no s_barrier)
+    __builtin_amdgcn_wave_barrier();
 
     if (mode == M_RESET) {
         // re-spawn in place of the inert call; episode id = games played so far
-        const int games = p.st.cnt[e].x;
-        const int64_t genv = p.env_offset + e;
-        spawn_bases(p.seed, genv, STREAM_AUTORESET, uint32_t(games), er);
-        er.bhp_r = er.bhp_b = int16_t(5 * n);
+        EnvRec nb; memset(&nb, 0, sizeof(nb));
+        spawn_bases(p.seed, genv, STREAM_AUTORESET, uint32_t(games), nb);
+        er.brx = nb.brx; er.bry = nb.bry; er.bbx = nb.bbx; er.bby = nb.bby;
+        er.bhp_r = er.bhp_b = 5 * n;
         er.tick = 0; er.done = 0; er.winner = BSX_WINNER_NONE;
         tick = 0;
-        if (valid) { spawn_plane(p.seed, genv, STREAM_AUTORESET, uint32_t(games), a, n, x, y, dir); hp = PLANE_HP; live = 0; }
+        spawn_plane(p.seed, genv, STREAM_AUTORESET, uint32_t(games), a < A ? a : A - 1, n, x, y, dir);
+        hp = PLANE_HP; live = 0;
     } else if (mode == M_PHYS && alive0) {
         // ---- process_action (battle_env.py:383-424)
         if (!CONT) {
-            int act;
-            if (p.action_kind == BSX_ACT_I32) act = static_cast<const int32_t*>(p.actions)[g];
-            else {   // np.argmax: first maximum; a NaN compares as the maximum
-                const float4 lg = static_cast<const float4*>(p.actions)[g];
-                const float v[4] = {lg.x, lg.y, lg.z, lg.w};
-                act = 0;
-                for (int i = 1; i < 4; ++i)
-                    if (!(v[act] != v[act]) && (v[i] > v[act] || v[i] != v[i])) act = i;
-            }
             if (act == 2) dir = rotate_dir(dir, 15.0);
             else if (act == 3) dir = rotate_dir(dir, -15.0);
             if (act >= 0 && act <= 3) {
-                const double2 dl = p.st.lut[int(dir)];   // 21.5*cos(-radians(d)), 21.5*sin(-radians(d)) from host libm
+                const double2 dl = s_lut[int(dir)];      // 21.5*cos(-radians(d)), 21.5*sin(-radians(d)) from host libm
                 x = int(double(x) + dl.x);               // Rect.center store truncates toward zero
                 y = int(double(y) + dl.y);
                 clamp_plane(x, y);
             }
             spawn = (act == 1);
         } else {
-            double a0, a1, a2;
-            if (p.action_kind == BSX_ACT_F32) {
-                const float* ap = static_cast<const float*>(p.actions) + 3 * g;
-                a0 = double(ap[0]); a1 = double(ap[1]); a2 = double(ap[2]);
-            } else {
-                const double* ap = static_cast<const double*>(p.actions) + 3 * g;
-                a0 = ap[0]; a1 = ap[1]; a2 = ap[2];
-            }
             a0 = fmin(fmax(a0, -1.0), 1.0); a1 = fmin(fmax(a1, -1.0), 1.0); a2 = fmin(fmax(a2, -1.0), 1.0);
             const double speed = ((a0 + 1.0) / 2.0) * 75.0 + 200.0;    // battle_env.py:419
             double sn, cs;
@@ -324,119 +426,158 @@ __global__ __launch_bounds__(TPB) void bsx_step_kernel(const StepArgs p) {
     // ---- stage the post-move block in LDS
     s_x[tid] = x; s_y[tid] = y; s_hp[tid] = valid ? hp : 0;
     s_bhit[tid] = 0;
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
-    const int team = (a < n) ? 0 : 1;                    // 0 red, 1 blue
-    const int eb = gl + (team == 0 ? n : 0);             // first enemy lane (thread index)
-    uint32_t consumed_rank = 0;
-    uint64_t ovl[3] = {0, 0, 0};                         // rank-ordered 16-bit overlap fields, 4 ranks per word
+    STAMP(2);
+    // ---- Bullet.__init__ (sprites.py:293-318) for this call's shot: heading = pre-move heading + (u*8 - 4)
+    const bool phys = (mode == M_PHYS) && valid && !(DIAG & 2u);
+    const int ks = tick % K;
     const int k0 = (tick + 1) % K;                       // slot of the oldest possible bullet
-    const uint32_t live0 = live;
-
-    if (mode == M_PHYS && valid) {
-        // ---- Bullet.__init__ (sprites.py:293-318) for this call's shot
-        const int ks = tick % K;
-        double2 nd = make_double2(0.0, 0.0);
-        if (spawn) {
-            double uu;
-            if (p.u) uu = p.u[g];
-            else {
-                const int games = p.st.cnt[e].x;
-                const uint4 r = draw4(p.seed, p.env_offset + e, STREAM_JITTER, uint32_t(games),
-                                      (uint32_t(tick) << 8) | uint32_t(a));
-                uu = uniform53(r.x, r.y);
-            }
-            const double bdir = d0 + (uu * 8.0 - 4.0);
-            double sn, cs;
-            sincos(-(bdir * DEG2RAD), &sn, &cs);
-            nd = make_double2(BULLET_STEP * cs, BULLET_STEP * sn);
-            p.st.bd[size_t(ks) * EA + g] = nd;
-            p.st.bdir[size_t(ks) * EA + g] = bdir;
-            live |= 1u << ks;
+    double2 nd = make_double2(0.0, 0.0);
+    spawn = spawn && phys;
+    if (spawn) {
+        double uu = uu_in;
+        if (!p.u) {
+            const uint4 r = draw4(p.seed, genv, STREAM_JITTER, uint32_t(games), (uint32_t(tick) << 8) | uint32_t(a));
+            uu = uniform53(r.x, r.y);
         }
-        if (live) {
-            // ---- Bullet.update for each of my bullets (sprites.py:321-351)
-            uint4 c[3];
+        const double bdir = d0 + (uu * 8.0 - 4.0);
+        double sn, cs;
+        sincos(-(bdir * DEG2RAD), &sn, &cs);
+        nd = make_double2(BULLET_STEP * cs, BULLET_STEP * sn);
+        p.st.bd[size_t(ks) * EA + g] = nd;
+        p.st.bdir[size_t(ks) * EA + g] = bdir;
+        live |= 1u << ks;
+    }
+
+    STAMP(3);
+    // ---- observation geometry (battle_env.py:202-244) from the staged block, BEFORE the bullets: poses are final after
+    //      the move, only the alive flags can still change; this fp64 math runs while the bullet-step loads are in flight.
+    const int obx = team == 0 ? er.bbx : er.brx, oby = team == 0 ? er.bby : er.bry;   // enemy base
+    float ob_d = -1.0f, ob_a = -1.0f;
+    float oe_d[NE], oe_a[NE];
+    int ex[NE], ey[NE];
+    if (!(DIAG & 1u)) obs_pair(x, y, dir, obx, oby, ob_d, ob_a);
+    if (N > 0) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) c[q] = p.st.bxy[size_t(q) * EA + g];
-            uint32_t* w = reinterpret_cast<uint32_t*>(c);
-            const int ebx = team == 0 ? er.bbx : er.brx, eby = team == 0 ? er.bby : er.bry;
-            int nbase = 0;
+        for (int j = 0; j < NE; ++j) {
+            ex[j] = s_x[eb + j]; ey[j] = s_y[eb + j];
+            oe_d[j] = -1.0f; oe_a[j] = -1.0f;
+            if (!(DIAG & 1u)) obs_pair(x, y, dir, ex[j], ey[j], oe_d[j], oe_a[j]);
+        }
+    }
+
+    STAMP(4);
+    // ---- Bullet.update for all 12 slots (sprites.py:321-351), branch-free, predicates as integer sign masks (0 / -1):
+    //      dead slots compute on harmless values and are masked out.
+    constexpr int FW = (N > 0 && N <= 4) ? 4 : 16;       // bits per overlap field
+    constexpr int OW = (FW == 4) ? 1 : 3;                // 64-bit words holding the 12 slot-indexed fields
+    uint64_t ovl[OW];
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                if (!((live >> k) & 1u)) continue;
-                const bool newb = spawn && k == ks;
-                int bx, by;
-                double2 d;
-                if (newb) { bx = x0; by = y0; d = nd; }
-                else { bx = sx16(w[k]); by = sy16(w[k]); d = p.st.bd[size_t(k) * EA + g]; }
-                bx = int(double(bx) + d.x);
-                by = int(double(by) + d.y);
-                int age = tick - k; age %= K; if (age < 0) age += K; age += 1;      // updates so far, 1..12
-                bool gone = false;
-                if (age >= 12 || bx > FIELD_W || bx < 0 || by > FIELD_H || by < 0) {      // 45*age >= 500 <=> age >= 12
-                    rew += p.cfg.miss_punishment; gone = true;
-                } else {
-                    const int bl = bx - 3, br = bx + 3, bt = by - 1, bb = by + 2;           // 6x3 rect
-                    if (bl < ebx + BASE_HALF && bt < eby + BASE_HALF && br > ebx - BASE_HALF && bb > eby - BASE_HALF) {
-                        rew += p.cfg.hit_base_reward; nbase += 1; gone = true;              // Base.hit, even if already dead
-                    } else {
-                        uint32_t m = 0;
-                        for (int j = 0; j < n; ++j) {
-                            const int qx = s_x[eb + j], qy = s_y[eb + j];
-                            if (s_hp[eb + j] > 0 && bl < qx + PLANE_HW && bt < qy + PLANE_HH && br > qx - PLANE_HW &&
-                                bb > qy - PLANE_HH) m |= 1u << j;
-                        }
-                        if (m) {
-                            const int r = 12 - age;                                         // oldest first
-                            const uint64_t f = uint64_t(m) << ((r & 3) * 16);
-                            ovl[0] |= (r >> 2) == 0 ? f : 0; ovl[1] |= (r >> 2) == 1 ? f : 0; ovl[2] |= (r >> 2) == 2 ? f : 0;
-                        }
-                    }
+    for (int q = 0; q < OW; ++q) ovl[q] = 0;
+    int nmiss = 0, nbase = 0, nplane = 0;
+    {
+        uint32_t* w = reinterpret_cast<uint32_t*>(c);
+        const int physm = phys ? -1 : 0;
+        const uint32_t live1 = live;
+        int eam[NE];
+        if (N > 0) {
+#pragma unroll
+            for (int j = 0; j < NE; ++j) eam[j] = (s_hp[eb + j] > 0) ? -1 : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int lvm = (-int((live1 >> k) & 1u)) & physm;                      // -1: live bullet of a running game
+            const int newm = (spawn && k == ks) ? -1 : 0;
+            const int bx0 = newm ? x0 : sx16(w[k]), by0 = newm ? y0 : sy16(w[k]);
+            const double2 dd = newm ? nd : d[k];
+            const int bx = int(double(bx0) + dd.x);                                 // truncation toward zero
+            const int by = int(double(by0) + dd.y);
+            // miss: dist_travelled >= 500 <=> 12th update (45*12 >= 500 > 45*11) <=> this is the oldest slot k0;
+            // else off the field (x>1200 | x<0 | y>800 | y<0)
+            const int missm = ((bx | (FIELD_W - bx) | by | (FIELD_H - by)) >> 31) | ((k == k0) ? -1 : 0);
+            // base: 6x3 bullet rect vs 62x62 base rect, strict overlap <=> dx in [-33,33] and dy in [-32,31]
+            const int dxb = bx - obx, dyb = by - oby;
+            const int basem = ~(((dxb + 33) | (33 - dxb) | (dyb + 32) | (31 - dyb)) >> 31) & ~missm;
+            // planes: vs the un-rotated 50x48 rect at the post-move pose <=> dx in [-27,27] and dy in [-25,24]
+            uint32_t m = 0;
+            if (N > 0) {
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    const int dxp = bx - ex[j], dyp = by - ey[j];
+                    const int pm = ~(((dxp + 27) | (27 - dxp) | (dyp + 25) | (24 - dyp)) >> 31) & eam[j];
+                    m |= uint32_t(pm) & (1u << j);
                 }
-                if (gone) live &= ~(1u << k);
-                else w[k] = pack_xy(bx, by);
+            } else {
+                for (int j = 0; j < n; ++j) {
+                    const int dxp = bx - s_x[eb + j], dyp = by - s_y[eb + j];
+                    const int pm = ~(((dxp + 27) | (27 - dxp) | (dyp + 25) | (24 - dyp)) >> 31) & (s_hp[eb + j] > 0 ? -1 : 0);
+                    m |= uint32_t(pm) & (1u << j);
+                }
             }
-            if (nbase) atomicAdd(&s_bhit[gl + team], nbase);
+            const int gonem = (missm | basem) & lvm;
+            const int keepm = lvm & ~gonem;
+            m &= uint32_t(keepm);
+            nmiss -= missm & lvm;
+            nbase -= basem & lvm;
+            ovl[(k * FW) / 64] |= uint64_t(m) << ((k * FW) % 64);
+            live &= ~(uint32_t(gonem) & (1u << k));
+            w[k] = (pack_xy(bx, by) & uint32_t(keepm)) | (w[k] & ~uint32_t(keepm));
+        }
+        if (nbase) atomicAdd(const_cast<int*>(&s_bhit[gl + team]), nbase);
+        if (phys) {
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                if (((live | live0) >> (4 * q)) & 0xFu) p.st.bxy[size_t(q) * EA + g] = c[q];
+                if ((live1 >> (4 * q)) & 0xFu) p.st.bxy[size_t(q) * EA + g] = c[q];
         }
     }
 
+    STAMP(5);
     // ---- ordered plane-hit resolve (battle_env.py:332-360 with sprites.py:348-350): creation order = oldest age
     //      first, then shooter id; a plane killed earlier in the walk no longer stops later bullets.
+    uint64_t any_ovl = 0;
 #pragma unroll
-    for (int r = 1; r < K; ++r) {            // rank 0 = age 12 = always a range miss
-        const uint32_t m = uint32_t(ovl[r >> 2] >> ((r & 3) * 16)) & 0xFFFFu;
-        if (__ballot(m != 0) == 0ull) continue;          // wave-uniform: nobody has a candidate of this age
-        for (int i = 0; i < n; ++i) {
-            if (m != 0 && (a - (team ? n : 0)) == i) {
-                for (int j = 0; j < n; ++j) {
-                    if (((m >> j) & 1u) && s_hp[eb + j] > 0) {
-                        s_hp[eb + j] = s_hp[eb + j] - 1;                                     // Plane.hit
-                        rew += p.cfg.hit_plane_reward;
-                        consumed_rank |= 1u << r;
-                        break;
+    for (int q = 0; q < OW; ++q) any_ovl |= ovl[q];
+    if (__ballot(any_ovl != 0ull) != 0ull && !(DIAG & 4u)) {   // wave-uniform: most waves have no candidate at all
+        uint32_t consumed = 0;                                 // by slot
+        for (int r = 1; r < K; ++r) {                          // rank 0 = age 12 = always a range miss
+            const int k = (k0 + r) % K;                        // my slot of this age
+            uint64_t wsel = ovl[0];
+            if (OW == 3) wsel = ((k * FW) / 64 == 0) ? ovl[0] : (((k * FW) / 64 == 1) ? ovl[OW > 1 ? 1 : 0] : ovl[OW > 2 ? 2 : 0]);
+            const uint32_t m = uint32_t(wsel >> ((k * FW) % 64)) & ((1u << FW) - 1u);
+            if (__ballot(m != 0) == 0ull) continue;            // wave-uniform: nobody has a candidate of this age
+            for (int i = 0; i < n; ++i) {
+                if (m != 0 && (a - (team ? n : 0)) == i) {
+                    for (int j = 0; j < n; ++j) {
+                        if (((m >> j) & 1u) && s_hp[eb + j] > 0) {
+                            s_hp[eb + j] = s_hp[eb + j] - 1;                                 // Plane.hit
+                            nplane += 1;
+                            consumed |= 1u << k;
+                            break;
+                        }
                     }
                 }
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
         }
+        live &= ~consumed;
     }
-    if (consumed_rank) live &= ~rotl12(consumed_rank, k0);
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
-    // ---- deaths, bases, win / tie (battle_env.py:353-372, :469-496)
+    // ---- rewards (battle_env.py:337-359), deaths, bases, win / tie (:363-372, :469-496)
+    double rew = double(nmiss) * p.cfg.miss_punishment + double(nbase) * p.cfg.hit_base_reward +
+                 double(nplane) * p.cfg.hit_plane_reward;
     bool alive = valid && hp > 0;
-    if (mode == M_PHYS && valid) {
+    if (mode == M_PHYS) {
         const int hp_new = s_hp[tid];
         if (alive0 && hp_new <= 0) rew += p.cfg.die_punishment;                              // :359
-        hp = hp_new;
-        alive = hp > 0;
-        er.tick = uint16_t(tick);
-        er.bhp_b = int16_t(er.bhp_b - s_bhit[gl + 0]);   // red shooters damage the blue base
-        er.bhp_r = int16_t(er.bhp_r - s_bhit[gl + 1]);
+        hp = valid ? hp_new : hp;
+        alive = valid && hp > 0;
+        er.tick = tick;
+        er.bhp_b -= s_bhit[gl + 0];                      // red shooters damage the blue base
+        er.bhp_r -= s_bhit[gl + 1];
         if (er.bhp_b <= 0) {                             // blue base dead: every red plane gets lose_punishment; red wins
             if (team == 0) rew += p.cfg.lose_punishment;
             er.winner = BSX_WINNER_RED; er.done = 1; cnt_delta.x += 1; cnt_delta.z += 1;
@@ -446,31 +587,76 @@ __global__ __launch_bounds__(TPB) void bsx_step_kernel(const StepArgs p) {
             er.winner = BSX_WINNER_BLUE; er.done = 1; cnt_delta.x += 1; cnt_delta.w += 1;
         }
     } else if (mode == M_TIE) {
-        er.tick = uint16_t(tick);
+        er.tick = tick;
         er.winner = BSX_WINNER_TIE; er.done = 1; cnt_delta.x += 1; cnt_delta.y += 1;
     }
 
+    STAMP(6);
     // ---- write back
     if (valid) {
-        if (mode == M_PHYS || mode == M_RESET) {
-            pr.x = int16_t(x); pr.y = int16_t(y); pr.live = uint16_t(live); pr.hp = int8_t(hp); pr.dir = dir;
-            p.st.plane[g] = pr;
-        }
+        if (mode == M_PHYS || mode == M_RESET)
+            reinterpret_cast<uint4*>(p.st.plane)[g] = pack_plane(x, y, live, hp, dir);
         p.rew[g] = float(rew);
         p.done[g] = er.done ? uint8_t(1) : uint8_t(alive ? 0 : 1);
-        write_obs<N>(p.obs + g * size_t(3 * n + 2), n, alive, x, y, dir, a,
-                     team == 0 ? er.bbx : er.brx, team == 0 ? er.bby : er.bry, gl, s_x, s_y, s_hp);
-        if (a == 0) {
-            if (mode != M_INERT) p.st.env[e] = er;
-            if (cnt_delta.x) {
-                int4 c = p.st.cnt[e];
-                c.x += cnt_delta.x; c.y += cnt_delta.y; c.z += cnt_delta.z; c.w += cnt_delta.w;
-                p.st.cnt[e] = c;
+    }
+    // observation row: a dead observer sees all -1, a dead enemy is [-1,-1,-1] (battle_env.py:215-218,235-242).
+    // Rows are staged in LDS ([lane][D], D odd -> conflict-free) and leave as coalesced 16-byte stores: the wave's rows
+    // are one contiguous block of global memory when every lane is an agent (G == A).
+    {
+        const int D = 3 * n + 2;
+        float* srow = const_cast<float*>(&s_obs[tid * D]);
+        srow[0] = alive ? ob_d : -1.0f;
+        srow[1] = alive ? ob_a : -1.0f;
+        if (N > 0) {
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                const bool on = alive && s_hp[eb + j] > 0;
+                srow[2 + 3 * j] = on ? 1.0f : -1.0f;
+                srow[3 + 3 * j] = on ? oe_d[j] : -1.0f;
+                srow[4 + 3 * j] = on ? oe_a[j] : -1.0f;
             }
-            if (p.env_done) p.env_done[e] = er.done;
-            if (p.winner) p.winner[e] = er.winner;
+        } else {
+            for (int j = 0; j < n; ++j) {
+                const bool on = alive && s_hp[eb + j] > 0;
+                float od = -1.0f, oa = -1.0f;
+                if (on && !(DIAG & 1u)) obs_pair(x, y, dir, s_x[eb + j], s_y[eb + j], od, oa);
+                srow[2 + 3 * j] = on ? 1.0f : -1.0f; srow[3 + 3 * j] = od; srow[4 + 3 * j] = oa;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (G == A && (reinterpret_cast<uintptr_t>(p.obs) & 15u) == 0) {
+            // rows of this wave: global floats [base, base + rows*D); the wave's offset SPB*D*4 bytes is a multiple of 16
+            const int64_t e_first = int64_t(blockIdx.x) * EPB;
+            const int64_t rows = min(int64_t(SPB), (p.E - e_first) * A);
+            const int64_t nfl = rows * D;                                   // floats to write
+            float* gbase = p.obs + size_t(e_first) * A * D;
+            for (int i = tid * 4; i < nfl; i += SPB * 4) {
+                if (i + 4 <= nfl) {
+                    const float4 v = make_float4(s_obs[i], s_obs[i + 1], s_obs[i + 2], s_obs[i + 3]);
+                    *reinterpret_cast<float4*>(gbase + i) = v;
+                } else {
+                    for (int t = i; t < nfl; ++t) gbase[t] = s_obs[t];
+                }
+            }
+        } else if (valid) {
+            float* out = p.obs + g * size_t(D);
+            for (int i = 0; i < D; ++i) out[i] = srow[i];
         }
     }
+    if (valid) {
+        if (a == 0) {
+            if (mode != M_INERT) reinterpret_cast<uint4*>(p.st.env)[e] = pack_env(er);
+            if (cnt_delta.x) {                           // game over: rare read-modify-write of the counters
+                int4 cnt = p.st.cnt[e];
+                cnt.x += cnt_delta.x; cnt.y += cnt_delta.y; cnt.z += cnt_delta.z; cnt.w += cnt_delta.w;
+                p.st.cnt[e] = cnt;
+            }
+            if (p.env_done) p.env_done[e] = uint8_t(er.done);
+            if (p.winner) p.winner[e] = uint8_t(er.winner);
+        }
+    }
+    STAMP(7);
 }
 
 // ---------------------------------------------------------------------------------------------- reset / observe
@@ -568,8 +754,8 @@ __global__ __launch_bounds__(TPB) void bsx_export_kernel(const ExportArgs p) {
 }
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
-inline int grid_for(int64_t E, int n) {
-    const int epb = TPB / group_width(n);
+inline int grid_for(int64_t E, int n, int tpb = TPB) {
+    const int epb = tpb / group_width(n);
     return int((E + epb - 1) / epb);
 }
 
@@ -588,7 +774,7 @@ int launch_step(void* state, int64_t E, int n, const void* actions, int action_k
     a.E = E; a.n = n; a.actions = actions; a.action_kind = action_kind; a.u = u;
     a.obs = obs; a.rew = rew; a.done = done; a.env_done = env_done; a.winner = winner;
     a.cfg = *cfg; a.flags = flags; a.seed = seed; a.env_offset = env_offset; a.tie_tick = bsx_tie_tick(n);
-    const dim3 grid(grid_for(E, n)), block(TPB);
+    const dim3 grid(grid_for(E, n, SPB)), block(SPB);
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (n) {
         case 1: hipLaunchKernelGGL((bsx_step_kernel<1, CONT>), grid, block, 0, s, a); break;
@@ -689,5 +875,13 @@ int bsx_export_state(const void* state, int64_t E, int n, const BsxExport* out, 
                        static_cast<hipStream_t>(stream), a);
     return int(hipGetLastError());
 }
+
+#ifdef BSX_STAMPS
+// diagnostic builds only: where the stamps go (device buffer of 8 * waves uint64)
+int bsx_debug_set_stamps(void* buf) {
+    unsigned long long* p = static_cast<unsigned long long*>(buf);
+    return int(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)));
+}
+#endif
 
 }  // extern "C"

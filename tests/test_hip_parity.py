@@ -110,3 +110,27 @@ def test_dropin_same_seed_same_game_as_reference():
             assert env.env_done == bool(t["env_done"][s])
     assert env.total_games == int(t["total_games"][-1]) and env.ties == int(t["ties"][-1])
     assert env.team["red"]["wins"] == int(t["wins_red"][-1]) and env.team["blue"]["wins"] == int(t["wins_blue"][-1])
+
+
+def test_principal_directions_hit_the_wrap_boundaries_exactly():
+    """rel_angle's +-180 wrap (battle_env.py:50-51) is reached EXACTLY by integer geometry along the 8 principal
+    directions; a last-bit error in atan2 there would flip an observation between +0.5 and -0.5.  Every heading
+    multiple of 15 x every principal offset, target = enemy base and enemy plane, against the CPU oracle."""
+    from oracle import battlespace_ref as ref
+    offs = [(200, 0), (-200, 0), (0, 150), (0, -150), (120, 120), (-120, 120), (120, -120), (-120, -120), (1, 0), (0, -1), (-1, 1)]
+    rows = []
+    for d in range(0, 361, 15):
+        for (dx, dy) in offs:
+            # plane0 at (600,400) heading d; enemy base at +off, enemy plane at -off (so one of them is "behind")
+            rows.append([100, 100, 600 + dx, 400 + dy, 600, 400, d, 600 - dx, 400 - dy, (d + 180) % 360])
+    spawn = np.asarray(rows, np.int32)
+    env = _env(n_envs=len(rows), rng="philox")
+    obs = env.reset(spawn=spawn)
+    got = np.stack([obs[a].cpu().numpy() for a in env.possible_agents], 1)
+    o = ref.RefEnv()
+    for i, r in enumerate(rows):
+        exp = o.reset(spawn=r)
+        want = np.stack([exp[a] for a in o.possible_agents])
+        assert np.array_equal(got[i][:, [1, 4]], want[:, [1, 4]]), (r, got[i], want)      # angles: bit-exact
+        np.testing.assert_allclose(got[i], want, rtol=1e-6, atol=1e-7)
+    assert set(np.unique(np.abs(got[:, :, [1, 4]]))) >= {0.0, 0.5}                          # the boundaries were exercised
