@@ -1,7 +1,7 @@
 """Diagnostic (GPU box): build a stamped library copy, run C2 steps, print per-phase shares of a wave's lifetime."""
 import ctypes, os, subprocess, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 src = os.path.join(ROOT, "deep-rl-battlespace_amd/csrc")
 lib = os.path.join(src, "libbattlespace_hip.so")
 os.rename(lib, lib + ".product")
