@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--mode", choices=("graph", "eager"), default="graph")
     ap.add_argument("--graph-len", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="process-group backend for the barrier / timing reduction (nccl = RCCL; gloo only to rehearse N>1 on a 1-GPU box)")
+    ap.add_argument("--rehearse-on-device0", action="store_true", help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -94,10 +97,15 @@ def main():
     rank, world, local_rank = sharding.rank_world()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)      # RCCL; used for the barrier / max-time reduction only
+    dev_index = 0 if args.rehearse_on_device0 else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")
+    if world > 1:                                           # used for the barrier / max-time reduction only
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
 
     n, E = args.n_agents, args.envs_per_gpu
     A = 2 * n
@@ -140,11 +148,11 @@ def main():
     dt = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / K                  # average launch-to-launch duration on the launch stream
     if world > 1:
-        t = torch.tensor([dt, kernel_ms], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt, kernel_ms], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, kernel_ms = float(t[0]), float(t[1])
 
-    games = sharding.reduce_counters(sharding.local_counter_sums(env))   # logging only, after the timed region
+    games = sharding.reduce_counters(sharding.local_counter_sums(env).to(red_dev))   # logging only, after the timed region
     if rank == 0:
         agent_steps = E * world * A * K
         bytes_per_launch = b_alg(n) * E * A

@@ -141,3 +141,55 @@ def test_graph_replay_equals_eager_steps():
             assert torch.equal(o, go[t]) and torch.equal(r, gr[t]) and torch.equal(d, gd[t]), (rep, t)
     sa, sb = a.export_state(), b.export_state()
     assert all(torch.equal(sa[k], sb[k]) for k in ("px", "py", "php", "tick", "counters", "bl_live"))
+
+
+def _compare_generic(E, n, T, seed, cont=False, logits=False, f32=False):
+    """HIP vs C oracle in the production configuration for any action encoding; ragged sizes (E not a multiple of the
+    games-per-wave count) exercise the clamped-index lanes and the partial last wavefront."""
+    A = 2 * n
+    env = _env(n_agents=n, n_envs=E, seed=seed, auto_reset=True, continuous_actions=cont)
+    c = cref.CRefBatch(E, n_agents=n, seed=seed, auto_reset=True, continuous_actions=cont)
+    env.reset(); c.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    n_exact = n_vals = 0
+    for t in range(T):
+        if cont:
+            a = (torch.rand((E, A, 3), generator=g, device="cuda", dtype=torch.float64) * 2.6 - 1.3)
+            a = a.to(torch.float32) if f32 else a
+            a[..., 2] = torch.where(torch.rand((E, A), generator=g, device="cuda") < 0.5, a[..., 2].abs(), a[..., 2])
+        elif logits:
+            a = torch.randn((E, A, 4), generator=g, device="cuda", dtype=torch.float32)
+            a[..., 1] += 0.8
+        else:
+            a = torch.randint(-1, 5, (E, A), generator=g, device="cuda", dtype=torch.int32)
+            a = torch.where(torch.rand((E, A), generator=g, device="cuda") < 0.5, torch.ones_like(a), a)
+        obs, rew, done = env.step_batch(a)
+        co, cr, cd = c.step(a.cpu().numpy())
+        o = obs.cpu().numpy()
+        assert np.array_equal(done.cpu().numpy(), cd), f"step {t}: done"
+        np.testing.assert_allclose(rew.cpu().numpy(), cr, rtol=1e-6, atol=1e-6, err_msg=f"step {t}: rew")
+        np.testing.assert_allclose(o, co, rtol=OBS_RTOL, atol=OBS_ATOL, err_msg=f"step {t}: obs")
+        n_exact += int((o == co).sum()); n_vals += o.size
+    sh = {k: v.cpu().numpy() for k, v in env.export_state().items()}
+    sc = c.export_state()
+    for f in ("px", "py", "pdir", "php", "bhp", "tick", "env_done", "winner", "bl_live", "counters"):
+        assert np.array_equal(sh[f], sc[f]), f
+    m = sc["bl_live"].astype(bool)
+    assert np.array_equal(sh["bl_x"][m], sc["bl_x"][m]) and np.array_equal(sh["bl_dir"][m], sc["bl_dir"][m])
+    assert n_exact >= n_vals * (1 - 2e-3)
+
+
+@pytest.mark.parametrize("E,n", [(1, 1), (31, 1), (33, 1), (1000, 2), (7, 3), (129, 4), (50, 5), (40, 8), (9, 16)])
+def test_ragged_sizes_and_every_team_size_vs_c_oracle(E, n):
+    _compare_generic(E, n, 10 * (10 + 2 * n) + 25, seed=100 + E + n)
+
+
+@pytest.mark.parametrize("n,f32", [(1, False), (1, True), (2, False), (4, True)])
+def test_continuous_actions_vs_c_oracle(n, f32):
+    """battle_env.py:418-424 at scale: float64 and float32 action tensors (clipped in-kernel), in-kernel jitter."""
+    _compare_generic(8192, n, 150, seed=300 + n, cont=True, f32=f32)
+
+
+def test_score_vector_actions_vs_c_oracle():
+    """[E, A, 4] score vectors arg-maxed in-kernel (battle_env.py:327-328)."""
+    _compare_generic(8192, 2, 150, seed=77, logits=True)
