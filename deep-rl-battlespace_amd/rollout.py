@@ -1,0 +1,124 @@
+"""On-device policy rollout feeding the fused step() (BASELINE.json configs[4]).
+
+The reference's callers run, per tick and per agent, `actor(obs) + noise -> clamp -> numpy -> env.step -> argmax`
+(maddpg/agent.py:25-33, main.py:179-181, envs/battle_env.py:327-328), crossing the host for every agent.  Here the
+whole loop `obs -> actor -> score vectors -> step() -> obs'` stays on the MI355X: the actors of all A agents are one
+stacked module evaluated with batched GEMMs (hipBLASLt through torch -- plain library GEMMs, 5..14 -> 64 -> 64 -> 4),
+the score vectors go straight into `bsx_step_discrete`'s arg-max path, T ticks are captured into one HIP graph and
+the transition buffers (`[T, E, A, ...]`) live in HBM for a learner to consume.  No host round trip inside a rollout.
+
+`StackedActor` reproduces the reference ActorNetwork (maddpg/networks.py:54-85): Linear(obs,64) -> LayerNorm -> ReLU ->
+Linear(64,64) -> LayerNorm -> ReLU -> Linear(64,n_actions) -> tanh, same initialisation; one set of weights per
+agent (MADDPG keeps one actor per plane), loadable from the reference's per-agent `state_dict` checkpoints.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import _lib
+
+
+class StackedActor(nn.Module):
+    """A independent actors evaluated together: parameters carry a leading agent axis."""
+
+    def __init__(self, n_actors, obs_len, n_actions, fc1_dims=64, fc2_dims=64, device=None, dtype=torch.float32):
+        super().__init__()
+        A, kw = n_actors, dict(device=device, dtype=dtype)
+        self.n_actors, self.obs_len, self.n_actions = A, obs_len, n_actions
+        f1, f2, f3 = 1.0 / math.sqrt(fc1_dims), 1.0 / math.sqrt(fc2_dims), 0.003     # networks.py:59,65,71
+
+        def uni(shape, f):
+            return nn.Parameter(torch.empty(shape, **kw).uniform_(-f, f))
+        self.w1, self.b1 = uni((A, obs_len, fc1_dims), f1), uni((A, 1, fc1_dims), f1)
+        self.g1, self.h1 = nn.Parameter(torch.ones((A, 1, fc1_dims), **kw)), nn.Parameter(torch.zeros((A, 1, fc1_dims), **kw))
+        self.w2, self.b2 = uni((A, fc1_dims, fc2_dims), f2), uni((A, 1, fc2_dims), f2)
+        self.g2, self.h2 = nn.Parameter(torch.ones((A, 1, fc2_dims), **kw)), nn.Parameter(torch.zeros((A, 1, fc2_dims), **kw))
+        self.w3, self.b3 = uni((A, fc2_dims, n_actions), f3), uni((A, 1, n_actions), f3)
+
+    @staticmethod
+    def _ln(x, g, h, eps=1e-5):
+        return torch.nn.functional.layer_norm(x, x.shape[-1:], None, None, eps) * g + h
+
+    def forward(self, obs):
+        """obs [E, A, D] -> scores [E, A, n_actions] (tanh-squashed, as the reference's actor output)."""
+        x = obs.transpose(0, 1)                                     # [A, E, D]
+        x = torch.relu(self._ln(torch.baddbmm(self.b1, x, self.w1), self.g1, self.h1))
+        x = torch.relu(self._ln(torch.baddbmm(self.b2, x, self.w2), self.g2, self.h2))
+        x = torch.tanh(torch.baddbmm(self.b3, x, self.w3))
+        return x.transpose(0, 1)
+
+    @torch.no_grad()
+    def load_reference_actor(self, agent_index, state_dict):
+        """Copy one reference ActorNetwork checkpoint (keys fc1/bn1/fc2/bn2/pi .weight/.bias, networks.py:58-75) into
+        slot `agent_index`."""
+        i = agent_index
+        self.w1[i].copy_(state_dict["fc1.weight"].t()); self.b1[i, 0].copy_(state_dict["fc1.bias"])
+        self.g1[i, 0].copy_(state_dict["bn1.weight"]); self.h1[i, 0].copy_(state_dict["bn1.bias"])
+        self.w2[i].copy_(state_dict["fc2.weight"].t()); self.b2[i, 0].copy_(state_dict["fc2.bias"])
+        self.g2[i, 0].copy_(state_dict["bn2.weight"]); self.h2[i, 0].copy_(state_dict["bn2.bias"])
+        self.w3[i].copy_(state_dict["pi.weight"].t()); self.b3[i, 0].copy_(state_dict["pi.bias"])
+
+
+class PolicyRollout:
+    """T ticks of (actor -> step) for all games, captured once into a HIP graph and replayed.
+
+        ro = PolicyRollout(env, actor, T=32, noise_std=0.1)
+        ro.start(); ro.capture()
+        ro.run()                       # one replay = T ticks of every game
+        ro.obs[t], ro.scores[t], ro.rew[t], ro.done[t], ro.obs[t+1]   # transition t, buffers in HBM
+
+    The env must be batched, discrete, rng='philox'; auto_reset is recommended (finished games re-spawn in place).
+    Exploration noise is Gaussian on the score vectors (the reference adds OU noise, utils/noise.py; OU state would
+    be one more [E, A, 4] tensor updated in the same graph), then clamp(-1, 1) as maddpg/agent.py:31 does."""
+
+    def __init__(self, env, actor, T, noise_std=0.0):
+        if env.continuous_actions or env._compat or env.rng != "philox":
+            raise ValueError("PolicyRollout needs a batched discrete env with rng='philox'")
+        self.env, self.actor, self.T, self.noise_std = env, actor, int(T), float(noise_std)
+        E, A, D, dev = env.n_envs, env._A, env.obs_size, env.device
+        self.obs = torch.empty((T + 1, E, A, D), dtype=torch.float32, device=dev)
+        self.scores = torch.empty((T, E, A, 4), dtype=torch.float32, device=dev)
+        self.rew = torch.empty((T, E, A), dtype=torch.float32, device=dev)
+        self._done = torch.empty((T, E, A), dtype=torch.uint8, device=dev)
+        self.done = self._done.view(torch.bool)
+        self.graph = None
+
+    def _tick(self, t):
+        with torch.no_grad():
+            s = self.actor(self.obs[t])
+            if self.noise_std > 0.0:
+                s = (s + self.noise_std * torch.randn_like(s)).clamp_(-1.0, 1.0)
+            self.scores[t].copy_(s)
+        self.env._launch(self.scores[t].data_ptr(), _lib.ACT_LOGITS_F32, False, None,
+                         self.obs[t + 1].data_ptr(), self.rew[t].data_ptr(), self._done[t].data_ptr())
+
+    def start(self):
+        """Begin from the env's current observations (call after env.reset())."""
+        self.obs[self.T].copy_(self.env._obs)          # every run starts by moving obs[T] to obs[0]
+
+    def capture(self):
+        """Record the T ticks into a HIP graph (one warm-up pass runs first, on a side stream, as torch requires)."""
+        s = torch.cuda.Stream(device=self.env.device)
+        s.wait_stream(torch.cuda.current_stream(self.env.device))
+        with torch.cuda.stream(s):
+            with torch.no_grad():
+                self.actor(self.obs[self.T])           # library warm-up (hipBLASLt handles, workspaces) outside the capture
+        torch.cuda.current_stream(self.env.device).wait_stream(s)
+        torch.cuda.synchronize(self.env.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._body()
+        return self
+
+    def _body(self):
+        self.obs[0].copy_(self.obs[self.T])            # continue where the previous rollout ended
+        for t in range(self.T):
+            self._tick(t)
+
+    def run(self):
+        """T ticks (asynchronous).  Afterwards obs[0..T], scores, rew, done hold this rollout's transitions."""
+        if self.graph is None:
+            self._body()
+        else:
+            self.graph.replay()

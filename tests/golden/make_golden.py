@@ -530,9 +530,38 @@ def scripted(be, tap):
     rec.save("g5_scripted_2v2", dict(driver="hand-scripted 2v2 edge cases"))
 
 
+def actor_fixture():
+    """G9: the reference ActorNetwork (maddpg/networks.py:54-85), seeded random init, on random observation rows:
+    weights + inputs + outputs, to pin the stacked on-device actor's forward pass.  (torch only; no stand-ins.)"""
+    import torch
+    sys.path[:0] = [REF]
+    import maddpg.networks as nets
+    torch.manual_seed(9)
+    out = {}
+    for tag, obs_len in (("1v1", 5), ("2v2", 8), ("4v4", 14)):
+        net = nets.ActorNetwork(obs_len, 4, chkpt_dir="/tmp", name="g9").to("cpu")
+        with torch.no_grad():
+            net.bn1.weight.uniform_(0.5, 1.5); net.bn1.bias.uniform_(-0.2, 0.2)      # non-trivial LayerNorm affine
+            net.bn2.weight.uniform_(0.5, 1.5); net.bn2.bias.uniform_(-0.2, 0.2)
+            net.pi.weight.uniform_(-0.5, 0.5)                                           # make tanh outputs distinguishable
+        net.eval()
+        x = torch.rand(64, obs_len) * 2 - 1
+        with torch.no_grad():
+            y = net.forward(x)
+        for k, v in net.state_dict().items():
+            out[f"{tag}/{k}"] = v.numpy()
+        out[f"{tag}/x"] = x.numpy(); out[f"{tag}/y"] = y.numpy()
+    np.savez_compressed(os.path.join(HERE, "g9_actor_forward.npz"), **out)
+    print("g9_actor_forward:", sorted(out)[:6], "...")
+
+
 if __name__ == "__main__":
+    if "--actor-only" in sys.argv:
+        actor_fixture()
+        sys.exit(0)
     cwd = os.getcwd()
     try:
         main()
     finally:
         os.chdir(cwd)
+    actor_fixture()

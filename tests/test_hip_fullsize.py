@@ -193,3 +193,31 @@ def test_continuous_actions_vs_c_oracle(n, f32):
 def test_score_vector_actions_vs_c_oracle():
     """[E, A, 4] score vectors arg-maxed in-kernel (battle_env.py:327-328)."""
     _compare_generic(8192, 2, 150, seed=77, logits=True)
+
+
+def test_policy_rollout_graph_equals_eager_loop():
+    """configs[4] plumbing: actor -> score vectors -> step() captured in one HIP graph plays the same games as the
+    tick-by-tick loop, and the transition buffers are consistent (obs[t+1] of tick t is obs[t] of tick t+1's input)."""
+    from deep_rl_battlespace_amd.rollout import PolicyRollout, StackedActor
+    E, n, T = 2048, 2, 24
+    torch.manual_seed(3)
+    actor = StackedActor(2 * n, 3 * n + 2, 4, device="cuda")
+    with torch.no_grad():
+        actor.w3.mul_(200.0)                                    # decisive scores (default init is +-0.003)
+    a = _env(n_agents=n, n_envs=E, seed=21, auto_reset=True); a.reset()
+    b = _env(n_agents=n, n_envs=E, seed=21, auto_reset=True); b.reset()
+    ro = PolicyRollout(b, actor, T)
+    ro.start(); ro.capture()
+    obs = a._obs.clone()
+    for rep in range(3):
+        ro.run()
+        torch.cuda.synchronize()
+        assert torch.equal(ro.obs[0], obs)
+        for t in range(T):
+            with torch.no_grad():
+                s = actor(obs)
+            o, r, d = a.step_batch(s.contiguous())
+            assert torch.equal(ro.scores[t], s) and torch.equal(ro.obs[t + 1], o) and torch.equal(ro.rew[t], r) and torch.equal(ro.done[t], d), (rep, t)
+            obs = o.clone()
+    acts = ro.scores.argmax(-1)
+    assert len(torch.unique(acts)) >= 3                        # the policy actually uses several actions

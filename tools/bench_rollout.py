@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""configs[4]: 65 536 games x 1v1 feeding an on-device actor, end-to-end agent-steps/s.
+Prints one JSON line: rollout (actor + step, one HIP graph of T ticks), and for reference the env alone and the
+actor alone at the same shapes.  Runs on the GPU box: python tools/bench_rollout.py [--envs E] [--n-agents n]"""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import torch
+import deep_rl_battlespace_amd as bsx
+from deep_rl_battlespace_amd.rollout import PolicyRollout, StackedActor
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--envs", type=int, default=65536); ap.add_argument("--n-agents", type=int, default=1)
+ap.add_argument("--T", type=int, default=32); ap.add_argument("--reps", type=int, default=40)
+ap.add_argument("--noise", type=float, default=0.1)
+args = ap.parse_args()
+E, n, T = args.envs, args.n_agents, args.T
+A, D = 2 * n, 3 * n + 2
+env = bsx.parallel_env(n_agents=n, n_envs=E, auto_reset=True, seed=1234)
+env.reset()
+torch.manual_seed(0)
+actor = StackedActor(A, D, 4, device="cuda")
+with torch.no_grad():
+    actor.w3.mul_(100.0)
+ro = PolicyRollout(env, actor, T, noise_std=args.noise)
+ro.start(); ro.capture()
+
+
+def timed(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+t_roll = timed(ro.run, args.reps) / T
+# env alone (same score-vector input path), actor alone
+g_env, _ = env.capture_steps(ro.scores)
+t_env = timed(g_env.replay, args.reps) / T
+g_act = torch.cuda.CUDAGraph()
+x = ro.obs[1]
+with torch.no_grad():
+    actor(x); torch.cuda.synchronize()
+    with torch.cuda.graph(g_act):
+        for _ in range(T):
+            y = actor(x)
+t_act = timed(g_act.replay, args.reps) / T
+c = env.counters().sum(0)
+print(json.dumps({"workload": f"{E} games x {n}v{n} + on-device actor (obs {D} -> 64 -> LN -> 64 -> LN -> 4, one per agent), T={T} ticks per graph",
+                  "rollout_agent_steps_per_s": round(E * A / t_roll, 1), "rollout_us_per_tick": round(t_roll * 1e6, 2),
+                  "env_only_us_per_tick": round(t_env * 1e6, 2), "actor_only_us_per_tick": round(t_act * 1e6, 2),
+                  "noise_std": args.noise, "games_finished": int(c[0]), "ties": int(c[1]), "red_wins": int(c[2]), "blue_wins": int(c[3])}))
