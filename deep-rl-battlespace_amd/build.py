@@ -13,16 +13,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "libbattlespace_hip.so")
-SOURCES = [os.path.join(CSRC, "bsx_kernels.hip")]
-HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-               "-Wall", "-Wno-unused-function"]
+COMMON = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# (source, extra flags).  The step path forbids FMA contraction (bit-exact float64 add-then-truncate); the actor MLP
+# has no such contract and wants contraction.
+SOURCES = [(os.path.join(CSRC, "bsx_kernels.hip"), ["-ffp-contract=off"]),
+           (os.path.join(CSRC, "bsx_actor.hip"), ["-ffp-contract=fast"])]
 
 
 def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = SOURCES + [os.path.join(INCLUDE, "battlespace_hip.h")]
+    deps = [src for src, _ in SOURCES] + [os.path.join(INCLUDE, "battlespace_hip.h"), os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -31,7 +33,15 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, *HIPCC_FLAGS, "-I", INCLUDE, *SOURCES, "-o", LIB]
+    objs = []
+    for src, extra in SOURCES:
+        obj = os.path.splitext(src)[0] + ".o"
+        cmd = [hipcc, *COMMON, *extra, "-I", INCLUDE, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

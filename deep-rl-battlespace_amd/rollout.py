@@ -49,6 +49,22 @@ class StackedActor(nn.Module):
         return x.transpose(0, 1)
 
     @torch.no_grad()
+    def pack(self, out=None):
+        """Weights in the layout `bsx_actor_forward` reads (include/battlespace_hip.h): per agent
+        W1[D][64] b1 ln1_gain ln1_bias W2[64][64] b2 ln2_gain ln2_bias W3[64][4] b3, float32, contiguous."""
+        if self.w1.shape[2] != 64 or self.w2.shape[2] != 64 or self.n_actions != 4:
+            raise ValueError("the fused actor kernel is built for fc1 = fc2 = 64 and 4 action scores (main.py:15-16)")
+        A = self.n_actors
+        parts = [self.w1.reshape(A, -1), self.b1.reshape(A, -1), self.g1.reshape(A, -1), self.h1.reshape(A, -1),
+                 self.w2.reshape(A, -1), self.b2.reshape(A, -1), self.g2.reshape(A, -1), self.h2.reshape(A, -1),
+                 self.w3.reshape(A, -1), self.b3.reshape(A, -1)]
+        blob = torch.cat([p.float() for p in parts], dim=1).contiguous()
+        if out is not None:
+            out.copy_(blob)
+            return out
+        return blob
+
+    @torch.no_grad()
     def load_reference_actor(self, agent_index, state_dict):
         """Copy one reference ActorNetwork checkpoint (keys fc1/bn1/fc2/bn2/pi .weight/.bias, networks.py:58-75) into
         slot `agent_index`."""
@@ -58,6 +74,44 @@ class StackedActor(nn.Module):
         self.w2[i].copy_(state_dict["fc2.weight"].t()); self.b2[i, 0].copy_(state_dict["fc2.bias"])
         self.g2[i, 0].copy_(state_dict["bn2.weight"]); self.h2[i, 0].copy_(state_dict["bn2.bias"])
         self.w3[i].copy_(state_dict["pi.weight"].t()); self.b3[i, 0].copy_(state_dict["pi.bias"])
+
+
+class FusedActor:
+    """The same per-agent actor as ONE hand-written HIP kernel (csrc/bsx_actor.hip, `bsx_actor_forward`): a row never
+    leaves registers -- 4*D bytes in, 16 bytes out -- instead of ~20 memory-bound torch passes over [A, E, 64]
+    activations.  Holds a packed copy of a StackedActor's weights; call `refresh()` after the learner updates them.
+    Optional exploration noise (Gaussian, then clamp(-1, 1) as maddpg/agent.py:31) is drawn in-kernel."""
+
+    def __init__(self, actor, n_agents_per_team, seed=0):
+        self.actor, self.n = actor, int(n_agents_per_team)
+        if actor.n_actors != 2 * self.n or actor.obs_len != 3 * self.n + 2:
+            raise ValueError("actor shape does not match the env")
+        self._lib = _lib.load()
+        self.weights = actor.pack()
+        nf = _lib.c_int()
+        _lib.check(self._lib.bsx_actor_blob_floats(actor.obs_len, _lib.ctypes.byref(nf)), "bsx_actor_blob_floats")
+        assert self.weights.shape == (actor.n_actors, nf.value), (self.weights.shape, nf.value)
+        self.seed, self.seq = int(seed), 0
+
+    def refresh(self):
+        self.actor.pack(out=self.weights)
+
+    def forward_into(self, obs, scores, noise_std=0.0, seq=None, seq_base=None):
+        """obs f32 [E, A, D] (contiguous) -> scores f32 [E, A, 4] (contiguous, 16-byte aligned), on the current stream.
+        seq_base: optional int64 device tensor (1 element) added to `seq` in-kernel (for captured graphs)."""
+        E = obs.shape[0]
+        if seq is None:
+            self.seq += 1
+            seq = self.seq
+        _lib.check(self._lib.bsx_actor_forward(self.weights.data_ptr(), obs.data_ptr(), scores.data_ptr(), E, self.n,
+                                               float(noise_std), self.seed, int(seq),
+                                               seq_base.data_ptr() if seq_base is not None else None,
+                                               torch.cuda.current_stream(obs.device).cuda_stream), "bsx_actor_forward")
+        return scores
+
+    def __call__(self, obs, noise_std=0.0, seq=None):
+        scores = torch.empty((*obs.shape[:2], 4), dtype=torch.float32, device=obs.device)
+        return self.forward_into(obs.contiguous(), scores, noise_std, seq)
 
 
 class PolicyRollout:
@@ -72,10 +126,14 @@ class PolicyRollout:
     Exploration noise is Gaussian on the score vectors (the reference adds OU noise, utils/noise.py; OU state would
     be one more [E, A, 4] tensor updated in the same graph), then clamp(-1, 1) as maddpg/agent.py:31 does."""
 
-    def __init__(self, env, actor, T, noise_std=0.0):
+    def __init__(self, env, actor, T, noise_std=0.0, fused=True, seed=0):
+        """actor: a StackedActor.  fused=True evaluates it with the hand-written HIP kernel (FusedActor), False with
+        torch ops (the fp32 reference of the same op)."""
         if env.continuous_actions or env._compat or env.rng != "philox":
             raise ValueError("PolicyRollout needs a batched discrete env with rng='philox'")
         self.env, self.actor, self.T, self.noise_std = env, actor, int(T), float(noise_std)
+        self.fused = FusedActor(actor, env.n_agents, seed=seed) if fused else None
+        self._seq_base = torch.zeros(1, dtype=torch.int64, device=env.device)
         E, A, D, dev = env.n_envs, env._A, env.obs_size, env.device
         self.obs = torch.empty((T + 1, E, A, D), dtype=torch.float32, device=dev)
         self.scores = torch.empty((T, E, A, 4), dtype=torch.float32, device=dev)
@@ -85,6 +143,13 @@ class PolicyRollout:
         self.graph = None
 
     def _tick(self, t):
+        if self.fused is not None:
+            # graph arguments are frozen: the noise key is (seed, seq_base + t, row) with seq_base a device word that the
+            # graph advances by T once per replay (_body)
+            self.fused.forward_into(self.obs[t], self.scores[t], self.noise_std, seq=t, seq_base=self._seq_base)
+            self.env._launch(self.scores[t].data_ptr(), _lib.ACT_LOGITS_F32, False, None,
+                             self.obs[t + 1].data_ptr(), self.rew[t].data_ptr(), self._done[t].data_ptr())
+            return
         with torch.no_grad():
             s = self.actor(self.obs[t])
             if self.noise_std > 0.0:
@@ -115,6 +180,7 @@ class PolicyRollout:
         self.obs[0].copy_(self.obs[self.T])            # continue where the previous rollout ended
         for t in range(self.T):
             self._tick(t)
+        self._seq_base.add_(self.T)                    # fresh exploration-noise keys for the next run
 
     def run(self):
         """T ticks (asynchronous).  Afterwards obs[0..T], scores, rew, done hold this rollout's transitions."""

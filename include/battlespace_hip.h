@@ -110,6 +110,21 @@ typedef struct BsxExport {
 } BsxExport;
 int bsx_export_state(const void* state, int64_t E, int n, const BsxExport* out, void* stream);
 
+/* ---- on-device policy rollout (BASELINE.json configs[4]): the fused per-agent actor in front of bsx_step_discrete.
+ * Replaces, on the rollout path, ActorNetwork.forward + noise + clamp of the reference's callers
+ * (maddpg/networks.py:81-85, maddpg/agent.py:25-33): obs[3n+2] -> 64 -> LayerNorm -> ReLU -> 64 -> LayerNorm -> ReLU ->
+ * 4 -> tanh [-> + N(0, noise_std) -> clamp(-1,1)], one independent weight set per agent a = 0..2n-1.
+ *   weights  float32, 16-byte aligned, 2n blobs of bsx_actor_blob_floats(3n+2) floats each, laid out
+ *            W1[D][64] b1[64] ln1_gain[64] ln1_bias[64] W2[64][64] b2[64] ln2_gain[64] ln2_bias[64] W3[64][4] b3[4]
+ *            (W[k][j] multiplies input k into output j, i.e. the transpose of torch's Linear.weight)
+ *   obs      float32[E*A*D] (what bsx_step_* / bsx_reset wrote);  scores float32[E*A*4], 16-byte aligned: feed it to
+ *            bsx_step_discrete with BSX_ACT_LOGITS_F32.  Noise is Philox-keyed by (seed, seq + *seq_base, row): pass a new
+ *            seq per call, or -- inside a captured HIP graph, whose arguments are frozen -- a device word seq_base (nullable)
+ *            that the graph itself advances once per replay. */
+int bsx_actor_blob_floats(int obs_len, int* floats_per_agent);
+int bsx_actor_forward(const float* weights, const float* obs, float* scores, int64_t E, int n, float noise_std,
+                      uint64_t seed, uint64_t seq, const uint64_t* seq_base, void* stream);
+
 /* Host helper: the call number on which the time-limit tie fires for n-per-team -- the reference accumulates
  * total_time += 0.1 in binary64 and compares >= 10+2n (battle_env.py:168,316-319): 121, 141, 161, 181, 200 ... */
 int bsx_tie_tick(int n);

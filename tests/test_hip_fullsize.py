@@ -221,3 +221,51 @@ def test_policy_rollout_graph_equals_eager_loop():
             obs = o.clone()
     acts = ro.scores.argmax(-1)
     assert len(torch.unique(acts)) >= 3                        # the policy actually uses several actions
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 6])
+def test_fused_actor_matches_torch_fp32_reference(n):
+    """bsx_actor_forward (hand-written HIP) against the torch fp32 composition of the same op (StackedActor), which is
+    itself pinned on the reference ActorNetwork's forward (tests/test_rollout_cpu.py).  fp32, different summation
+    order: 2e-5 absolute on tanh outputs."""
+    from deep_rl_battlespace_amd.rollout import FusedActor, StackedActor
+    torch.manual_seed(10 + n)
+    E, A, D = 5000, 2 * n, 3 * n + 2
+    actor = StackedActor(A, D, 4, device="cuda")
+    with torch.no_grad():
+        actor.w3.mul_(50.0); actor.g1.uniform_(0.5, 1.5); actor.h1.uniform_(-0.3, 0.3); actor.g2.uniform_(0.5, 1.5); actor.h2.uniform_(-0.3, 0.3)
+    fused = FusedActor(actor, n)
+    obs = torch.rand((E, A, D), device="cuda") * 2 - 1
+    obs[::7] = -1.0                                             # dead observers see all -1
+    with torch.no_grad():
+        want = actor(obs)
+    got = fused(obs)
+    torch.testing.assert_close(got, want, rtol=0, atol=2e-5)
+    assert float((got.argmax(-1) == want.argmax(-1)).float().mean()) > 0.999
+    # weights refresh after an update
+    with torch.no_grad():
+        actor.b3.add_(0.1)
+    fused.refresh()
+    torch.testing.assert_close(fused(obs), actor(obs).detach(), rtol=0, atol=2e-5)
+
+
+def test_fused_actor_noise_is_gaussian_clamped_and_rekeyed():
+    from deep_rl_battlespace_amd.rollout import FusedActor, StackedActor
+    torch.manual_seed(1)
+    n, E = 1, 200000
+    actor = StackedActor(2, 5, 4, device="cuda")                 # default init: scores ~ 0 (+-0.003 head)
+    fused = FusedActor(actor, n, seed=5)
+    obs = torch.rand((E, 2, 5), device="cuda") * 2 - 1
+    base = fused(obs, noise_std=0.0)
+    a = fused(obs, noise_std=0.25, seq=7)
+    b = fused(obs, noise_std=0.25, seq=7)
+    c = fused(obs, noise_std=0.25, seq=8)
+    assert torch.equal(a, b) and not torch.equal(a, c)           # deterministic per key, fresh per seq
+    z = (a - base) / 0.25
+    assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1.0) < 0.01
+    assert abs(float((z ** 3).mean())) < 0.03 and abs(float((z ** 4).mean()) - 3.0) < 0.1
+    big = fused(obs, noise_std=5.0, seq=9)
+    assert float(big.max()) <= 1.0 and float(big.min()) >= -1.0 and float((big.abs() == 1.0).float().mean()) > 0.5
+    sb = torch.tensor([1], dtype=torch.int64, device="cuda")
+    d = torch.empty_like(a); fused.forward_into(obs, d, 0.25, seq=6, seq_base=sb)
+    assert torch.equal(d, a)                                     # seq + *seq_base

@@ -11,7 +11,7 @@ from deep_rl_battlespace_amd.rollout import PolicyRollout, StackedActor
 ap = argparse.ArgumentParser()
 ap.add_argument("--envs", type=int, default=65536); ap.add_argument("--n-agents", type=int, default=1)
 ap.add_argument("--T", type=int, default=32); ap.add_argument("--reps", type=int, default=40)
-ap.add_argument("--noise", type=float, default=0.1)
+ap.add_argument("--noise", type=float, default=0.1); ap.add_argument("--torch-actor", action="store_true")
 args = ap.parse_args()
 E, n, T = args.envs, args.n_agents, args.T
 A, D = 2 * n, 3 * n + 2
@@ -21,7 +21,7 @@ torch.manual_seed(0)
 actor = StackedActor(A, D, 4, device="cuda")
 with torch.no_grad():
     actor.w3.mul_(100.0)
-ro = PolicyRollout(env, actor, T, noise_std=args.noise)
+ro = PolicyRollout(env, actor, T, noise_std=args.noise, fused=not args.torch_actor)
 ro.start(); ro.capture()
 
 
@@ -44,11 +44,14 @@ x = ro.obs[1]
 with torch.no_grad():
     actor(x); torch.cuda.synchronize()
     with torch.cuda.graph(g_act):
-        for _ in range(T):
-            y = actor(x)
+        for t in range(T):
+            if ro.fused is not None:
+                ro.fused.forward_into(x, ro.scores[t], args.noise, seq=t)
+            else:
+                y = actor(x)
 t_act = timed(g_act.replay, args.reps) / T
 c = env.counters().sum(0)
 print(json.dumps({"workload": f"{E} games x {n}v{n} + on-device actor (obs {D} -> 64 -> LN -> 64 -> LN -> 4, one per agent), T={T} ticks per graph",
                   "rollout_agent_steps_per_s": round(E * A / t_roll, 1), "rollout_us_per_tick": round(t_roll * 1e6, 2),
                   "env_only_us_per_tick": round(t_env * 1e6, 2), "actor_only_us_per_tick": round(t_act * 1e6, 2),
-                  "noise_std": args.noise, "games_finished": int(c[0]), "ties": int(c[1]), "red_wins": int(c[2]), "blue_wins": int(c[3])}))
+                  "actor": "torch ops" if args.torch_actor else "fused HIP kernel (bsx_actor_forward)", "noise_std": args.noise, "games_finished": int(c[0]), "ties": int(c[1]), "red_wins": int(c[2]), "blue_wins": int(c[3])}))
