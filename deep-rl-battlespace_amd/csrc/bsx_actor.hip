@@ -7,7 +7,7 @@
 // 65 536 x 1v1); fused, a row never leaves registers: 20 B in, 16 B out.
 //
 // Mapping: one lane = one observation row; a workgroup handles 256 rows of ONE agent index, so its weights are
-// workgroup-uniform: staged once in LDS (19 KB) and read as broadcast ds_read_b128 (all lanes, same address).
+// workgroup-uniform: they arrive through the SCALAR path (s_load -> SGPR operands of the FMAs), not LDS or VGPRs.
 // The 64x64 layer is 4096 FMAs per row issued as packed-f32 FMAs (v_pk_fma_f32) with both activation vectors in
 // VGPRs.  f32 MFMA would run at the same rate as packed VALU on gfx950 (64 FLOP/clk/SIMD) and the per-lane row layout
 // needs no fragment shuffles, so this stays on the vector pipe.
@@ -62,7 +62,7 @@ __device__ inline void ln_relu(float (&h)[H], const float* __restrict__ g, const
     }
 }
 
-// out[j] += x * w[j], j = 0..H-1, as packed FMAs; w = 64 contiguous LDS floats (broadcast reads)
+// out[j] += x * w[j], j = 0..H-1, as packed FMAs; w = 64 contiguous floats at a wave-uniform address (scalar loads)
 __device__ inline void axpy64(float2v (&acc)[H / 2], float x, const float* __restrict__ w) {
     const float2v xx = {x, x};
 #pragma unroll
@@ -80,17 +80,15 @@ struct ActorArgs {
 };
 
 template <int DT>   // DT = compile-time obs length (5, 8, 11, 14) or 0 = runtime D (obs row re-read from memory)
-__global__ __launch_bounds__(TPB) void bsx_actor_kernel(const ActorArgs p) {
+__global__ __launch_bounds__(TPB) void bsx_actor_kernel(const float* __restrict__ weights, const ActorArgs p) {
     const int D = DT > 0 ? DT : p.D;
     const int a = blockIdx.y;
     const int64_t e = int64_t(blockIdx.x) * TPB + threadIdx.x;
     const int P = blob_floats(D);
-    extern __shared__ __attribute__((aligned(16))) float sw[];
-    {   // stage this agent's weights: P floats, P % 4 == 0
-        const float4* src = reinterpret_cast<const float4*>(p.weights + size_t(a) * P);
-        float4* dst = reinterpret_cast<float4*>(sw);
-        for (int i = threadIdx.x; i < P / 4; i += TPB) dst[i] = src[i];
-    }
+    // This workgroup's weights are wave-uniform addresses of read-only memory: the compiler fetches them with scalar
+    // loads (s_load_dwordx8/x16 through the scalar cache) and feeds them to the packed FMAs as SGPR operands -- no LDS
+    // traffic and no per-lane weight registers.
+    const float* __restrict__ sw = weights + size_t(a) * P;
     const int64_t ec = e < p.E ? e : p.E - 1;
     const size_t row = size_t(ec) * p.A + a;
     float x[DT > 0 ? DT : 1];
@@ -98,7 +96,6 @@ __global__ __launch_bounds__(TPB) void bsx_actor_kernel(const ActorArgs p) {
 #pragma unroll
         for (int k = 0; k < DT; ++k) x[k] = p.obs[row * DT + k];
     }
-    __syncthreads();
     const float* W1 = sw;                 const float* b1 = W1 + D * H;   const float* g1 = b1 + H; const float* be1 = g1 + H;
     const float* W2 = be1 + H;            const float* b2 = W2 + H * H;   const float* g2 = b2 + H; const float* be2 = g2 + H;
     const float* W3 = be2 + H;            const float* b3 = W3 + H * NA;
@@ -180,14 +177,13 @@ int bsx_actor_forward(const float* weights, const float* obs, float* scores, int
     const int A = 2 * n, D = 3 * n + 2;
     ActorArgs a{weights, obs, scores, E, A, D, noise_std, seed, seq, seq_base};
     const dim3 grid(unsigned((E + TPB - 1) / TPB), unsigned(A)), block(TPB);
-    const size_t lds = size_t(blob_floats(D)) * sizeof(float);
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (n) {
-        case 1: hipLaunchKernelGGL(bsx_actor_kernel<5>, grid, block, lds, s, a); break;
-        case 2: hipLaunchKernelGGL(bsx_actor_kernel<8>, grid, block, lds, s, a); break;
-        case 3: hipLaunchKernelGGL(bsx_actor_kernel<11>, grid, block, lds, s, a); break;
-        case 4: hipLaunchKernelGGL(bsx_actor_kernel<14>, grid, block, lds, s, a); break;
-        default: hipLaunchKernelGGL(bsx_actor_kernel<0>, grid, block, lds, s, a); break;
+        case 1: hipLaunchKernelGGL(bsx_actor_kernel<5>, grid, block, 0, s, weights, a); break;
+        case 2: hipLaunchKernelGGL(bsx_actor_kernel<8>, grid, block, 0, s, weights, a); break;
+        case 3: hipLaunchKernelGGL(bsx_actor_kernel<11>, grid, block, 0, s, weights, a); break;
+        case 4: hipLaunchKernelGGL(bsx_actor_kernel<14>, grid, block, 0, s, weights, a); break;
+        default: hipLaunchKernelGGL(bsx_actor_kernel<0>, grid, block, 0, s, weights, a); break;
     }
     return int(hipGetLastError());
 }

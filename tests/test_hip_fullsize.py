@@ -195,7 +195,8 @@ def test_score_vector_actions_vs_c_oracle():
     _compare_generic(8192, 2, 150, seed=77, logits=True)
 
 
-def test_policy_rollout_graph_equals_eager_loop():
+@pytest.mark.parametrize("fused", [False, True])
+def test_policy_rollout_graph_equals_eager_loop(fused):
     """configs[4] plumbing: actor -> score vectors -> step() captured in one HIP graph plays the same games as the
     tick-by-tick loop, and the transition buffers are consistent (obs[t+1] of tick t is obs[t] of tick t+1's input)."""
     from deep_rl_battlespace_amd.rollout import PolicyRollout, StackedActor
@@ -206,16 +207,18 @@ def test_policy_rollout_graph_equals_eager_loop():
         actor.w3.mul_(200.0)                                    # decisive scores (default init is +-0.003)
     a = _env(n_agents=n, n_envs=E, seed=21, auto_reset=True); a.reset()
     b = _env(n_agents=n, n_envs=E, seed=21, auto_reset=True); b.reset()
-    ro = PolicyRollout(b, actor, T)
+    ro = PolicyRollout(b, actor, T, fused=fused)
     ro.start(); ro.capture()
     obs = a._obs.clone()
+    from deep_rl_battlespace_amd.rollout import FusedActor
+    fa = FusedActor(actor, n)
     for rep in range(3):
         ro.run()
         torch.cuda.synchronize()
         assert torch.equal(ro.obs[0], obs)
         for t in range(T):
             with torch.no_grad():
-                s = actor(obs)
+                s = fa(obs) if fused else actor(obs)
             o, r, d = a.step_batch(s.contiguous())
             assert torch.equal(ro.scores[t], s) and torch.equal(ro.obs[t + 1], o) and torch.equal(ro.rew[t], r) and torch.equal(ro.done[t], d), (rep, t)
             obs = o.clone()
