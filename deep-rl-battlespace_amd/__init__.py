@@ -7,9 +7,11 @@ Only what the hot path needs lives here:
   envs/battle_env.py   `parallel_env`: the reference's PettingZoo ParallelEnv surface, batched over n_envs
   spaces.py      Box / Discrete metadata containers (gym is not a dependency)
   sharding.py    one contiguous env range per rank (no collective on the step path)
+  instinct/      the reference's scripted opponent, evaluated on device (next row f-2)
+  rollout.py     on-device actor + step loop in one HIP graph (next row f-1); csrc/bsx_actor.hip is its fused actor
 There is no CPU fallback: without the HIP library the env cannot be constructed.
 """
-from . import envs  # noqa: F401
+from . import envs, instinct  # noqa: F401
 from .envs.battle_env import parallel_env  # noqa: F401
 
-__all__ = ["envs", "parallel_env"]
+__all__ = ["envs", "instinct", "parallel_env"]

@@ -753,6 +753,58 @@ __global__ __launch_bounds__(TPB) void bsx_export_kernel(const ExportArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- scripted opponent
+// instinct/agent.py:10-62: decode the observation row, score every target by dist * |angle| (base wins ties, a dead
+// enemy scores 1e6), then shoot / turn toward the chosen target.  binary64 on the float32 values, as the reference
+// computes under its pinned numpy.
+struct InstinctArgs {
+    const float* obs; void* actions; const double* rnd; int64_t E; int n; int team; int out_kind; int continuous;
+    uint64_t seed; uint64_t seq; const uint64_t* seq_base;
+};
+
+__global__ __launch_bounds__(TPB) void bsx_instinct_kernel(const InstinctArgs p) {
+    const int A = 2 * p.n, D = 3 * p.n + 2;
+    const size_t g = size_t(blockIdx.x) * TPB + threadIdx.x;
+    if (g >= size_t(p.E) * A) return;
+    const int a = int(g % A);
+    const int tm = a < p.n ? 0 : 1;
+    if (p.team != 2 && p.team != tm) return;
+    const float* o = p.obs + g * D;
+    double td = (double(o[0]) + 1.0) / 2.0 * FIELD_DIAG;          // agent.py:15-16
+    double ta = double(o[1]) * 360.0;
+    double best = td * fabs(ta);
+    for (int j = 0; j < p.n; ++j) {                               // agent.py:20-39: strict '<' keeps the first minimum
+        const double d = (double(o[3 + 3 * j]) + 1.0) / 2.0 * FIELD_DIAG, an = double(o[4 + 3 * j]) * 360.0;
+        const double sc = (o[2 + 3 * j] == 1.0f) ? d * fabs(an) : 1000000.0;
+        if (sc < best) { best = sc; td = d; ta = an; }
+    }
+    if (!p.continuous) {                                          // agent.py:56-62
+        const int act = (td < 250.0 && fabs(ta) < 20.0) ? 1 : (ta > 0.0 ? 3 : 2);
+        if (p.out_kind == BSX_ACT_I32) static_cast<int32_t*>(p.actions)[g] = act;
+        else static_cast<float4*>(p.actions)[g] = make_float4(act == 0 ? 1.f : -1.f, act == 1 ? 1.f : -1.f, act == 2 ? 1.f : -1.f, act == 3 ? 1.f : -1.f);
+        return;
+    }
+    double r0, n0, n1, n2;                                        // agent.py:41-54
+    if (p.rnd) { r0 = p.rnd[4 * g]; n0 = p.rnd[4 * g + 1]; n1 = p.rnd[4 * g + 2]; n2 = p.rnd[4 * g + 3]; }
+    else {
+        const uint64_t seq = p.seq + (p.seq_base ? *p.seq_base : 0ull);
+        const uint4 r = philox4x32_10(make_uint4(uint32_t(g), uint32_t(uint64_t(g) >> 32) ^ 0x10000000u, uint32_t(seq), uint32_t(seq >> 32)),
+                                      make_uint2(uint32_t(p.seed), uint32_t(p.seed >> 32)));
+        r0 = double(r.x) * (1.0 / 4294967296.0);
+        n0 = -0.15 + 0.3 * (double(r.y) * (1.0 / 4294967296.0));
+        n1 = -0.15 + 0.3 * (double(r.z) * (1.0 / 4294967296.0));
+        n2 = -0.15 + 0.3 * (double(r.w) * (1.0 / 4294967296.0));
+    }
+    double a2 = 0.0;
+    if (td < 500.0 / 3.0 * 2.0 && fabs(ta) < 20.0) a2 = r0 < 0.6 ? 1.0 : -1.0;
+    const double a0 = td / FIELD_DIAG * 2.0 - 1.0;
+    const double a1 = ta > 0.0 ? fmax(-ta / 35.0, -1.0) : fmin(-ta / 35.0, 1.0);
+    double* out = static_cast<double*>(p.actions) + 3 * g;
+    out[0] = fmin(fmax(a0 + n0, -1.0), 1.0);
+    out[1] = fmin(fmax(a1 + n1, -1.0), 1.0);
+    out[2] = fmin(fmax(a2 + n2, -1.0), 1.0);
+}
+
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 inline int grid_for(int64_t E, int n, int tpb = TPB) {
     const int epb = tpb / group_width(n);
@@ -873,6 +925,26 @@ int bsx_export_state(const void* state, int64_t E, int n, const BsxExport* out, 
     const size_t EA = size_t(E) * 2 * n;
     hipLaunchKernelGGL(bsx_export_kernel, dim3(unsigned((EA + TPB - 1) / TPB)), dim3(TPB), 0,
                        static_cast<hipStream_t>(stream), a);
+    return int(hipGetLastError());
+}
+
+int bsx_instinct_discrete(const float* obs, void* actions, int out_kind, int64_t E, int n, int team, void* stream) {
+    if (!obs || !actions || E <= 0 || n < 1 || n > BSX_MAX_N || team < 0 || team > 2) return BSX_E_ARG;
+    if (out_kind != BSX_ACT_I32 && out_kind != BSX_ACT_LOGITS_F32) return BSX_E_ARG;
+    if (!aligned(obs, 4) || !aligned(actions, out_kind == BSX_ACT_I32 ? 4 : 16)) return BSX_E_ALIGN;
+    InstinctArgs a{obs, actions, nullptr, E, n, team, out_kind, 0, 0, 0, nullptr};
+    const size_t EA = size_t(E) * 2 * n;
+    hipLaunchKernelGGL(bsx_instinct_kernel, dim3(unsigned((EA + TPB - 1) / TPB)), dim3(TPB), 0, static_cast<hipStream_t>(stream), a);
+    return int(hipGetLastError());
+}
+
+int bsx_instinct_continuous(const float* obs, double* actions, const double* rnd, int64_t E, int n, int team,
+                            uint64_t seed, uint64_t seq, const uint64_t* seq_base, void* stream) {
+    if (!obs || !actions || E <= 0 || n < 1 || n > BSX_MAX_N || team < 0 || team > 2) return BSX_E_ARG;
+    if (!aligned(obs, 4) || !aligned(actions, 8) || (rnd && !aligned(rnd, 8))) return BSX_E_ALIGN;
+    InstinctArgs a{obs, actions, rnd, E, n, team, 0, 1, seed, seq, seq_base};
+    const size_t EA = size_t(E) * 2 * n;
+    hipLaunchKernelGGL(bsx_instinct_kernel, dim3(unsigned((EA + TPB - 1) / TPB)), dim3(TPB), 0, static_cast<hipStream_t>(stream), a);
     return int(hipGetLastError());
 }
 

@@ -125,6 +125,17 @@ int bsx_actor_blob_floats(int obs_len, int* floats_per_agent);
 int bsx_actor_forward(const float* weights, const float* obs, float* scores, int64_t E, int n, float noise_std,
                       uint64_t seed, uint64_t seq, const uint64_t* seq_base, void* stream);
 
+/* ---- the reference's scripted opponent on device (instinct/agent.py:10-62, instinct/team.py:3-15): a pure function of
+ * the observation rows.  Writes ONLY the rows of `team` (0 red, 1 blue, 2 both) so a learned policy can fill the others
+ * in the same tensor.  binary64 arithmetic on the float32 observation values, as the reference computes.
+ *   discrete:   actions int32[E*A] (BSX_ACT_I32) or one-hot +-1 float32[E*A*4] (BSX_ACT_LOGITS_F32, 16-byte aligned)
+ *   continuous: actions float64[E*A*3] (speed, turn, shoot; noise added and clipped as agent.py:51-52);
+ *               rnd nullable float64[E*A*4] = the np.random.rand() value and the three uniform(-0.15, 0.15) values to
+ *               use (parity runs); null = Philox keyed by (seed, seq + *seq_base, row). */
+int bsx_instinct_discrete(const float* obs, void* actions, int out_kind, int64_t E, int n, int team, void* stream);
+int bsx_instinct_continuous(const float* obs, double* actions, const double* rnd, int64_t E, int n, int team,
+                            uint64_t seed, uint64_t seq, const uint64_t* seq_base, void* stream);
+
 /* Host helper: the call number on which the time-limit tie fires for n-per-team -- the reference accumulates
  * total_time += 0.1 in binary64 and compares >= 10+2n (battle_env.py:168,316-319): 121, 141, 161, 181, 200 ... */
 int bsx_tie_tick(int n);

@@ -317,7 +317,11 @@ def main():
     tap = RngTap()
     tap.install()
     try:
-        generate(be, instinct_mod, tap)
+        if "--instinct-only" in sys.argv:
+            instinct_fixture(be, instinct_mod, tap)
+        else:
+            generate(be, instinct_mod, tap)
+            instinct_fixture(be, instinct_mod, tap)
     finally:
         tap.uninstall()
 
@@ -530,6 +534,62 @@ def scripted(be, tap):
     rec.save("g5_scripted_2v2", dict(driver="hand-scripted 2v2 edge cases"))
 
 
+def instinct_fixture(be, instinct_mod, tap):
+    """G8: (observation row -> action) pairs of the reference's scripted opponent (instinct/agent.py:10-62).
+    The agent is called with a float64 COPY of each float32 observation: with the reference's pinned numpy 1.23.1 a
+    float32 scalar is promoted to float64 by its first operation with a Python number, so float64 arithmetic on the
+    float32 values is what the reference computes (numpy 2.x here would otherwise stay in float32).  The continuous
+    branch draws from numpy's global generator; np.random.rand / np.random.uniform are wrapped to record the draws."""
+    real_rand, real_uniform = np.random.rand, np.random.uniform
+    draws = {"rand": [], "noise": []}
+
+    def rand_tap():
+        v = real_rand(); draws["rand"].append(v); return v
+
+    def uniform_tap(lo, hi, size=None):
+        v = real_uniform(lo, hi, size=size); draws["noise"].append(np.asarray(v, np.float64).copy()); return v
+    out = {}
+    for cont in (False, True):
+        for n in (1, 2, 4):
+            random.seed(800 + n + 10 * cont); np.random.seed(800 + n + 10 * cont)
+            env = be.parallel_env(n_agents=n, continuous_actions=cont)
+            red = instinct_mod.Team(env.possible_red, env.possible_blue, env)
+            blue = instinct_mod.Team(env.possible_blue, env.possible_red, env)
+            rows = []
+            np.random.rand, np.random.uniform = rand_tap, uniform_tap
+            try:
+                for ep in range(6 if n < 4 else 3):
+                    obs = env.reset()
+                    while not env.env_done:
+                        acts = {}
+                        for team in (red, blue):
+                            for aid, agent in team.agents.items():
+                                o32 = obs[aid]
+                                draws["rand"].clear(); draws["noise"].clear()
+                                a = agent.choose_action(np.asarray(o32, np.float64))
+                                acts[aid] = a
+                                if cont:
+                                    rows.append((o32.copy(), env.possible_agents.index(aid), np.asarray(a, np.float64),
+                                                 draws["rand"][0] if draws["rand"] else np.nan, draws["noise"][0].copy()))
+                                else:
+                                    rows.append((o32.copy(), env.possible_agents.index(aid), int(a)))
+                        obs, _, _, _ = env.step(acts)
+                    # a few post-mortem rows: dead observers see all -1
+            finally:
+                np.random.rand, np.random.uniform = real_rand, real_uniform
+            tag = f"{'cont' if cont else 'disc'}_{n}v{n}"
+            out[f"{tag}/obs"] = np.stack([r[0] for r in rows]).astype(np.float32)
+            out[f"{tag}/agent"] = np.asarray([r[1] for r in rows], np.int32)
+            if cont:
+                out[f"{tag}/action"] = np.stack([r[2] for r in rows]).astype(np.float64)
+                out[f"{tag}/rand"] = np.asarray([r[3] for r in rows], np.float64)
+                out[f"{tag}/noise"] = np.stack([r[4] for r in rows]).astype(np.float64)
+            else:
+                out[f"{tag}/action"] = np.asarray([r[2] for r in rows], np.int32)
+            print(f"g8 {tag}: {len(rows)} rows", np.bincount(out[f"{tag}/action"]) if not cont else "")
+    np.savez_compressed(os.path.join(HERE, "g8_instinct_pairs.npz"), **out)
+
+
 def actor_fixture():
     """G9: the reference ActorNetwork (maddpg/networks.py:54-85), seeded random init, on random observation rows:
     weights + inputs + outputs, to pin the stacked on-device actor's forward pass.  (torch only; no stand-ins.)"""
@@ -564,4 +624,5 @@ if __name__ == "__main__":
         main()
     finally:
         os.chdir(cwd)
-    actor_fixture()
+    if "--instinct-only" not in sys.argv:
+        actor_fixture()

@@ -95,3 +95,15 @@ def test_spaces_and_ids():
     assert env.action_space("plane3").n == 4 and env.n_actions == 4
     c = ref.RefEnv(n_agents=1, continuous_actions=True)
     assert c.n_actions == 3 and c.action_space("plane0").shape == (3,) and c.max_turn == 35
+
+
+def test_instinct_oracle_reproduces_reference_agent():
+    from oracle import instinct_ref as ir
+    z = np.load(f"{GOLDEN}/g8_instinct_pairs.npz")
+    for n in (1, 2, 4):
+        obs, act = z[f"disc_{n}v{n}/obs"], z[f"disc_{n}v{n}/action"]
+        assert [ir.discrete_action(o, n) for o in obs] == act.tolist()
+        obs, act = z[f"cont_{n}v{n}/obs"], z[f"cont_{n}v{n}/action"]
+        rnd, noise = z[f"cont_{n}v{n}/rand"], z[f"cont_{n}v{n}/noise"]
+        got = np.stack([ir.continuous_action(o, n, r, nz) for o, r, nz in zip(obs, rnd, noise)])
+        assert np.array_equal(got, act)
