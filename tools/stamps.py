@@ -12,14 +12,15 @@ try:
     from deep_rl_battlespace_amd import _lib
     E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    env = bsx.parallel_env(n_agents=n, n_envs=E, auto_reset=True, seed=1)
+    cont = len(sys.argv) > 3 and sys.argv[3] == 'cont'
+    env = bsx.parallel_env(n_agents=n, n_envs=E, auto_reset=True, seed=1, continuous_actions=cont)
     env.reset()
     L = _lib.load()
     G = 2 if n == 1 else (4 if n == 2 else 8)
     waves = (E * G + 63) // 64
     buf = torch.zeros(waves * 8, dtype=torch.int64, device="cuda")
     L.bsx_debug_set_stamps.argtypes = [ctypes.c_void_p]
-    acts = torch.randint(0, 4, (64, E, 2 * n), dtype=torch.int32, device="cuda")
+    acts = (torch.rand((64, E, 2 * n, 3), device='cuda') * 2 - 1) if cont else torch.randint(0, 4, (64, E, 2 * n), dtype=torch.int32, device="cuda")
     for t in range(60):
         env.step_batch(acts[t])
     torch.cuda.synchronize()
