@@ -49,7 +49,7 @@ __device__ unsigned long long* g_stamps = nullptr;
         __builtin_amdgcn_sched_barrier(0);                                                         \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        if (g_stamps && (threadIdx.x & 63) == 0) g_stamps[size_t(blockIdx.x) * 8 + (i)] = t_; \
+        if (g_stamps && (threadIdx.x & 63) == 0) g_stamps[size_t(blockIdx.x) * 10 + (i)] = t_; \
     } while (0)
 #else
 #define STAMP(i) do { } while (0)
@@ -274,6 +274,7 @@ __device__ inline void obs_pair(int x, int y, double dir, int tx, int ty, float&
 
 template <int N, bool CONT>
 __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
+    STAMP(8);                                            // diagnostic builds: kernel entry, before any kernarg load
     const int n = (N > 0) ? N : p.n;
     const int A = 2 * n;
     const int G = group_width(n);
