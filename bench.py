@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--mode", choices=("graph", "eager"), default="graph")
     ap.add_argument("--graph-len", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the two extra (non-headline) measurements")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="process-group backend for the barrier / timing reduction (nccl = RCCL; gloo only to rehearse N>1 on a 1-GPU box)")
     ap.add_argument("--rehearse-on-device0", action="store_true", help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
@@ -107,52 +108,70 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    n, E = args.n_agents, args.envs_per_gpu
-    A = 2 * n
-    env = sharding.make_shard(E * world, rank, world, n_agents=n, device=dev, seed=1234, auto_reset=True)
-    env.reset()
-    K, W = args.steps, args.warmup
-    G = max(1, min(args.graph_len, K))
-    while K % G:
-        G -= 1
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    actions = torch.randint(0, 4, (G, E, A), generator=gen, device=dev, dtype=torch.int32)
-
-    if args.mode == "graph":
-        graph, _ = env.capture_steps(actions)
-
-        def run(steps):
-            for _ in range(steps // G):
-                graph.replay()
-            for t in range(steps % G):
-                env.step_batch(actions[t])
-    else:
-        def run(steps):
-            for t in range(steps):
-                env.step_batch(actions[t % G])
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    run(W)
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    run(K)
-    ev1.record()
-    barrier()
-    dt = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / K                  # average launch-to-launch duration on the launch stream
-    if world > 1:
-        t = torch.tensor([dt, kernel_ms], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, kernel_ms = float(t[0]), float(t[1])
+    def measure(n, E, K, W, mode, graph_len):
+        """K timed step() calls of E games x n-v-n on this rank; returns (env, seconds, kernel ms per launch, graph len)."""
+        A = 2 * n
+        env = sharding.make_shard(E * world, rank, world, n_agents=n, device=dev, seed=1234, auto_reset=True)
+        env.reset()
+        G = max(1, min(graph_len, K))
+        while K % G:
+            G -= 1
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1234 + rank)
+        actions = torch.randint(0, 4, (G, E, A), generator=gen, device=dev, dtype=torch.int32)
+        if mode == "graph":
+            graph, _ = env.capture_steps(actions)
+
+            def run(steps):
+                for _ in range(steps // G):
+                    graph.replay()
+                for t in range(steps % G):
+                    env.step_batch(actions[t])
+        else:
+            def run(steps):
+                for t in range(steps):
+                    env.step_batch(actions[t % G])
+        run(W)
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        run(K)
+        ev1.record()
+        barrier()
+        dt = time.perf_counter() - t0
+        kernel_ms = ev0.elapsed_time(ev1) / K              # average launch-to-launch duration on the launch stream
+        if world > 1:
+            t = torch.tensor([dt, kernel_ms], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt, kernel_ms = float(t[0]), float(t[1])
+        return env, dt, kernel_ms, G
+
+    n, E = args.n_agents, args.envs_per_gpu
+    A = 2 * n
+    K, W = args.steps, args.warmup
+    env, dt, kernel_ms, G = measure(n, E, K, W, args.mode, args.graph_len)
 
     games = sharding.reduce_counters(sharding.local_counter_sums(env).to(red_dev))   # logging only, after the timed region
+
+    # not the headline: the same kernel on BASELINE.json configs[2] and in the streaming regime (working set > Infinity
+    # Cache), a few hundred steps each, so one run shows how the roofline fraction moves with the batch
+    others = {}
+    if world == 1 and not args.no_other_workloads and (n, E) == (1, 65536):
+        for tag, (n2, E2, K2) in {"configs[2] 65536 x 4v4": (4, 65536, 400), "1048576 x 1v1 (streaming)": (1, 1048576, 200)}.items():
+            del env
+            torch.cuda.empty_cache()
+            env, dt2, km2, _ = measure(n2, E2, K2, 50, args.mode, 100)
+            ach = b_alg(n2) * E2 * 2 * n2 / (km2 * 1e-3) / 1e9
+            others[tag] = {"agent_steps_per_s": round(E2 * 2 * n2 * K2 / dt2, 1), "avg_launch_us": round(km2 * 1e3, 2),
+                           "roofline_frac": round(ach / HBM_PEAK_GBS, 4)}
+        del env
+        torch.cuda.empty_cache()
     if rank == 0:
         agent_steps = E * world * A * K
         bytes_per_launch = b_alg(n) * E * A
@@ -183,6 +202,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        out["other_workloads"] = others
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -4,8 +4,8 @@ set -e
 cd $GRAFT_REPO_ROOT
 T=${1:-x}
 mkdir -p gpurun_out
-timeout -k 10 120 python bench.py --steps 2000 --warmup 200 --no-cpu-baseline > gpurun_out/${T}_C2.json
-timeout -k 10 120 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --n-agents 4 > gpurun_out/${T}_C3.json
-timeout -k 10 120 python bench.py --steps 400 --warmup 50 --no-cpu-baseline --envs-per-gpu 1048576 > gpurun_out/${T}_1M.json
-timeout -k 10 120 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --envs-per-gpu 16384 > gpurun_out/${T}_16k.json
+timeout -k 10 120 python bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-other-workloads > gpurun_out/${T}_C2.json
+timeout -k 10 120 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-other-workloads --n-agents 4 > gpurun_out/${T}_C3.json
+timeout -k 10 120 python bench.py --steps 400 --warmup 50 --no-cpu-baseline --no-other-workloads --envs-per-gpu 1048576 > gpurun_out/${T}_1M.json
+timeout -k 10 120 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-other-workloads --envs-per-gpu 16384 > gpurun_out/${T}_16k.json
 for f in gpurun_out/${T}_*.json; do python -c "import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[1], round(d['value']/1e9,3), 'G/s', d['roofline']['avg_launch_us'], 'us frac', d['roofline']['frac'])" $f; done

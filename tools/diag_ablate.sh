@@ -8,13 +8,13 @@ FLAGS="-O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 -I i
 cp $SRC/libbattlespace_hip.so /tmp/product.so
 for d in 1 2 4 7; do
   hipcc $FLAGS -DBSX_DIAG=$d $SRC/bsx_kernels.hip -o $SRC/libbattlespace_hip.so
-  timeout -k 10 120 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline > gpurun_out/diag/diag$d.json
+  timeout -k 10 120 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-other-workloads > gpurun_out/diag/diag$d.json
 done
 cp /tmp/product.so $SRC/libbattlespace_hip.so
-timeout -k 10 120 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline > gpurun_out/diag/diag0.json
-timeout -k 10 120 python bench.py --steps 400 --warmup 50 --no-cpu-baseline --envs-per-gpu 1048576 > gpurun_out/diag/big1M.json
-timeout -k 10 120 python bench.py --steps 400 --warmup 50 --no-cpu-baseline --envs-per-gpu 262144 > gpurun_out/diag/big256k.json
-timeout -k 10 120 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --envs-per-gpu 16384 > gpurun_out/diag/small16k.json
+timeout -k 10 120 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-other-workloads > gpurun_out/diag/diag0.json
+timeout -k 10 120 python bench.py --steps 400 --warmup 50 --no-cpu-baseline --no-other-workloads --envs-per-gpu 1048576 > gpurun_out/diag/big1M.json
+timeout -k 10 120 python bench.py --steps 400 --warmup 50 --no-cpu-baseline --no-other-workloads --envs-per-gpu 262144 > gpurun_out/diag/big256k.json
+timeout -k 10 120 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-other-workloads --envs-per-gpu 16384 > gpurun_out/diag/small16k.json
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 P="python bench.py --steps 200 --warmup 20 --no-cpu-baseline --mode eager"
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d gpurun_out/diag/pmcA -- $P > /dev/null 2> gpurun_out/diag/pmcA.err
