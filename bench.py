@@ -68,7 +68,24 @@ def cpu_baseline(seconds_target=12.0):
         dt = time.perf_counter() - t0
         if dt >= seconds_target:
             break
-    return {"value": round(calls * 2 / dt, 1), "unit": "agent-steps/s", "cores": 1, "kind": "port",
+    extra = {}
+    try:    # context only: the C restatement of the same path (oracle/battlespace_ref.c, OpenMP over games), all host cores
+        from oracle import cref
+        Ec, Tc = 16384, 60
+        c = cref.CRefBatch(Ec, n_agents=1, seed=1234, auto_reset=True)
+        c.reset()
+        a = np.random.default_rng(1).integers(0, 4, size=(Tc, Ec, 2)).astype(np.int32)
+        for t in range(5):
+            c.step(a[t])
+        t1 = time.perf_counter()
+        for t in range(Tc):
+            c.step(a[t])
+        dtc = time.perf_counter() - t1
+        extra = {"c_port_all_cores": {"value": round(Ec * 2 * Tc / dtc, 1), "unit": "agent-steps/s", "cores": os.cpu_count(),
+                                      "sample": f"{Tc} steps of {Ec} games x 1v1, oracle/battlespace_ref.c, OpenMP"}}
+    except Exception as exc:      # the C oracle is optional context; the Python port above is the reported baseline
+        extra = {"c_port_all_cores": {"error": str(exc)[:120]}}
+    return {**extra, "value": round(calls * 2 / dt, 1), "unit": "agent-steps/s", "cores": 1, "kind": "port",
             "sample": f"{calls} step() calls of 1 game x 1v1 (configs[0]), uniform random actions seed 1234, "
                       f"reset on done, {dt:.1f} s on 1 of {os.cpu_count()} host cores ({platform.processor() or platform.machine()}, "
                       f"CPython {platform.python_version()}); oracle/battlespace_ref.py"}
