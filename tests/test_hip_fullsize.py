@@ -272,3 +272,32 @@ def test_fused_actor_noise_is_gaussian_clamped_and_rekeyed():
     sb = torch.tensor([1], dtype=torch.int64, device="cuda")
     d = torch.empty_like(a); fused.forward_into(obs, d, 0.25, seq=6, seq_base=sb)
     assert torch.equal(d, a)                                     # seq + *seq_base
+
+
+def test_rollout_into_replay_buffer_on_device():
+    """f-1 -> f-3: a rollout's transitions go into the device replay ring without touching the host; a sampled batch is
+    self-consistent (next-state of a stored row is the state the env produced one tick later)."""
+    from deep_rl_battlespace_amd.replay import ReplayBuffer
+    from deep_rl_battlespace_amd.rollout import PolicyRollout, StackedActor
+    E, n, T = 512, 2, 16
+    env = _env(n_agents=n, n_envs=E, seed=5, auto_reset=True); env.reset()
+    actor = StackedActor(2 * n, 3 * n + 2, 4, device="cuda")
+    with torch.no_grad():
+        actor.w3.mul_(100.0)
+    ro = PolicyRollout(env, actor, T, noise_std=0.2); ro.start(); ro.capture()
+    buf = ReplayBuffer(20000, 256, env.possible_red, env.obs_size, env.obs_size * n, 4, device="cuda")
+    for rep in range(3):
+        ro.run()
+        buf.store_rollout(ro, range(n))
+    torch.cuda.synchronize()
+    assert buf.mem_cntr == 3 * T * E and buf.is_ready()
+    # rows of the LAST rollout sit at the ring positions mem_cntr - T*E ... (tick-major): check a few against the buffers
+    base = (buf.mem_cntr - T * E) % buf.mem_size
+    for t, e in ((0, 0), (3, 17), (T - 1, E - 1)):
+        row = (base + t * E + e) % buf.mem_size
+        assert torch.equal(buf.actor_states[row], ro.obs[t, e, :n]) and torch.equal(buf.actor_new_states[row], ro.obs[t + 1, e, :n])
+        assert torch.equal(buf.action_mem[row], ro.scores[t, e, :n]) and torch.equal(buf.rew_mem[row], ro.rew[t, e, :n])
+        assert torch.equal(buf.done_mem[row], ro.done[t, e, :n])
+    a_s, s, a, r, a_s2, s2, d = buf.sample()
+    assert s.shape == (256, n * env.obs_size) and a.shape == (n, 256, 4) and d.dtype == torch.bool
+    assert float(a.abs().max()) <= 1.0
