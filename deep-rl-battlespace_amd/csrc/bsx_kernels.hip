@@ -343,18 +343,24 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     unpack_plane(prw, x, y, live, hp, dir);
     EnvU er = unpack_env(erw);
     const uint32_t live0 = live;
-    // dead slots / empty chunks read the heading table's first entry instead (one shared cache line, no DRAM traffic)
-    uint4 c[3];
+    // Bullets are sparse (uniform random play: 0.6 live per agent out of 12 slots), so a lane does not walk its 12 slots:
+    // it takes its FIRST FOUR live slots as statically indexed "items" (slot, packed xy word, per-update step), all
+    // eight loads issued here in one batch; lanes with more than four live bullets are finished by a wave-uniform loop
+    // further down.  A missing item reads the heading table's first entry (one shared cache line, no DRAM traffic).
+    constexpr int NI = 4;
+    const uint32_t* bxy_w = reinterpret_cast<const uint32_t*>(p.st.bxy);
+    uint32_t rem = (DIAG & 2u) ? 0u : live0;
+    int ik[NI]; uint32_t iw[NI]; double2 idd[NI];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const uint4* src = ((live0 >> (4 * q)) & 0xFu) ? &p.st.bxy[size_t(q) * EA + g] : reinterpret_cast<const uint4*>(p.st.lut);
-        c[q] = *src;
-    }
-    double2 d[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const double2* src = ((live0 >> k) & 1u) ? &p.st.bd[size_t(k) * EA + g] : p.st.lut;
-        d[k] = (DIAG & 2u) ? make_double2(0.0, 0.0) : *src;
+    for (int j = 0; j < NI; ++j) {
+        const bool has = rem != 0u;
+        const int k = has ? __builtin_ctz(rem) : 0;
+        rem &= rem - 1u;
+        ik[j] = has ? k : -1;
+        const uint32_t* wsrc = has ? bxy_w + (size_t(k >> 2) * EA + g) * 4 + (k & 3) : reinterpret_cast<const uint32_t*>(p.st.lut);
+        const double2* dsrc = has ? &p.st.bd[size_t(k) * EA + g] : p.st.lut;
+        iw[j] = *wsrc;
+        idd[j] = *dsrc;
     }
     if (!CONT) {
 #pragma unroll
@@ -449,7 +455,6 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
         nd = make_double2(BULLET_STEP * cs, BULLET_STEP * sn);
         p.st.bd[size_t(ks) * EA + g] = nd;
         p.st.bdir[size_t(ks) * EA + g] = bdir;
-        live |= 1u << ks;
     }
 
     STAMP(3);
@@ -470,70 +475,83 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     }
 
     STAMP(4);
-    // ---- Bullet.update for all 12 slots (sprites.py:321-351), branch-free, predicates as integer sign masks (0 / -1):
-    //      dead slots compute on harmless values and are masked out.
+    // ---- Bullet.update (sprites.py:321-351) per live bullet ("item"), branch-free, predicates as integer sign masks (0 / -1)
     constexpr int FW = (N > 0 && N <= 4) ? 4 : 16;       // bits per overlap field
     constexpr int OW = (FW == 4) ? 1 : 3;                // 64-bit words holding the 12 slot-indexed fields
     uint64_t ovl[OW];
 #pragma unroll
     for (int q = 0; q < OW; ++q) ovl[q] = 0;
     int nmiss = 0, nbase = 0, nplane = 0;
-    {
-        uint32_t* w = reinterpret_cast<uint32_t*>(c);
-        const int physm = phys ? -1 : 0;
-        const uint32_t live1 = live;
-        int eam[NE];
+    int eam[NE];
+    if (N > 0) {
+#pragma unroll
+        for (int j = 0; j < NE; ++j) eam[j] = (s_hp[eb + j] > 0) ? -1 : 0;
+    }
+    uint32_t* bxy_wr = reinterpret_cast<uint32_t*>(p.st.bxy);
+    // one bullet: position word `w0` (or the shooter's pre-move pose for this call's shot), step `dd`, slot k, live mask `lvm`
+    auto update_item = [&](int k, int bx0, int by0, double2 dd, int lvm) {
+        const int bx = int(double(bx0) + dd.x);                                     // truncation toward zero
+        const int by = int(double(by0) + dd.y);
+        // miss: dist_travelled >= 500 <=> 12th update (45*12 >= 500 > 45*11) <=> this is the oldest slot k0;
+        // else off the field (x>1200 | x<0 | y>800 | y<0)
+        const int missm = ((bx | (FIELD_W - bx) | by | (FIELD_H - by)) >> 31) | ((k == k0) ? -1 : 0);
+        // base: 6x3 bullet rect vs 62x62 base rect, strict overlap <=> dx in [-33,33] and dy in [-32,31]
+        const int dxb = bx - obx, dyb = by - oby;
+        const int basem = ~(((dxb + 33) | (33 - dxb) | (dyb + 32) | (31 - dyb)) >> 31) & ~missm;
+        // planes: vs the un-rotated 50x48 rect at the post-move pose <=> dx in [-27,27] and dy in [-25,24]
+        uint32_t m = 0;
         if (N > 0) {
 #pragma unroll
-            for (int j = 0; j < NE; ++j) eam[j] = (s_hp[eb + j] > 0) ? -1 : 0;
-        }
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const int lvm = (-int((live1 >> k) & 1u)) & physm;                      // -1: live bullet of a running game
-            const int newm = (spawn && k == ks) ? -1 : 0;
-            const int bx0 = newm ? x0 : sx16(w[k]), by0 = newm ? y0 : sy16(w[k]);
-            const double2 dd = newm ? nd : d[k];
-            const int bx = int(double(bx0) + dd.x);                                 // truncation toward zero
-            const int by = int(double(by0) + dd.y);
-            // miss: dist_travelled >= 500 <=> 12th update (45*12 >= 500 > 45*11) <=> this is the oldest slot k0;
-            // else off the field (x>1200 | x<0 | y>800 | y<0)
-            const int missm = ((bx | (FIELD_W - bx) | by | (FIELD_H - by)) >> 31) | ((k == k0) ? -1 : 0);
-            // base: 6x3 bullet rect vs 62x62 base rect, strict overlap <=> dx in [-33,33] and dy in [-32,31]
-            const int dxb = bx - obx, dyb = by - oby;
-            const int basem = ~(((dxb + 33) | (33 - dxb) | (dyb + 32) | (31 - dyb)) >> 31) & ~missm;
-            // planes: vs the un-rotated 50x48 rect at the post-move pose <=> dx in [-27,27] and dy in [-25,24]
-            uint32_t m = 0;
-            if (N > 0) {
-#pragma unroll
-                for (int j = 0; j < NE; ++j) {
-                    const int dxp = bx - ex[j], dyp = by - ey[j];
-                    const int pm = ~(((dxp + 27) | (27 - dxp) | (dyp + 25) | (24 - dyp)) >> 31) & eam[j];
-                    m |= uint32_t(pm) & (1u << j);
-                }
-            } else {
-                for (int j = 0; j < n; ++j) {
-                    const int dxp = bx - s_x[eb + j], dyp = by - s_y[eb + j];
-                    const int pm = ~(((dxp + 27) | (27 - dxp) | (dyp + 25) | (24 - dyp)) >> 31) & (s_hp[eb + j] > 0 ? -1 : 0);
-                    m |= uint32_t(pm) & (1u << j);
-                }
+            for (int j = 0; j < NE; ++j) {
+                const int dxp = bx - ex[j], dyp = by - ey[j];
+                const int pm = ~(((dxp + 27) | (27 - dxp) | (dyp + 25) | (24 - dyp)) >> 31) & eam[j];
+                m |= uint32_t(pm) & (1u << j);
             }
-            const int gonem = (missm | basem) & lvm;
-            const int keepm = lvm & ~gonem;
-            m &= uint32_t(keepm);
-            nmiss -= missm & lvm;
-            nbase -= basem & lvm;
-            ovl[(k * FW) / 64] |= uint64_t(m) << ((k * FW) % 64);
-            live &= ~(uint32_t(gonem) & (1u << k));
-            w[k] = (pack_xy(bx, by) & uint32_t(keepm)) | (w[k] & ~uint32_t(keepm));
+        } else {
+            for (int j = 0; j < n; ++j) {
+                const int dxp = bx - s_x[eb + j], dyp = by - s_y[eb + j];
+                const int pm = ~(((dxp + 27) | (27 - dxp) | (dyp + 25) | (24 - dyp)) >> 31) & (s_hp[eb + j] > 0 ? -1 : 0);
+                m |= uint32_t(pm) & (1u << j);
+            }
+        }
+        const int gonem = (missm | basem) & lvm;
+        const int keepm = lvm & ~gonem;
+        m &= uint32_t(keepm);
+        nmiss -= missm & lvm;
+        nbase -= basem & lvm;
+        const int kk = k & 15;
+        if (OW == 1) ovl[0] |= uint64_t(m) << (kk * FW);
+        else {
+            const uint64_t f = uint64_t(m) << ((kk & 3) * 16);
+            ovl[0] |= (kk >> 2) == 0 ? f : 0ull; ovl[OW > 1 ? 1 : 0] |= (kk >> 2) == 1 ? f : 0ull; ovl[OW > 2 ? 2 : 0] |= (kk >> 2) == 2 ? f : 0ull;
+        }
+        live = (live & ~(uint32_t(gonem) & (1u << kk))) | (uint32_t(keepm) & (1u << kk));
+        if (keepm) bxy_wr[(size_t(kk >> 2) * EA + g) * 4 + (kk & 3)] = pack_xy(bx, by);
+    };
+    {
+        const int physm = phys ? -1 : 0;
+        // this call's shot first (it is the newest bullet; per-bullet outcomes do not depend on the order, the ordered
+        // resolve below does and walks slots by age)
+        update_item(ks, x0, y0, nd, (spawn ? -1 : 0) & physm);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) update_item(ik[j], sx16(iw[j]), sy16(iw[j]), idd[j], (ik[j] >= 0 ? -1 : 0) & physm);
+        // lanes with more than NI live bullets: rare under sparse play, up to two more rounds when every slot is in use
+        while (__any(rem != 0u)) {
+            int rk[NI]; uint32_t rw[NI]; double2 rd[NI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const bool has = rem != 0u;
+                const int k = has ? __builtin_ctz(rem) : 0;
+                rem &= rem - 1u;
+                rk[j] = has ? k : -1;
+                rw[j] = *(has ? bxy_w + (size_t(k >> 2) * EA + g) * 4 + (k & 3) : reinterpret_cast<const uint32_t*>(p.st.lut));
+                rd[j] = *(has ? &p.st.bd[size_t(k) * EA + g] : p.st.lut);
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) update_item(rk[j], sx16(rw[j]), sy16(rw[j]), rd[j], (rk[j] >= 0 ? -1 : 0) & physm);
         }
         if (nbase) atomicAdd(const_cast<int*>(&s_bhit[gl + team]), nbase);
-        if (phys) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-                if ((live1 >> (4 * q)) & 0xFu) p.st.bxy[size_t(q) * EA + g] = c[q];
-        }
     }
-
     STAMP(5);
     // ---- ordered plane-hit resolve (battle_env.py:332-360 with sprites.py:348-350): creation order = oldest age
     //      first, then shooter id; a plane killed earlier in the walk no longer stops later bullets.
