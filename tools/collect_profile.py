@@ -21,6 +21,10 @@ for f in glob.glob(os.path.join(src, "bench_*.json")):
 ks = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
 if ks:
     shutil.copy(ks[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+G = 2
+while G < 2 * n:
+    G *= 2
+grid_threads = ((E + 64 // G - 1) // (64 // G)) * 64      # the step kernel's launch: one 64-lane workgroup per 64/G games
 summary = {}
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc"):
     cc = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
@@ -28,7 +32,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc"):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(cc[0])):
-        if "bsx_step_kernel" in r["Kernel_Name"]:
+        if f"bsx_step_kernel<{n if n <= 4 else 0}, false>" in r["Kernel_Name"] and int(r["Grid_Size"]) == grid_threads:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     kt = glob.glob(os.path.join(src, sub, "*", "*_kernel_trace.csv"))
     du = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(kt[0])) if "bsx_step_kernel" in r["Kernel_Name"]]

@@ -15,7 +15,7 @@ timeout -k 10 200 python bench.py --n-agents 4 --steps 1000 --warmup 100 --no-cp
 timeout -k 10 200 python bench.py --steps 400 --warmup 50 --no-cpu-baseline --no-other-workloads --envs-per-gpu 1048576 > $O/bench_1M.json
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline --no-other-workloads > $O/bench_C2_under_rocprof.json 2> $O/stats.err
-P="python bench.py --steps 300 --warmup 30 --no-cpu-baseline --mode eager"
+P="python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-other-workloads --mode eager"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $P > /dev/null 2> $O/pmc_fetch.err
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $P > /dev/null 2> $O/pmc_write.err
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq -- $P > /dev/null 2> $O/pmc_sq.err
