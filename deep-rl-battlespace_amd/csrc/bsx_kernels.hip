@@ -68,7 +68,7 @@ constexpr double TIME_STEP = 0.1;
 // ---------------------------------------------------------------------------------------------- state layout
 struct __align__(16) PlaneRec {   // 16 B per agent
     int16_t x, y;                 // sprite centre (pygame Rect ints)
-    uint16_t live;                // bit k: bullet slot k in flight
+    uint16_t live;                // number of entries (0..12) in this agent's bullet list
     int8_t hp;                    // alive <=> hp > 0 (sprites.py:143-153)
     uint8_t pad;
     double dir;                   // degrees, [0, 360]
@@ -92,22 +92,24 @@ __host__ __device__ inline Layout make_layout(int64_t E, int n) {
     L.env = o;   o = align256(o + size_t(E) * sizeof(EnvRec));
     L.cnt = o;   o = align256(o + size_t(E) * sizeof(int4));
     L.plane = o; o = align256(o + EA * sizeof(PlaneRec));
-    L.bxy = o;   o = align256(o + 3 * EA * sizeof(uint4));       // [3][EA]: slot k -> chunk k>>2, word k&3, x | y<<16
-    L.bd = o;    o = align256(o + size_t(K) * EA * sizeof(double2)); // [K][EA]: per-update displacement (45cos, 45sin)
-    L.bdir = o;  o = align256(o + size_t(K) * EA * sizeof(double));  // [K][EA]: bullet heading (written at spawn only)
+    // Bullets of an agent are a DENSE list in creation order (entry j of every agent is row j: lanes read the same row
+    // -> coalesced however sparse the bullets are); an entry = packed word x(12) | y(12) | age(4) | 0(4) plus its step.
+    L.bxy = o;   o = align256(o + size_t(K) * EA * sizeof(uint32_t)); // [K][EA] words; age 1..11 = updates so far, 15 = tombstone
+    L.bd = o;    o = align256(o + size_t(K) * EA * sizeof(double2));  // [K][EA]: per-update displacement (45cos, 45sin), same index
+    L.bdir = o;  o = align256(o + size_t(K) * EA * sizeof(double));   // [K][EA]: heading, RING by birth tick % 12 (export only)
     L.total = o;
     return L;
 }
 
 struct StatePtrs {
-    const double2* lut; EnvRec* env; int4* cnt; PlaneRec* plane; uint4* bxy; double2* bd; double* bdir;
+    const double2* lut; EnvRec* env; int4* cnt; PlaneRec* plane; uint32_t* bxy; double2* bd; double* bdir;
 };
 inline StatePtrs state_ptrs(void* base, int64_t E, int n) {
     Layout L = make_layout(E, n);
     char* b = static_cast<char*>(base);
     return StatePtrs{reinterpret_cast<const double2*>(b + L.lut), reinterpret_cast<EnvRec*>(b + L.env),
                      reinterpret_cast<int4*>(b + L.cnt), reinterpret_cast<PlaneRec*>(b + L.plane),
-                     reinterpret_cast<uint4*>(b + L.bxy), reinterpret_cast<double2*>(b + L.bd),
+                     reinterpret_cast<uint32_t*>(b + L.bxy), reinterpret_cast<double2*>(b + L.bd),
                      reinterpret_cast<double*>(b + L.bdir)};
 }
 
@@ -175,6 +177,12 @@ __device__ inline uint32_t rotl12(uint32_t v, int s) {  // rotate a 12-bit mask 
 __device__ inline int sx16(uint32_t w) { return int(int16_t(w & 0xFFFFu)); }
 __device__ inline int sy16(uint32_t w) { return int(int16_t(w >> 16)); }
 __device__ inline uint32_t pack_xy(int x, int y) { return (uint32_t(x) & 0xFFFFu) | (uint32_t(y) << 16); }
+// bullet list entry: a stored bullet is inside the field (0..1200, 0..800), so 12 unsigned bits per coordinate
+constexpr uint32_t TOMBSTONE_AGE = 15;
+__device__ inline uint32_t pack_bullet(int x, int y, int age) { return uint32_t(x) | (uint32_t(y) << 12) | (uint32_t(age) << 24); }
+__device__ inline int bullet_x(uint32_t w) { return int(w & 0xFFFu); }
+__device__ inline int bullet_y(uint32_t w) { return int((w >> 12) & 0xFFFu); }
+__device__ inline int bullet_age(uint32_t w) { return int((w >> 24) & 0xFu); }
 
 __host__ __device__ constexpr int group_width(int n) {
     int g = 2;
@@ -343,24 +351,19 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     unpack_plane(prw, x, y, live, hp, dir);
     EnvU er = unpack_env(erw);
     const uint32_t live0 = live;
-    // Bullets are sparse (uniform random play: 0.6 live per agent out of 12 slots), so a lane does not walk its 12 slots:
-    // it takes its FIRST FOUR live slots as statically indexed "items" (slot, packed xy word, per-update step), all
-    // eight loads issued here in one batch; lanes with more than four live bullets are finished by a wave-uniform loop
-    // further down.  A missing item reads the heading table's first entry (one shared cache line, no DRAM traffic).
+    // Bullets are sparse (uniform random play: 0.6 per agent, 12 at most), and each agent's bullets are a dense list in
+    // creation order: entry j of every agent lives in row j, so the lanes of a wave that own a j-th bullet read ONE
+    // contiguous row.  The first four entries are statically indexed "items", their eight loads issued here in one
+    // batch; longer lists are finished by a wave-uniform loop further down.  A missing item reads the heading
+    // table's first entry (one shared cache line, no DRAM traffic).
     constexpr int NI = 4;
-    const uint32_t* bxy_w = reinterpret_cast<const uint32_t*>(p.st.bxy);
-    uint32_t rem = (DIAG & 2u) ? 0u : live0;
-    int ik[NI]; uint32_t iw[NI]; double2 idd[NI];
+    const int cnt0 = (DIAG & 2u) ? 0 : int(live0 & 15u);
+    uint32_t iw[NI]; double2 idd[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-        const bool has = rem != 0u;
-        const int k = has ? __builtin_ctz(rem) : 0;
-        rem &= rem - 1u;
-        ik[j] = has ? k : -1;
-        const uint32_t* wsrc = has ? bxy_w + (size_t(k >> 2) * EA + g) * 4 + (k & 3) : reinterpret_cast<const uint32_t*>(p.st.lut);
-        const double2* dsrc = has ? &p.st.bd[size_t(k) * EA + g] : p.st.lut;
-        iw[j] = *wsrc;
-        idd[j] = *dsrc;
+        const bool has = j < cnt0;
+        iw[j] = *(has ? &p.st.bxy[size_t(j) * EA + g] : reinterpret_cast<const uint32_t*>(p.st.lut));
+        idd[j] = *(has ? &p.st.bd[size_t(j) * EA + g] : p.st.lut);
     }
     if (!CONT) {
 #pragma unroll
@@ -439,8 +442,7 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     STAMP(2);
     // ---- Bullet.__init__ (sprites.py:293-318) for this call's shot: heading = pre-move heading + (u*8 - 4)
     const bool phys = (mode == M_PHYS) && valid && !(DIAG & 2u);
-    const int ks = tick % K;
-    const int k0 = (tick + 1) % K;                       // slot of the oldest possible bullet
+    const int ks = tick % K;                             // birth-tick ring slot of this call's shot (heading, export only)
     double2 nd = make_double2(0.0, 0.0);
     spawn = spawn && phys;
     if (spawn) {
@@ -453,8 +455,7 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
         double sn, cs;
         sincos(-(bdir * DEG2RAD), &sn, &cs);
         nd = make_double2(BULLET_STEP * cs, BULLET_STEP * sn);
-        p.st.bd[size_t(ks) * EA + g] = nd;
-        p.st.bdir[size_t(ks) * EA + g] = bdir;
+        p.st.bdir[size_t(ks) * EA + g] = bdir;       // ring by birth tick: never moves, read only by bsx_export_state
     }
 
     STAMP(3);
@@ -475,26 +476,28 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     }
 
     STAMP(4);
-    // ---- Bullet.update (sprites.py:321-351) per live bullet ("item"), branch-free, predicates as integer sign masks (0 / -1)
-    constexpr int FW = (N > 0 && N <= 4) ? 4 : 16;       // bits per overlap field
-    constexpr int OW = (FW == 4) ? 1 : 3;                // 64-bit words holding the 12 slot-indexed fields
+    // ---- Bullet.update (sprites.py:321-351) per list entry ("item"), predicates as integer sign masks (0 / -1).
+    //      Survivors are written back compacted (position `pos` <= own index), which keeps creation order.
+    constexpr int FW = (N > 0 && N <= 4) ? 4 : 16;       // bits per overlap field, indexed by AGE (1..11)
+    constexpr int OW = (FW == 4) ? 1 : 3;                // 64-bit words holding the 12 fields
     uint64_t ovl[OW];
 #pragma unroll
     for (int q = 0; q < OW; ++q) ovl[q] = 0;
     int nmiss = 0, nbase = 0, nplane = 0;
+    int pos = 0;                                         // entries written so far = new list length
+    uint64_t posmap = 0;                                 // 4 bits per age: where the survivor of that age now sits
     int eam[NE];
     if (N > 0) {
 #pragma unroll
         for (int j = 0; j < NE; ++j) eam[j] = (s_hp[eb + j] > 0) ? -1 : 0;
     }
-    uint32_t* bxy_wr = reinterpret_cast<uint32_t*>(p.st.bxy);
-    // one bullet: position word `w0` (or the shooter's pre-move pose for this call's shot), step `dd`, slot k, live mask `lvm`
-    auto update_item = [&](int k, int bx0, int by0, double2 dd, int lvm) {
+    // one bullet: pre-update position, step `dd`, updates so far `age0`, list index `j` it was read from (-1: this call's shot)
+    auto update_item = [&](int j, int bx0, int by0, int age0, double2 dd, int lvm) {
         const int bx = int(double(bx0) + dd.x);                                     // truncation toward zero
         const int by = int(double(by0) + dd.y);
-        // miss: dist_travelled >= 500 <=> 12th update (45*12 >= 500 > 45*11) <=> this is the oldest slot k0;
-        // else off the field (x>1200 | x<0 | y>800 | y<0)
-        const int missm = ((bx | (FIELD_W - bx) | by | (FIELD_H - by)) >> 31) | ((k == k0) ? -1 : 0);
+        const int age = age0 + 1;
+        // miss: dist_travelled >= 500 <=> 12th update (45*12 >= 500 > 45*11); else off the field (x>1200|x<0|y>800|y<0)
+        const int missm = ((bx | (FIELD_W - bx) | by | (FIELD_H - by) | (11 - age)) >> 31);
         // base: 6x3 bullet rect vs 62x62 base rect, strict overlap <=> dx in [-33,33] and dy in [-32,31]
         const int dxb = bx - obx, dyb = by - oby;
         const int basem = ~(((dxb + 33) | (33 - dxb) | (dyb + 32) | (31 - dyb)) >> 31) & ~missm;
@@ -502,16 +505,16 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
         uint32_t m = 0;
         if (N > 0) {
 #pragma unroll
-            for (int j = 0; j < NE; ++j) {
-                const int dxp = bx - ex[j], dyp = by - ey[j];
-                const int pm = ~(((dxp + 27) | (27 - dxp) | (dyp + 25) | (24 - dyp)) >> 31) & eam[j];
-                m |= uint32_t(pm) & (1u << j);
+            for (int q = 0; q < NE; ++q) {
+                const int dxp = bx - ex[q], dyp = by - ey[q];
+                const int pm = ~(((dxp + 27) | (27 - dxp) | (dyp + 25) | (24 - dyp)) >> 31) & eam[q];
+                m |= uint32_t(pm) & (1u << q);
             }
         } else {
-            for (int j = 0; j < n; ++j) {
-                const int dxp = bx - s_x[eb + j], dyp = by - s_y[eb + j];
-                const int pm = ~(((dxp + 27) | (27 - dxp) | (dyp + 25) | (24 - dyp)) >> 31) & (s_hp[eb + j] > 0 ? -1 : 0);
-                m |= uint32_t(pm) & (1u << j);
+            for (int q = 0; q < n; ++q) {
+                const int dxp = bx - s_x[eb + q], dyp = by - s_y[eb + q];
+                const int pm = ~(((dxp + 27) | (27 - dxp) | (dyp + 25) | (24 - dyp)) >> 31) & (s_hp[eb + q] > 0 ? -1 : 0);
+                m |= uint32_t(pm) & (1u << q);
             }
         }
         const int gonem = (missm | basem) & lvm;
@@ -519,38 +522,46 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
         m &= uint32_t(keepm);
         nmiss -= missm & lvm;
         nbase -= basem & lvm;
-        const int kk = k & 15;
-        if (OW == 1) ovl[0] |= uint64_t(m) << (kk * FW);
+        const int ag = age & 15;
+        if (OW == 1) ovl[0] |= uint64_t(m) << (ag * FW);
         else {
-            const uint64_t f = uint64_t(m) << ((kk & 3) * 16);
-            ovl[0] |= (kk >> 2) == 0 ? f : 0ull; ovl[OW > 1 ? 1 : 0] |= (kk >> 2) == 1 ? f : 0ull; ovl[OW > 2 ? 2 : 0] |= (kk >> 2) == 2 ? f : 0ull;
+            const uint64_t f = uint64_t(m) << ((ag & 3) * 16);
+            ovl[0] |= (ag >> 2) == 0 ? f : 0ull; ovl[OW > 1 ? 1 : 0] |= (ag >> 2) == 1 ? f : 0ull; ovl[OW > 2 ? 2 : 0] |= (ag >> 2) == 2 ? f : 0ull;
         }
-        live = (live & ~(uint32_t(gonem) & (1u << kk))) | (uint32_t(keepm) & (1u << kk));
-        if (keepm) bxy_wr[(size_t(kk >> 2) * EA + g) * 4 + (kk & 3)] = pack_xy(bx, by);
+        if (keepm) {
+            p.st.bxy[size_t(pos) * EA + g] = pack_bullet(bx, by, age);
+            if (pos != j) p.st.bd[size_t(pos) * EA + g] = dd;           // the entry moved down (or is new): its step moves with it
+            posmap |= uint64_t(pos) << (4 * ag);
+            pos += 1;
+        }
     };
     {
         const int physm = phys ? -1 : 0;
-        // this call's shot first (it is the newest bullet; per-bullet outcomes do not depend on the order, the ordered
-        // resolve below does and walks slots by age)
-        update_item(ks, x0, y0, nd, (spawn ? -1 : 0) & physm);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) update_item(ik[j], sx16(iw[j]), sy16(iw[j]), idd[j], (ik[j] >= 0 ? -1 : 0) & physm);
-        // lanes with more than NI live bullets: rare under sparse play, up to two more rounds when every slot is in use
-        while (__any(rem != 0u)) {
-            int rk[NI]; uint32_t rw[NI]; double2 rd[NI];
+        for (int j = 0; j < NI; ++j) {
+            const int age0 = bullet_age(iw[j]);                                     // a tombstone (plane hit last call) is dropped
+            update_item(j, bullet_x(iw[j]), bullet_y(iw[j]), age0, idd[j], ((j < cnt0 && age0 != int(TOMBSTONE_AGE)) ? -1 : 0) & physm);
+        }
+        // lists longer than NI: rare under sparse play, two more rounds when every agent fires every tick
+        for (int base = NI; __any(cnt0 > base); base += NI) {
+            uint32_t rw[NI]; double2 rd[NI];
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
-                const bool has = rem != 0u;
-                const int k = has ? __builtin_ctz(rem) : 0;
-                rem &= rem - 1u;
-                rk[j] = has ? k : -1;
-                rw[j] = *(has ? bxy_w + (size_t(k >> 2) * EA + g) * 4 + (k & 3) : reinterpret_cast<const uint32_t*>(p.st.lut));
-                rd[j] = *(has ? &p.st.bd[size_t(k) * EA + g] : p.st.lut);
+                const bool has = base + j < cnt0;
+                rw[j] = *(has ? &p.st.bxy[size_t(base + j) * EA + g] : reinterpret_cast<const uint32_t*>(p.st.lut));
+                rd[j] = *(has ? &p.st.bd[size_t(base + j) * EA + g] : p.st.lut);
             }
 #pragma unroll
-            for (int j = 0; j < NI; ++j) update_item(rk[j], sx16(rw[j]), sy16(rw[j]), rd[j], (rk[j] >= 0 ? -1 : 0) & physm);
+            for (int j = 0; j < NI; ++j) {
+                const int age0 = bullet_age(rw[j]);
+                update_item(base + j, bullet_x(rw[j]), bullet_y(rw[j]), age0, rd[j],
+                            ((base + j < cnt0 && age0 != int(TOMBSTONE_AGE)) ? -1 : 0) & physm);
+            }
         }
+        // this call's shot is the newest bullet: appended last
+        update_item(-1, x0, y0, 0, nd, (spawn ? -1 : 0) & physm);
         if (nbase) atomicAdd(const_cast<int*>(&s_bhit[gl + team]), nbase);
+        if (phys) live = uint32_t(pos);
     }
     STAMP(5);
     // ---- ordered plane-hit resolve (battle_env.py:332-360 with sprites.py:348-350): creation order = oldest age
@@ -559,12 +570,11 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
 #pragma unroll
     for (int q = 0; q < OW; ++q) any_ovl |= ovl[q];
     if (__ballot(any_ovl != 0ull) != 0ull && !(DIAG & 4u)) {   // wave-uniform: most waves have no candidate at all
-        uint32_t consumed = 0;                                 // by slot
-        for (int r = 1; r < K; ++r) {                          // rank 0 = age 12 = always a range miss
-            const int k = (k0 + r) % K;                        // my slot of this age
+        uint32_t consumed = 0;                                 // by age
+        for (int ag = K - 1; ag >= 1; --ag) {                  // oldest first; an age-12 bullet is always a range miss
             uint64_t wsel = ovl[0];
-            if (OW == 3) wsel = ((k * FW) / 64 == 0) ? ovl[0] : (((k * FW) / 64 == 1) ? ovl[OW > 1 ? 1 : 0] : ovl[OW > 2 ? 2 : 0]);
-            const uint32_t m = uint32_t(wsel >> ((k * FW) % 64)) & ((1u << FW) - 1u);
+            if (OW == 3) wsel = ((ag >> 2) == 0) ? ovl[0] : (((ag >> 2) == 1) ? ovl[OW > 1 ? 1 : 0] : ovl[OW > 2 ? 2 : 0]);
+            const uint32_t m = uint32_t(wsel >> (OW == 1 ? ag * FW : (ag & 3) * 16)) & ((1u << FW) - 1u);
             if (__ballot(m != 0) == 0ull) continue;            // wave-uniform: nobody has a candidate of this age
             for (int i = 0; i < n; ++i) {
                 if (m != 0 && (a - (team ? n : 0)) == i) {
@@ -572,7 +582,7 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
                         if (((m >> j) & 1u) && s_hp[eb + j] > 0) {
                             s_hp[eb + j] = s_hp[eb + j] - 1;                                 // Plane.hit
                             nplane += 1;
-                            consumed |= 1u << k;
+                            consumed |= 1u << ag;
                             break;
                         }
                     }
@@ -580,7 +590,12 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        live &= ~consumed;
+        // a bullet that hit a plane is gone: its list entry becomes a tombstone, dropped by the next call's compaction
+        while (consumed) {
+            const int ag = __builtin_ctz(consumed);
+            consumed &= consumed - 1u;
+            p.st.bxy[size_t((posmap >> (4 * ag)) & 15u) * EA + g] = pack_bullet(0, 0, int(TOMBSTONE_AGE));
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -731,7 +746,7 @@ __global__ void bsx_mark_done_kernel(EnvRec* env, int64_t E) {
     if (e < E) { EnvRec r; memset(&r, 0, sizeof(r)); r.done = 1; env[e] = r; }
 }
 
-struct ExportArgs { StatePtrs st; int64_t E; int n; BsxExport out; };
+struct ExportArgs { StatePtrs st; int64_t E; int n; BsxExport out; int tie_tick; };
 
 __global__ __launch_bounds__(TPB) void bsx_export_kernel(const ExportArgs p) {
     const int A = 2 * p.n;
@@ -747,16 +762,29 @@ __global__ __launch_bounds__(TPB) void bsx_export_kernel(const ExportArgs p) {
     if (o.pdir) o.pdir[g] = pr.dir;
     if (o.php) o.php[g] = pr.hp;
     if (o.palive) o.palive[g] = pr.hp > 0;
-    uint4 c[3];
-    for (int q = 0; q < 3; ++q) c[q] = p.st.bxy[size_t(q) * EA + g];
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(c);
+    // list entries -> the slot view of the export schema: slot = birth tick % 12, birth tick = (ticks on which bullets
+    // were updated) - age + 1; the time-limit tie call advances the clock but not the bullets (battle_env.py:316-323)
+    const EnvRec ev = p.st.env[e];
+    const int ptick = int(ev.tick) - ((ev.done && ev.winner == BSX_WINNER_TIE && int(ev.tick) >= p.tie_tick) ? 1 : 0);
     for (int k = 0; k < K; ++k) {
-        const bool lv = (pr.live >> k) & 1u;
         const size_t i = g * K + k;
-        if (o.bl_live) o.bl_live[i] = lv;
-        if (o.bl_x) o.bl_x[i] = lv ? sx16(w[k]) : 0;
-        if (o.bl_y) o.bl_y[i] = lv ? sy16(w[k]) : 0;
-        if (o.bl_dir) o.bl_dir[i] = lv ? p.st.bdir[size_t(k) * EA + g] : 0.0;
+        if (o.bl_live) o.bl_live[i] = 0;
+        if (o.bl_x) o.bl_x[i] = 0;
+        if (o.bl_y) o.bl_y[i] = 0;
+        if (o.bl_dir) o.bl_dir[i] = 0.0;
+    }
+    const int cnt = int(pr.live & 15u);
+    for (int j2 = 0; j2 < cnt; ++j2) {
+        const uint32_t w = p.st.bxy[size_t(j2) * EA + g];
+        const int age = bullet_age(w);
+        if (age == int(TOMBSTONE_AGE)) continue;
+        int slot = (ptick - age + 1) % K;
+        if (slot < 0) slot += K;
+        const size_t i = g * K + slot;
+        if (o.bl_live) o.bl_live[i] = 1;
+        if (o.bl_x) o.bl_x[i] = bullet_x(w);
+        if (o.bl_y) o.bl_y[i] = bullet_y(w);
+        if (o.bl_dir) o.bl_dir[i] = p.st.bdir[size_t(slot) * EA + g];
     }
     if (a == 0) {
         const EnvRec er = p.st.env[e];
@@ -940,7 +968,7 @@ int bsx_observe(void* state, int64_t E, int n, float* obs, void* stream) {
 int bsx_export_state(const void* state, int64_t E, int n, const BsxExport* out, void* stream) {
     if (!state || E <= 0 || n < 1 || n > BSX_MAX_N || !out) return BSX_E_ARG;
     if (!aligned(state, 256)) return BSX_E_ALIGN;
-    ExportArgs a{state_ptrs(const_cast<void*>(state), E, n), E, n, *out};
+    ExportArgs a{state_ptrs(const_cast<void*>(state), E, n), E, n, *out, bsx_tie_tick(n)};
     const size_t EA = size_t(E) * 2 * n;
     hipLaunchKernelGGL(bsx_export_kernel, dim3(unsigned((EA + TPB - 1) / TPB)), dim3(TPB), 0,
                        static_cast<hipStream_t>(stream), a);

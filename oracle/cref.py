@@ -13,9 +13,9 @@ _LIB = None
 def load(build=True):
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "libbattlespace_ref.so")
+        path = os.environ.get("BSR_LIB") or os.path.join(_HERE, "libbattlespace_ref.so")   # BSR_LIB: e.g. the ASan build
         src = os.path.join(_HERE, "battlespace_ref.c")
-        if build and (not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src)):
+        if build and not os.environ.get("BSR_LIB") and (not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src)):
             subprocess.run(["make", "-s", "-C", _HERE], check=True)
         lib = ctypes.CDLL(path)
         vp, i64, u64, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_int

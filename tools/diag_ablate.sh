@@ -1,25 +1,17 @@
 #!/bin/bash
-# profiling helper (runs on the GPU box): ablation builds + PMC passes of the C2 bench.  Scratch output under gpurun_out/.
+# Timing-only ablation builds (GPU box): tools/diag_ablate.sh "<bits> <bits> ..." -> gpurun_out/diag/*.json
+# (bits: 1 obs math, 2 bullets, 4 resolve, 8 shot Philox+sincos; results are WRONG with any bit set)
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/diag
 SRC=deep-rl-battlespace_amd/csrc
-FLAGS="-O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 -I include"
 cp $SRC/libbattlespace_hip.so /tmp/product.so
-for d in 1 2 4 7; do
-  hipcc $FLAGS -DBSX_DIAG=$d $SRC/bsx_kernels.hip -o $SRC/libbattlespace_hip.so
-  timeout -k 10 120 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-other-workloads > gpurun_out/diag/diag$d.json
+hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=fast -I include -c $SRC/bsx_actor.hip -o /tmp/actor.o
+for d in ${1:-"8 1 2"}; do
+  hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=off -DBSX_DIAG=$d -I include -c $SRC/bsx_kernels.hip -o /tmp/k.o
+  hipcc --offload-arch=gfx950 -shared -fPIC /tmp/k.o /tmp/actor.o -o $SRC/libbattlespace_hip.so
+  timeout -k 10 120 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-other-workloads > gpurun_out/diag/diag${d}_C2.json
+  timeout -k 10 120 python bench.py --steps 300 --warmup 50 --no-cpu-baseline --no-other-workloads --envs-per-gpu 1048576 > gpurun_out/diag/diag${d}_1M.json
 done
 cp /tmp/product.so $SRC/libbattlespace_hip.so
-timeout -k 10 120 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-other-workloads > gpurun_out/diag/diag0.json
-timeout -k 10 120 python bench.py --steps 400 --warmup 50 --no-cpu-baseline --no-other-workloads --envs-per-gpu 1048576 > gpurun_out/diag/big1M.json
-timeout -k 10 120 python bench.py --steps 400 --warmup 50 --no-cpu-baseline --no-other-workloads --envs-per-gpu 262144 > gpurun_out/diag/big256k.json
-timeout -k 10 120 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-other-workloads --envs-per-gpu 16384 > gpurun_out/diag/small16k.json
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-P="python bench.py --steps 200 --warmup 20 --no-cpu-baseline --mode eager"
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d gpurun_out/diag/pmcA -- $P > /dev/null 2> gpurun_out/diag/pmcA.err
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/diag/pmcB -- $P > /dev/null 2> gpurun_out/diag/pmcB.err
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/diag/pmcC -- $P > /dev/null 2> gpurun_out/diag/pmcC.err
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/diag/pmcD -- $P > /dev/null 2> gpurun_out/diag/pmcD.err
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/diag/pmcE -- $P > /dev/null 2> gpurun_out/diag/pmcE.err
-echo done
+for f in gpurun_out/diag/*.json; do python -c "import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[1], round(d['value']/1e9,3), 'G/s', d['roofline']['avg_launch_us'], 'us')" $f; done
