@@ -307,7 +307,7 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     __shared__ volatile int s_x[SPB], s_y[SPB], s_hp[SPB];
     __shared__ volatile int s_bhit[SPB];                 // base hits, index gl + shooter team
     __shared__ double2 s_lut[CONT ? 1 : 384];            // heading table (361 entries) staged per wave (discrete only)
-    __shared__ volatile float s_obs[SPB * ((N > 0) ? 3 * N + 2 : 3 * BSX_MAX_N + 2)];   // observation rows of the wave
+    __shared__ __attribute__((aligned(16))) float s_obs[SPB * ((N > 0) ? 3 * N + 2 : 3 * BSX_MAX_N + 2)];   // observation rows of the wave
 
     STAMP(0);
     // ================= T0: every load that depends on no other load, issued back to back, raw 16-byte words ========
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     // are one contiguous block of global memory when every lane is an agent (G == A).
     {
         const int D = 3 * n + 2;
-        float* srow = const_cast<float*>(&s_obs[tid * D]);
+        float* srow = &s_obs[tid * D];
         srow[0] = alive ? ob_d : -1.0f;
         srow[1] = alive ? ob_a : -1.0f;
         if (N > 0) {
@@ -659,6 +659,7 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (G == A && (reinterpret_cast<uintptr_t>(p.obs) & 15u) == 0) {
             // rows of this wave: global floats [base, base + rows*D); the wave's offset SPB*D*4 bytes is a multiple of 16
             const int64_t e_first = int64_t(blockIdx.x) * EPB;
@@ -667,8 +668,7 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
             float* gbase = p.obs + size_t(e_first) * A * D;
             for (int i = tid * 4; i < nfl; i += SPB * 4) {
                 if (i + 4 <= nfl) {
-                    const float4 v = make_float4(s_obs[i], s_obs[i + 1], s_obs[i + 2], s_obs[i + 3]);
-                    *reinterpret_cast<float4*>(gbase + i) = v;
+                    *reinterpret_cast<float4*>(gbase + i) = *reinterpret_cast<const float4*>(&s_obs[i]);   // ds_read_b128
                 } else {
                     for (int t = i; t < nfl; ++t) gbase[t] = s_obs[t];
                 }
