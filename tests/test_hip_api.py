@@ -1,0 +1,104 @@
+"""Boundary behaviour of the batched parallel_env surface (GPU): dict API, masked reset, checkpoint, observe(), argument
+errors, inert-after-done semantics inside a batch, counters."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _env(**kw):
+    import deep_rl_battlespace_amd as bsx
+    return bsx.parallel_env(**kw)
+
+
+def _acts(E, A, seed, p_shoot=0.5):
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    a = torch.randint(0, 4, (E, A), generator=g, device="cuda", dtype=torch.int32)
+    return torch.where(torch.rand((E, A), generator=g, device="cuda") < p_shoot, torch.ones_like(a), a)
+
+
+def test_dict_api_is_a_view_of_the_batched_tensors():
+    E, n = 300, 2
+    a, b = _env(n_agents=n, n_envs=E, seed=3), _env(n_agents=n, n_envs=E, seed=3)
+    oa, ob = a.reset(), b.reset()
+    assert set(oa) == set(a.possible_agents) and oa["plane1"].shape == (E, a.obs_size) and oa["plane1"].is_cuda
+    for t in range(40):
+        act = _acts(E, 2 * n, t)
+        obs, rew, dones, infos = a.step({ag: act[:, i].to(torch.int64) for i, ag in enumerate(a.possible_agents)})
+        o2, r2, d2 = b.step_batch(act)
+        for i, ag in enumerate(a.possible_agents):
+            assert torch.equal(obs[ag], o2[:, i]) and torch.equal(rew[ag], r2[:, i]) and torch.equal(dones[ag], d2[:, i])
+        assert infos == {ag: {} for ag in a.possible_agents}
+    assert torch.equal(a.observe("plane2"), o2[:, 2])                      # observe() recomputes the same rows
+    assert a.env_done.dtype == torch.bool and a.winner.dtype == torch.uint8 and a.agents == a.possible_agents
+
+
+def test_inert_after_done_inside_a_batch_and_masked_reset():
+    """auto_reset=False: finished games ignore step() (battle_env.py:303-306) while the others keep playing; a masked
+    reset re-spawns only the selected games and keeps every counter (battle_env.py:246-279)."""
+    E, n = 2000, 1
+    env = _env(n_agents=n, n_envs=E, seed=11)
+    env.reset()
+    for t in range(125):
+        obs, rew, done = env.step_batch(_acts(E, 2, 100 + t, p_shoot=0.7))
+    assert bool(env.env_done.all())                                        # the time-limit tie caught every game by call 121
+    st0 = env.export_state()
+    obs, rew, done = env.step_batch(_acts(E, 2, 999))
+    st1 = env.export_state()
+    assert all(torch.equal(st0[k], st1[k]) for k in st0) and float(rew.abs().max()) == 0.0 and bool(done.all())
+    c0 = env.counters()
+    assert (c0[:, 0] >= 1).all() and (c0[:, 0] == c0[:, 1] + c0[:, 2] + c0[:, 3]).all()
+    mask = torch.zeros(E, dtype=torch.bool, device="cuda"); mask[::3] = True
+    env.reset(mask=mask)
+    assert torch.equal(env.env_done, ~mask)
+    st2 = env.export_state()
+    assert bool((st2["tick"][mask] == 0).all()) and torch.equal(st2["tick"][~mask], st1["tick"][~mask])
+    assert np.array_equal(env.counters(), c0)                              # win / tie counters persist across resets
+    obs, rew, done = env.step_batch(_acts(E, 2, 5))
+    st3 = env.export_state()
+    assert bool((st3["tick"][mask] == 1).all()) and torch.equal(st3["px"][~mask], st1["px"][~mask])
+
+
+def test_checkpoint_roundtrip_replays_the_same_games():
+    E, n = 512, 2
+    env = _env(n_agents=n, n_envs=E, seed=8, auto_reset=True); env.reset()
+    for t in range(30):
+        env.step_batch(_acts(E, 4, t))
+    sd = env.state_dict()
+    ref = [tuple(x.clone() for x in env.step_batch(_acts(E, 4, 100 + t))) for t in range(40)]
+    env.load_state_dict(sd)
+    for t in range(40):
+        o, r, d = env.step_batch(_acts(E, 4, 100 + t))
+        assert torch.equal(o, ref[t][0]) and torch.equal(r, ref[t][1]) and torch.equal(d, ref[t][2])
+
+
+def test_bad_arguments_raise_before_launch():
+    env = _env(n_agents=2, n_envs=16)
+    env.reset()
+    with pytest.raises(ValueError):
+        env.step_batch(torch.zeros((16, 3), dtype=torch.int32, device="cuda"))            # wrong agent count
+    with pytest.raises(TypeError):
+        env.step_batch(torch.zeros((16, 4), dtype=torch.float32, device="cuda"))          # float indices
+    with pytest.raises(ValueError):
+        env.step_batch(torch.zeros((16, 4, 5), dtype=torch.float32, device="cuda"))       # score vectors must be 4 wide
+    with pytest.raises(ValueError):
+        env.reset(spawn=np.zeros((16, 5), np.int32))
+    with pytest.raises(ValueError):
+        _env(n_agents=0)
+    with pytest.raises(ValueError):
+        _env(n_agents=1, n_envs=4, auto_reset=True, rng="python")
+    c = _env(n_agents=1, n_envs=4, continuous_actions=True); c.reset()
+    with pytest.raises(ValueError):
+        c.step_batch(torch.zeros((4, 2), dtype=torch.float32, device="cuda"))
+    # int64 indices (torch's default) and CPU tensors are accepted and converted
+    env.step_batch(torch.zeros((16, 4), dtype=torch.int64))
+
+
+def test_empty_call_ties_every_running_game_of_the_batch():
+    E = 64
+    env = _env(n_agents=1, n_envs=E); env.reset()
+    env.step_batch(_acts(E, 2, 1))
+    obs, rew, dones, _ = env.step({})
+    assert bool(env.env_done.all()) and bool((env.winner == 3).all()) and float(rew["plane0"].abs().max()) == 0.0
+    assert (env.counters()[:, :2] == 1).all()
