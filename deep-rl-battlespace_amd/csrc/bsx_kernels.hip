@@ -306,7 +306,6 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     // operations in order, so cross-lane hand-offs need no s_barrier -- only a compiler scheduling fence.
     __shared__ volatile int s_x[SPB], s_y[SPB], s_hp[SPB];
     __shared__ volatile int s_bhit[SPB];                 // base hits, index gl + shooter team
-    __shared__ double2 s_lut[CONT ? 1 : 384];            // heading table (361 entries) staged per wave (discrete only)
     __shared__ __attribute__((aligned(16))) float s_obs[SPB * ((N > 0) ? 3 * N + 2 : 3 * BSX_MAX_N + 2)];   // observation rows of the wave
 
     STAMP(0);
@@ -315,12 +314,6 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     const uint4 erw = reinterpret_cast<const uint4*>(p.st.env)[ec];
     const int games = reinterpret_cast<const int*>(p.st.cnt)[4 * ec];   // games finished so far = episode id of the RNG streams
     const uint4 prw = reinterpret_cast<const uint4*>(p.st.plane)[g];
-    // heading table: 361 entries = 6 per lane (L2-resident); stored to LDS after the next load batch is out
-    double2 lt[6];
-    if (!CONT) {
-#pragma unroll
-        for (int q = 0; q < 6; ++q) lt[q] = p.st.lut[min(tid + SPB * q, 360)];
-    }
     int act = -1;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, uu_in = 0.0;
     if (p.actions) {                                     // uniform branch
@@ -356,6 +349,15 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     // contiguous row.  The first four entries are statically indexed "items", their eight loads issued here in one
     // batch; longer lists are finished by a wave-uniform loop further down.  A missing item reads the heading
     // table's first entry (one shared cache line, no DRAM traffic).
+    // The heading table (361 x 16 B, read by every wave of every launch) stays hot in each CU's L1: the entry for the
+    // post-rotation heading is gathered FIRST in this batch, so the plane can move while the bullet loads are in flight.
+    double dir_rot = dir;
+    if (!CONT) {
+        if (act == 2) dir_rot = rotate_dir(dir, 15.0);
+        else if (act == 3) dir_rot = rotate_dir(dir, -15.0);
+    }
+    double2 dl = make_double2(0.0, 0.0);
+    if (!CONT) dl = p.st.lut[min(max(int(dir_rot), 0), 360)];   // 21.5*cos(-radians(d)), 21.5*sin(-radians(d)) from host libm
     constexpr int NI = 4;
     const int cnt0 = (DIAG & 2u) ? 0 : int(live0 & 15u);
     uint32_t iw[NI]; double2 idd[NI];
@@ -364,10 +366,6 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
         const bool has = j < cnt0;
         iw[j] = *(has ? &p.st.bxy[size_t(j) * EA + g] : reinterpret_cast<const uint32_t*>(p.st.lut));
         idd[j] = *(has ? &p.st.bd[size_t(j) * EA + g] : p.st.lut);
-    }
-    if (!CONT) {
-#pragma unroll
-        for (int q = 0; q < 6; ++q) s_lut[tid + SPB * q] = lt[q];   // 384 slots: the clamped tail is never read
     }
     const bool alive0 = valid && hp > 0;
     STAMP(1);
@@ -394,8 +392,6 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     const double d0 = dir;
     const int64_t genv = p.env_offset + ec;
 
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // heading table is in LDS (wave-private: no s_barrier)
-    __builtin_amdgcn_wave_barrier();
 
     if (mode == M_RESET) {
         // re-spawn in place of the inert call; episode id = games played so far
@@ -410,10 +406,8 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     } else if (mode == M_PHYS && alive0) {
         // ---- process_action (battle_env.py:383-424)
         if (!CONT) {
-            if (act == 2) dir = rotate_dir(dir, 15.0);
-            else if (act == 3) dir = rotate_dir(dir, -15.0);
+            dir = dir_rot;
             if (act >= 0 && act <= 3) {
-                const double2 dl = s_lut[int(dir)];      // 21.5*cos(-radians(d)), 21.5*sin(-radians(d)) from host libm
                 x = int(double(x) + dl.x);               // Rect.center store truncates toward zero
                 y = int(double(y) + dl.y);
                 clamp_plane(x, y);
