@@ -8,13 +8,19 @@
 //
 // Mapping to the hardware
 //   * lane = agent, lanes of one env are adjacent (group width G = next pow2 >= 2n, G <= 32), so an env never
-//     straddles a 64-wide wavefront; every per-agent array is struct-of-arrays indexed e*A + a: consecutive lanes
-//     touch consecutive 16-byte records -> dwordx4 loads/stores, fully coalesced.
-//   * post-move plane poses and hit points of the workgroup's envs are staged in LDS; each lane reads the opposing
-//     team's block from there for bullet overlap tests, the ordered hit resolve and the all-pairs range / angle-off
-//     observations.
-//   * the ordered plane-hit resolve walks the 12 bullet ages oldest-first; a wavefront ballot skips ages at which no
-//     lane of the wave has a candidate (almost all of them), and group ballots give the "nobody left alive" test.
+//     straddles a 64-wide wavefront and a workgroup is ONE wavefront: LDS hand-offs are wave-private, no s_barrier.
+//     Every per-agent array is struct-of-arrays indexed e*A + a: consecutive lanes touch consecutive 16-byte records.
+//   * the kernel is latency-bound at 65 536 games and issue-bound at a million, so: all independent loads go out in one
+//     batch as raw 16-byte words (clamped indices, no per-lane branches); the single dependent batch (heading-table
+//     entry, first four bullet-list entries) follows as soon as the plane record lands and is covered by the fp64
+//     observation math; predicates are integer sign masks, not SGPR lane masks.
+//   * an agent's bullets are a dense creation-ordered list (row j = j-th bullet of every agent), so sparse bullets still
+//     read contiguous rows; survivors are written back compacted.
+//   * post-move plane poses and hit points of the wave's envs are staged in LDS; each lane reads the opposing team's
+//     block from there for bullet overlap tests, the ordered hit resolve and the all-pairs range / angle-off
+//     observations; observation rows leave through LDS as coalesced 16-byte stores.
+//   * the ordered plane-hit resolve walks bullet ages oldest-first; a wavefront ballot skips ages at which no lane of
+//     the wave has a candidate (almost all of them), and group ballots give the "nobody left alive" test.
 //   * HBM-bound integer/fp64 work, no dense contraction: no MFMA.
 // Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off   (no FMA contraction: positions are float64 add-then-
 // truncate in the reference, sprites.py:130-131,332-333, and must round exactly as CPython rounds them).
