@@ -2,16 +2,23 @@
 //
 // Replaces, for the rollout path, the reference's per-agent `ActorNetwork.forward` + noise + clamp
 // (maddpg/networks.py:81-85, maddpg/agent.py:25-33): obs[D] -> Linear 64 -> LayerNorm -> ReLU -> Linear 64 ->
-// LayerNorm -> ReLU -> Linear n_actions(4) -> tanh (-> + N(0, std) -> clamp(-1, 1)), one independent weight set per
-// agent.  Composed from torch ops this is ~20 memory-bound passes over [A, E, 64] activations (420 us per tick at
-// 65 536 x 1v1); fused, a row never leaves registers: 20 B in, 16 B out.
+// LayerNorm -> ReLU -> Linear 4 -> tanh (-> + N(0, std) -> clamp(-1, 1)), one independent weight set per agent.
+// Composed from torch ops this is ~20 memory-bound passes over [A, E, 64] activations (420 us per tick at
+// 65 536 x 1v1); fused, a row never leaves the register file: 4*D bytes in, 16 bytes out.
 //
-// Mapping: one lane = one observation row; a workgroup handles 256 rows of ONE agent index, so its weights are
-// workgroup-uniform: they arrive through the SCALAR path (s_load -> SGPR operands of the FMAs), not LDS or VGPRs.
-// The 64x64 layer is 4096 FMAs per row issued as packed-f32 FMAs (v_pk_fma_f32) with both activation vectors in
-// VGPRs.  f32 MFMA would run at the same rate as packed VALU on gfx950 (64 FLOP/clk/SIMD) and the per-lane row layout
-// needs no fragment shuffles, so this stays on the vector pipe.
-// Built WITHOUT -ffp-contract=off (no bit-exactness contract here; checked against a torch fp32 reference).
+// This is the one GEMM-shaped op of the project, so it runs on the matrix cores: v_mfma_f32_32x32x2_f32 (f32 in, f32
+// accumulate -- bit-for-bit an fmaf chain, no reduced precision).  Everything is computed TRANSPOSED,
+//     H^T [64 neurons x 64 rows] = W^T [64 x K] * X^T [K x 64 rows],
+// so that a wave's 64 observation rows sit on the N (lane) axis and neurons on the M (register) axis:
+//   * A operand = weights, one VGPR per k-step and 32-neuron tile, loaded once per wave (the 64x64 layer is 64 VGPRs);
+//   * B operand of layer 1 = observation values straight from memory;
+//   * B operand of layer 2 = the ACCUMULATOR REGISTERS of layer 1 as they stand: register v of tile mt in lane l holds
+//     neuron 32*mt + (v&3) + 8*(v>>2) + 4*(l>>5) of row (l&31) -- exactly a (k_lo, k_hi) pair of a K=2 step.  The K order
+//     is therefore permuted; the host packs W2 in the same order, and a sum does not care.  No LDS, no shuffles.
+//   * LayerNorm needs a row's 64 neurons: 32 registers of the lane plus the partner lane l^32 -> one xor-32 shuffle.
+//   * the 64 -> 4 head is 128 VALU FMAs per lane on the accumulator registers plus the same xor-32 add.
+// A workgroup = 4 waves x 64 rows of ONE agent (blockIdx.y); the small per-neuron vectors and the head weights are
+// staged once in LDS.  Built WITHOUT -ffp-contract=off (checked against a torch fp32 reference, not bit-exact).
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -23,13 +30,23 @@ namespace {
 constexpr int H = 64;            // fc1_dims = fc2_dims = 64 (main.py:15-16)
 constexpr int NA = 4;            // discrete action scores
 constexpr int TPB = 256;
+constexpr int ROWS_PER_WAVE = 64;
 
-typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__host__ __device__ constexpr int blob_floats(int D) {
-    // W1[D][H] b1 g1 be1 | W2[H][H] b2 g2 be2 | W3[H][NA] b3[NA]
-    return D * H + 3 * H + H * H + 3 * H + H * NA + NA;
-}
+// packed blob per agent (floats); Dp = obs_len rounded up to even
+//   W1A[mo 2][s Dp/2][lane 64]                 W1[k = 2s + (lane>>5)][32*mo + (lane&31)], 0 for k >= D
+//   W2A[mo 2][mt 2][vq 4][lane 64][t 4]        W2[k = nid(mt, 4*vq+t, lane>>5)][32*mo + (lane&31)]
+//   small: b1p g1p be1p b2p g2p be2p, each [hh 2][mo 2][v 16] = value[nid(mo, v, hh)]
+//   W3P[hh 2][mt 2][v 16][4]                   W3[k = nid(mt, v, hh)][0..3]
+//   b3[4]
+// nid(m, v, hh) = 32*m + (v&3) + 8*(v>>2) + 4*hh  -- the neuron held by accumulator register v of tile m in lane half hh
+__host__ __device__ constexpr int dpad(int D) { return (D + 1) & ~1; }
+__host__ __device__ constexpr int off_w2(int D) { return H * dpad(D); }
+__host__ __device__ constexpr int off_small(int D) { return off_w2(D) + H * H; }
+__host__ __device__ constexpr int off_w3(int D) { return off_small(D) + 6 * H; }
+__host__ __device__ constexpr int off_b3(int D) { return off_w3(D) + H * NA; }
+__host__ __device__ constexpr int blob_floats(int D) { return off_b3(D) + NA; }
 
 __device__ inline uint4 philox4x32_10(uint4 ctr, uint2 key) {
 #pragma unroll
@@ -42,102 +59,133 @@ __device__ inline uint4 philox4x32_10(uint4 ctr, uint2 key) {
     return ctr;
 }
 
-// y = relu(layernorm(h) * g + b), in place, h in registers (torch semantics: biased variance, eps 1e-5)
-__device__ inline void ln_relu(float (&h)[H], const float* __restrict__ g, const float* __restrict__ b) {
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < H; ++j) s += h[j];
-    const float mean = s * (1.0f / H);
-    float v = 0.f;
-#pragma unroll
-    for (int j = 0; j < H; ++j) { const float d = h[j] - mean; v = fmaf(d, d, v); }
-    const float rstd = rsqrtf(v * (1.0f / H) + 1e-5f);
-#pragma unroll
-    for (int j = 0; j < H; j += 4) {
-        const float4 gg = *reinterpret_cast<const float4*>(g + j), bb = *reinterpret_cast<const float4*>(b + j);
-        h[j + 0] = fmaxf(fmaf((h[j + 0] - mean) * rstd, gg.x, bb.x), 0.f);
-        h[j + 1] = fmaxf(fmaf((h[j + 1] - mean) * rstd, gg.y, bb.y), 0.f);
-        h[j + 2] = fmaxf(fmaf((h[j + 2] - mean) * rstd, gg.z, bb.z), 0.f);
-        h[j + 3] = fmaxf(fmaf((h[j + 3] - mean) * rstd, gg.w, bb.w), 0.f);
-    }
-}
-
-// out[j] += x * w[j], j = 0..H-1, as packed FMAs; w = 64 contiguous floats at a wave-uniform address (scalar loads)
-__device__ inline void axpy64(float2v (&acc)[H / 2], float x, const float* __restrict__ w) {
-    const float2v xx = {x, x};
-#pragma unroll
-    for (int j = 0; j < H; j += 4) {
-        const float4 ww = *reinterpret_cast<const float4*>(w + j);
-        const float2v w0 = {ww.x, ww.y}, w1 = {ww.z, ww.w};
-        acc[j / 2] = __builtin_elementwise_fma(xx, w0, acc[j / 2]);
-        acc[j / 2 + 1] = __builtin_elementwise_fma(xx, w1, acc[j / 2 + 1]);
-    }
-}
-
 struct ActorArgs {
     const float* weights; const float* obs; float* scores;
     int64_t E; int A; int D; float noise_std; uint64_t seed; uint64_t seq; const uint64_t* seq_base;
 };
 
-template <int DT>   // DT = compile-time obs length (5, 8, 11, 14) or 0 = runtime D (obs row re-read from memory)
-__global__ __launch_bounds__(TPB) void bsx_actor_kernel(const float* __restrict__ weights, const ActorArgs p) {
-    const int D = DT > 0 ? DT : p.D;
+// LayerNorm over the 64 neurons of each row + ReLU, in place on the accumulator tiles acc[mo][nt] (torch semantics:
+// biased variance, eps 1e-5).  gp / bp: this lane half's gain / bias vectors, [mo 2][v 16] floats in LDS.
+__device__ inline void ln_relu_tiles(f32x16 (&acc)[2][2], const float* __restrict__ gp, const float* __restrict__ bp) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        float s = 0.f;
+#pragma unroll
+        for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) s += acc[mo][nt][v];
+        s += __shfl_xor(s, 32);
+        const float mean = s * (1.0f / H);
+        float q = 0.f;
+#pragma unroll
+        for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { const float d = acc[mo][nt][v] - mean; q = fmaf(d, d, q); }
+        q += __shfl_xor(q, 32);
+        const float rstd = rsqrtf(q * (1.0f / H) + 1e-5f);
+#pragma unroll
+        for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+                acc[mo][nt][v] = fmaxf(fmaf((acc[mo][nt][v] - mean) * rstd, gp[mo * 16 + v], bp[mo * 16 + v]), 0.f);
+    }
+}
+
+__global__ __launch_bounds__(TPB) void bsx_actor_kernel(const ActorArgs p) {
+    const int D = p.D, Dp = dpad(D);
     const int a = blockIdx.y;
-    const int64_t e = int64_t(blockIdx.x) * TPB + threadIdx.x;
-    const int P = blob_floats(D);
-    // This workgroup's weights are wave-uniform addresses of read-only memory: the compiler fetches them with scalar
-    // loads (s_load_dwordx8/x16 through the scalar cache) and feeds them to the packed FMAs as SGPR operands -- no LDS
-    // traffic and no per-lane weight registers.
-    const float* __restrict__ sw = weights + size_t(a) * P;
-    const int64_t ec = e < p.E ? e : p.E - 1;
-    const size_t row = size_t(ec) * p.A + a;
-    float x[DT > 0 ? DT : 1];
-    if (DT > 0) {
-#pragma unroll
-        for (int k = 0; k < DT; ++k) x[k] = p.obs[row * DT + k];
-    }
-    const float* W1 = sw;                 const float* b1 = W1 + D * H;   const float* g1 = b1 + H; const float* be1 = g1 + H;
-    const float* W2 = be1 + H;            const float* b2 = W2 + H * H;   const float* g2 = b2 + H; const float* be2 = g2 + H;
-    const float* W3 = be2 + H;            const float* b3 = W3 + H * NA;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hh = lane >> 5, c = lane & 31;
+    const float* __restrict__ W = p.weights + size_t(a) * blob_floats(D);
 
-    // ---- layer 1
-    float2v acc[H / 2];
-#pragma unroll
-    for (int j = 0; j < H; j += 4) {
-        const float4 bb = *reinterpret_cast<const float4*>(b1 + j);
-        acc[j / 2] = float2v{bb.x, bb.y}; acc[j / 2 + 1] = float2v{bb.z, bb.w};
-    }
-    if (DT > 0) {
-#pragma unroll
-        for (int k = 0; k < DT; ++k) axpy64(acc, x[k], W1 + k * H);
-    } else {
-        for (int k = 0; k < D; ++k) axpy64(acc, p.obs[row * D + k], W1 + k * H);
-    }
-    float h[H];
-#pragma unroll
-    for (int j = 0; j < H / 2; ++j) { h[2 * j] = acc[j].x; h[2 * j + 1] = acc[j].y; }
-    ln_relu(h, g1, be1);
+    // per-neuron vectors (6 x 64), head weights (256) and head bias (4): once per workgroup into LDS
+    __shared__ __attribute__((aligned(16))) float s_small[6 * H + H * NA + NA];
+    for (int i = tid; i < (6 * H + H * NA + NA) / 4; i += TPB)
+        reinterpret_cast<float4*>(s_small)[i] = reinterpret_cast<const float4*>(W + off_small(D))[i];
 
-    // ---- layer 2: 64 x 64, fully unrolled so that h[k] is a static register index
+    // the 64 x 64 layer's A operands: 64 VGPRs, coalesced 16-byte loads, in flight while layer 1 runs
+    float4 w2[2][2][4];
 #pragma unroll
-    for (int j = 0; j < H; j += 4) {
-        const float4 bb = *reinterpret_cast<const float4*>(b2 + j);
-        acc[j / 2] = float2v{bb.x, bb.y}; acc[j / 2 + 1] = float2v{bb.z, bb.w};
-    }
+    for (int mo = 0; mo < 2; ++mo)
 #pragma unroll
-    for (int k = 0; k < H; ++k) axpy64(acc, h[k], W2 + k * H);
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int j = 0; j < H / 2; ++j) { h[2 * j] = acc[j].x; h[2 * j + 1] = acc[j].y; }
-    ln_relu(h, g2, be2);
+            for (int vq = 0; vq < 4; ++vq)
+                w2[mo][mt][vq] = reinterpret_cast<const float4*>(W + off_w2(D))[((mo * 2 + mt) * 4 + vq) * 64 + lane];
 
-    // ---- head: 64 -> 4, tanh
-    float4 o = *reinterpret_cast<const float4*>(b3);
+    const int64_t row0 = (int64_t(blockIdx.x) * (TPB / 64) + wave) * ROWS_PER_WAVE;   // first env of this wave
+    __syncthreads();
+    const float* sm = s_small + hh * 32;      // this lane half's [mo][v] slice of each 64-float vector ([hh][mo][v])
+
+    // ---- layer 1: acc1[mo][nt] = b1 + W1^T * X^T
+    f32x16 acc1[2][2];
 #pragma unroll
-    for (int k = 0; k < H; ++k) {
-        const float4 ww = *reinterpret_cast<const float4*>(W3 + k * NA);
-        o.x = fmaf(h[k], ww.x, o.x); o.y = fmaf(h[k], ww.y, o.y); o.z = fmaf(h[k], ww.z, o.z); o.w = fmaf(h[k], ww.w, o.w);
+    for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { acc1[mo][0][v] = sm[0 * H + mo * 16 + v]; acc1[mo][1][v] = acc1[mo][0][v]; }
+    const float* xrow[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int64_t en = row0 + 32 * nt + c;
+        xrow[nt] = p.obs + (size_t(en < p.E ? en : p.E - 1) * p.A + a) * D;
     }
-    o.x = tanhf(o.x); o.y = tanhf(o.y); o.z = tanhf(o.z); o.w = tanhf(o.w);
+    for (int s = 0; s < Dp / 2; ++s) {
+        const int k = 2 * s + hh;
+        const float a0 = W[(0 * (Dp / 2) + s) * 64 + lane], a1 = W[(1 * (Dp / 2) + s) * 64 + lane];
+        const float b0 = k < D ? xrow[0][k] : 0.f, b1 = k < D ? xrow[1][k] : 0.f;
+        acc1[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc1[0][0], 0, 0, 0);
+        acc1[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc1[0][1], 0, 0, 0);
+        acc1[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc1[1][0], 0, 0, 0);
+        acc1[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc1[1][1], 0, 0, 0);
+    }
+    ln_relu_tiles(acc1, sm + 1 * H, sm + 2 * H);
+
+    // ---- layer 2: acc2[mo][nt] = b2 + W2^T * H1^T, the K index running over layer 1's accumulator registers
+    f32x16 acc2[2][2];
+#pragma unroll
+    for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { acc2[mo][0][v] = sm[3 * H + mo * 16 + v]; acc2[mo][1][v] = acc2[mo][0][v]; }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const float4 q0 = w2[0][mt][v >> 2], q1 = w2[1][mt][v >> 2];
+            const float wa0 = (v & 3) == 0 ? q0.x : ((v & 3) == 1 ? q0.y : ((v & 3) == 2 ? q0.z : q0.w));
+            const float wa1 = (v & 3) == 0 ? q1.x : ((v & 3) == 1 ? q1.y : ((v & 3) == 2 ? q1.z : q1.w));
+            acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa0, acc1[mt][0][v], acc2[0][0], 0, 0, 0);
+            acc2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa0, acc1[mt][1][v], acc2[0][1], 0, 0, 0);
+            acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa1, acc1[mt][0][v], acc2[1][0], 0, 0, 0);
+            acc2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa1, acc1[mt][1][v], acc2[1][1], 0, 0, 0);
+        }
+    ln_relu_tiles(acc2, sm + 4 * H, sm + 5 * H);
+
+    // ---- head: 64 -> 4 on the vector pipe; each lane sums its 32 neurons, the partner lane l^32 has the other 32
+    const float4* w3 = reinterpret_cast<const float4*>(s_small + 6 * H) + hh * 32;   // [hh][mt][v] float4
+    float4 o[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const float4 ww = w3[mt * 16 + v];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const float hv = acc2[mt][nt][v];
+                o[nt].x = fmaf(hv, ww.x, o[nt].x); o[nt].y = fmaf(hv, ww.y, o[nt].y);
+                o[nt].z = fmaf(hv, ww.z, o[nt].z); o[nt].w = fmaf(hv, ww.w, o[nt].w);
+            }
+        }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        o[nt].x += __shfl_xor(o[nt].x, 32); o[nt].y += __shfl_xor(o[nt].y, 32);
+        o[nt].z += __shfl_xor(o[nt].z, 32); o[nt].w += __shfl_xor(o[nt].w, 32);
+    }
+    // lower half finishes the rows of tile 0, upper half those of tile 1: every lane writes one row
+    float4 r4 = hh ? o[1] : o[0];
+    const float4 b3 = *reinterpret_cast<const float4*>(s_small + 6 * H + H * NA);
+    r4.x = tanhf(r4.x + b3.x); r4.y = tanhf(r4.y + b3.y); r4.z = tanhf(r4.z + b3.z); r4.w = tanhf(r4.w + b3.w);
+    const int64_t e = row0 + 32 * hh + c;
+    const size_t row = size_t(e < p.E ? e : p.E - 1) * p.A + a;
 
     // ---- exploration noise + clamp (maddpg/agent.py:30-31), Gaussian via Philox + Box-Muller, keyed by (seed, seq, row)
     if (p.noise_std > 0.f) {
@@ -150,12 +198,12 @@ __global__ __launch_bounds__(TPB) void bsx_actor_kernel(const float* __restrict_
         float s0, c0, s1, c1;
         __sincosf(6.2831853071795864f * u1, &s0, &c0);
         __sincosf(6.2831853071795864f * u3, &s1, &c1);
-        o.x = fminf(fmaxf(fmaf(p.noise_std, m0 * c0, o.x), -1.f), 1.f);
-        o.y = fminf(fmaxf(fmaf(p.noise_std, m0 * s0, o.y), -1.f), 1.f);
-        o.z = fminf(fmaxf(fmaf(p.noise_std, m1 * c1, o.z), -1.f), 1.f);
-        o.w = fminf(fmaxf(fmaf(p.noise_std, m1 * s1, o.w), -1.f), 1.f);
+        r4.x = fminf(fmaxf(fmaf(p.noise_std, m0 * c0, r4.x), -1.f), 1.f);
+        r4.y = fminf(fmaxf(fmaf(p.noise_std, m0 * s0, r4.y), -1.f), 1.f);
+        r4.z = fminf(fmaxf(fmaf(p.noise_std, m1 * c1, r4.z), -1.f), 1.f);
+        r4.w = fminf(fmaxf(fmaf(p.noise_std, m1 * s1, r4.w), -1.f), 1.f);
     }
-    if (e < p.E) reinterpret_cast<float4*>(p.scores)[row] = o;
+    if (e < p.E) reinterpret_cast<float4*>(p.scores)[row] = r4;
 }
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
@@ -176,15 +224,9 @@ int bsx_actor_forward(const float* weights, const float* obs, float* scores, int
     if (!aligned(weights, 16) || !aligned(scores, 16) || !aligned(obs, 4)) return BSX_E_ALIGN;
     const int A = 2 * n, D = 3 * n + 2;
     ActorArgs a{weights, obs, scores, E, A, D, noise_std, seed, seq, seq_base};
-    const dim3 grid(unsigned((E + TPB - 1) / TPB), unsigned(A)), block(TPB);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    switch (n) {
-        case 1: hipLaunchKernelGGL(bsx_actor_kernel<5>, grid, block, 0, s, weights, a); break;
-        case 2: hipLaunchKernelGGL(bsx_actor_kernel<8>, grid, block, 0, s, weights, a); break;
-        case 3: hipLaunchKernelGGL(bsx_actor_kernel<11>, grid, block, 0, s, weights, a); break;
-        case 4: hipLaunchKernelGGL(bsx_actor_kernel<14>, grid, block, 0, s, weights, a); break;
-        default: hipLaunchKernelGGL(bsx_actor_kernel<0>, grid, block, 0, s, weights, a); break;
-    }
+    const int rows_per_block = (TPB / 64) * ROWS_PER_WAVE;
+    const dim3 grid(unsigned((E + rows_per_block - 1) / rows_per_block), unsigned(A)), block(TPB);
+    hipLaunchKernelGGL(bsx_actor_kernel, grid, block, 0, static_cast<hipStream_t>(stream), a);
     return int(hipGetLastError());
 }
 

@@ -50,15 +50,42 @@ class StackedActor(nn.Module):
 
     @torch.no_grad()
     def pack(self, out=None):
-        """Weights in the layout `bsx_actor_forward` reads (include/battlespace_hip.h): per agent
-        W1[D][64] b1 ln1_gain ln1_bias W2[64][64] b2 ln2_gain ln2_bias W3[64][4] b3, float32, contiguous."""
+        """Weights in the layout `bsx_actor_forward` reads (csrc/bsx_actor.hip): everything is laid out for the MFMA
+        fragments of the transposed product H^T = W^T X^T -- per agent
+          W1A[mo 2][s Dp/2][lane 64]            = W1[2s + (lane>>5)][32 mo + (lane&31)]   (0 beyond obs_len; Dp = obs_len rounded up to even)
+          W2A[mo 2][mt 2][vq 4][lane 64][t 4]   = W2[nid(mt, 4 vq + t, lane>>5)][32 mo + (lane&31)]
+          b1 g1 be1 b2 g2 be2, each [hh 2][mo 2][v 16] = vec[nid(mo, v, hh)]
+          W3P[hh 2][mt 2][v 16][4]              = W3[nid(mt, v, hh)][:]        b3[4]
+        with nid(m, v, hh) = 32 m + (v&3) + 8 (v>>2) + 4 hh, the neuron that accumulator register v of 32-neuron tile m
+        holds in lane half hh.  float32, contiguous, [n_actors, floats]."""
         if self.w1.shape[2] != 64 or self.w2.shape[2] != 64 or self.n_actions != 4:
             raise ValueError("the fused actor kernel is built for fc1 = fc2 = 64 and 4 action scores (main.py:15-16)")
-        A = self.n_actors
-        parts = [self.w1.reshape(A, -1), self.b1.reshape(A, -1), self.g1.reshape(A, -1), self.h1.reshape(A, -1),
-                 self.w2.reshape(A, -1), self.b2.reshape(A, -1), self.g2.reshape(A, -1), self.h2.reshape(A, -1),
-                 self.w3.reshape(A, -1), self.b3.reshape(A, -1)]
-        blob = torch.cat([p.float() for p in parts], dim=1).contiguous()
+        A, D, dev = self.n_actors, self.obs_len, self.w1.device
+        Dp = (D + 1) & ~1
+        lane = torch.arange(64, device=dev)
+        hh_l, c_l = lane >> 5, lane & 31
+        v16 = torch.arange(16, device=dev)
+        nid = lambda m, v, hh: 32 * m + (v & 3) + 8 * (v >> 2) + 4 * hh          # noqa: E731
+        w1 = torch.zeros((A, Dp, 64), dtype=torch.float32, device=dev)
+        w1[:, :D] = self.w1.float()
+        # W1A[a, mo, s, lane]
+        mo = torch.arange(2, device=dev).view(2, 1, 1); s_ = torch.arange(Dp // 2, device=dev).view(1, -1, 1)
+        k1 = (2 * s_ + hh_l.view(1, 1, 64)).expand(2, Dp // 2, 64)
+        j1 = (32 * mo + c_l.view(1, 1, 64)).expand(2, Dp // 2, 64)
+        W1A = w1[:, k1, j1].reshape(A, -1)
+        # W2A[a, mo, mt, vq, lane, t]
+        mo5 = torch.arange(2, device=dev).view(2, 1, 1, 1, 1); mt5 = torch.arange(2, device=dev).view(1, 2, 1, 1, 1)
+        vq5 = torch.arange(4, device=dev).view(1, 1, 4, 1, 1); t5 = torch.arange(4, device=dev).view(1, 1, 1, 1, 4)
+        l5 = lane.view(1, 1, 1, 64, 1)
+        k2 = nid(mt5, 4 * vq5 + t5, l5 >> 5).expand(2, 2, 4, 64, 4)
+        j2 = (32 * mo5 + (l5 & 31)).expand(2, 2, 4, 64, 4)
+        W2A = self.w2.float()[:, k2, j2].reshape(A, -1)
+        # per-neuron vectors [hh, mo, v]
+        hh3 = torch.arange(2, device=dev).view(2, 1, 1); mo3 = torch.arange(2, device=dev).view(1, 2, 1)
+        idx = nid(mo3, v16.view(1, 1, 16), hh3).reshape(-1)                      # [hh][mo][v] -> neuron
+        small = [x.float().reshape(A, 64)[:, idx] for x in (self.b1, self.g1, self.h1, self.b2, self.g2, self.h2)]
+        W3P = self.w3.float()[:, idx, :].reshape(A, -1)                            # [hh][mt][v][4]: same index pattern with mt for mo
+        blob = torch.cat([W1A, W2A, *small, W3P, self.b3.float().reshape(A, -1)], dim=1).contiguous()
         if out is not None:
             out.copy_(blob)
             return out
@@ -77,9 +104,9 @@ class StackedActor(nn.Module):
 
 
 class FusedActor:
-    """The same per-agent actor as ONE hand-written HIP kernel (csrc/bsx_actor.hip, `bsx_actor_forward`): a row never
-    leaves registers -- 4*D bytes in, 16 bytes out -- instead of ~20 memory-bound torch passes over [A, E, 64]
-    activations.  Holds a packed copy of a StackedActor's weights; call `refresh()` after the learner updates them.
+    """The same per-agent actor as ONE hand-written HIP kernel on the matrix cores (csrc/bsx_actor.hip,
+    `bsx_actor_forward`: f32 MFMA, exact f32): a row never leaves the register file -- 4*D bytes in, 16 bytes out --
+    instead of ~20 memory-bound torch passes over [A, E, 64] activations.  Holds a packed copy of a StackedActor's weights; call `refresh()` after the learner updates them.
     Optional exploration noise (Gaussian, then clamp(-1, 1) as maddpg/agent.py:31) is drawn in-kernel."""
 
     def __init__(self, actor, n_agents_per_team, seed=0):

@@ -114,9 +114,14 @@ int bsx_export_state(const void* state, int64_t E, int n, const BsxExport* out, 
  * Replaces, on the rollout path, ActorNetwork.forward + noise + clamp of the reference's callers
  * (maddpg/networks.py:81-85, maddpg/agent.py:25-33): obs[3n+2] -> 64 -> LayerNorm -> ReLU -> 64 -> LayerNorm -> ReLU ->
  * 4 -> tanh [-> + N(0, noise_std) -> clamp(-1,1)], one independent weight set per agent a = 0..2n-1.
- *   weights  float32, 16-byte aligned, 2n blobs of bsx_actor_blob_floats(3n+2) floats each, laid out
- *            W1[D][64] b1[64] ln1_gain[64] ln1_bias[64] W2[64][64] b2[64] ln2_gain[64] ln2_bias[64] W3[64][4] b3[4]
- *            (W[k][j] multiplies input k into output j, i.e. the transpose of torch's Linear.weight)
+ *   weights  float32, 16-byte aligned, 2n blobs of bsx_actor_blob_floats(3n+2) floats each, packed for the MFMA fragments
+ *            of the transposed product H^T = W^T X^T (f32 MFMA 32x32x2: exact f32).  With Dp = D rounded up to even and
+ *            nid(m, v, hh) = 32m + (v&3) + 8(v>>2) + 4hh (the neuron held by accumulator register v of tile m, lane half hh):
+ *              W1A[mo 2][s Dp/2][lane 64]          = W1[2s + (lane>>5)][32mo + (lane&31)], 0 beyond D
+ *              W2A[mo 2][mt 2][vq 4][lane 64][t 4] = W2[nid(mt, 4vq + t, lane>>5)][32mo + (lane&31)]
+ *              b1 ln1_gain ln1_bias b2 ln2_gain ln2_bias, each [hh 2][mo 2][v 16] = vec[nid(mo, v, hh)]
+ *              W3P[hh 2][mt 2][v 16][4] = W3[nid(mt, v, hh)][0..3];  b3[4]
+ *            (W[k][j] multiplies input k into output j, i.e. the transpose of torch's Linear.weight.)
  *   obs      float32[E*A*D] (what bsx_step_* / bsx_reset wrote);  scores float32[E*A*4], 16-byte aligned: feed it to
  *            bsx_step_discrete with BSX_ACT_LOGITS_F32.  Noise is Philox-keyed by (seed, seq + *seq_base, row): pass a new
  *            seq per call, or -- inside a captured HIP graph, whose arguments are frozen -- a device word seq_base (nullable)
