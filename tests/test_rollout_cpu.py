@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from trace_util import GOLDEN
@@ -57,3 +58,78 @@ def test_replay_buffer_ring_and_sample_layout_follow_the_reference():
     big._put(torch.arange(12.).reshape(12, 1, 1).expand(12, 2, obs_size), torch.zeros(12, 2, nact), torch.arange(12.).reshape(12, 1).expand(12, 2),
              torch.zeros(12, 2, obs_size), torch.zeros(12, 2, dtype=torch.bool))
     assert sorted(big.rew_mem[:, 0].tolist()) == [7., 8., 9., 10., 11.] and big.mem_cntr == 12
+
+
+def _mfma_32x32x2(avec, bvec, acc):
+    """v_mfma_f32_32x32x2_f32 on host arrays indexed by lane: A[i = l&31][k = l>>5], B[k = l>>5][j = l&31],
+    D[i = (v&3) + 8(v>>2) + 4(l>>5)][j = l&31] in register v of lane l (cdna_hip_programming.md section 3)."""
+    lanes = np.arange(64)
+    Am = np.zeros((32, 2)); Bm = np.zeros((2, 32))
+    Am[lanes & 31, lanes >> 5] = avec
+    Bm[lanes >> 5, lanes & 31] = bvec
+    Dm = Am @ Bm
+    for v in range(16):
+        acc[v] += Dm[(v & 3) + 8 * (v >> 2) + 4 * (lanes >> 5), lanes & 31]
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_packed_actor_blob_drives_the_mfma_fragment_arithmetic(n):
+    """StackedActor.pack() + the kernel's index arithmetic (csrc/bsx_actor.hip), emulated lane by lane on the host with
+    the documented MFMA fragment maps, reproduce the plain forward: pins the blob layout of include/battlespace_hip.h."""
+    from deep_rl_battlespace_amd.rollout import StackedActor
+    torch.manual_seed(n)
+    A, D = 2 * n, 3 * n + 2
+    act = StackedActor(A, D, 4)
+    with torch.no_grad():
+        act.g1.uniform_(0.5, 1.5); act.h1.uniform_(-.3, .3); act.g2.uniform_(0.5, 1.5); act.h2.uniform_(-.3, .3); act.w3.mul_(50)
+    blob = act.pack().numpy()
+    Dp = (D + 1) & ~1
+    ow2 = 64 * Dp; osm = ow2 + 4096; ow3 = osm + 384; ob3 = ow3 + 256
+    assert blob.shape == (A, ob3 + 4)
+    obs = torch.rand(64, A, D) * 2 - 1
+    want = act(obs).detach().numpy()
+    lanes = np.arange(64); hh = lanes >> 5
+    for a in range(A):
+        W = blob[a]
+        sm = W[osm:osm + 384].reshape(6, 2, 2, 16)                    # [vector][hh][mo][v]
+        x = obs[:, a, :].numpy()
+        acc1 = np.zeros((2, 2, 16, 64))
+        for mo in range(2):
+            for nt in range(2):
+                acc1[mo, nt] = sm[0][hh, mo].T
+        for s in range(Dp // 2):
+            k = 2 * s + hh
+            for mo in range(2):
+                avec = W[(mo * (Dp // 2) + s) * 64:(mo * (Dp // 2) + s) * 64 + 64]
+                for nt in range(2):
+                    bvec = np.where(k < D, x[32 * nt + (lanes & 31), np.minimum(k, D - 1)], 0.0)
+                    _mfma_32x32x2(avec, bvec, acc1[mo, nt])
+
+        def ln(acc, gi, bi):
+            for nt in range(2):
+                for c in range(32):
+                    cols = [c, c + 32]
+                    vals = acc[:, nt][:, :, cols].reshape(-1)
+                    mean = vals.mean(); rstd = 1 / np.sqrt(((vals - mean) ** 2).mean() + 1e-5)
+                    for h2 in range(2):
+                        for mo in range(2):
+                            acc[mo, nt, :, c + 32 * h2] = np.maximum((acc[mo, nt, :, c + 32 * h2] - mean) * rstd * sm[gi, h2, mo] + sm[bi, h2, mo], 0)
+        ln(acc1, 1, 2)
+        acc2 = np.zeros((2, 2, 16, 64))
+        for mo in range(2):
+            for nt in range(2):
+                acc2[mo, nt] = sm[3][hh, mo].T
+        w2 = W[ow2:ow2 + 4096].reshape(2, 2, 4, 64, 4)
+        for mt in range(2):
+            for v in range(16):
+                for mo in range(2):
+                    for nt in range(2):
+                        _mfma_32x32x2(w2[mo, mt, v >> 2, :, v & 3], acc1[mt, nt, v], acc2[mo, nt])
+        ln(acc2, 4, 5)
+        w3 = W[ow3:ow3 + 256].reshape(2, 2, 16, 4); b3 = W[ob3:ob3 + 4]
+        out = np.zeros((64, 4))
+        for nt in range(2):
+            for c in range(32):
+                o = sum(acc2[mt, nt, v, c + 32 * h2] * w3[h2, mt, v] for h2 in range(2) for mt in range(2) for v in range(16))
+                out[32 * nt + c] = np.tanh(o + b3)
+        np.testing.assert_allclose(out, want[:, a, :], atol=2e-5)
