@@ -8,7 +8,9 @@ Only what the hot path needs lives here:
   spaces.py      Box / Discrete metadata containers (gym is not a dependency)
   sharding.py    one contiguous env range per rank (no collective on the step path)
   instinct/      the reference's scripted opponent, evaluated on device (next row f-2)
-  rollout.py     on-device actor + step loop in one HIP graph (next row f-1); csrc/bsx_actor.hip is its fused actor
+  rollout.py     on-device actor + step loop in one HIP graph (next row f-1); csrc/bsx_actor.hip is its MFMA actor
+  replay.py      device-resident transition ring, mirror of maddpg/buffer.py (next row f-3)
+  render.py      one game's exported state as an RGB image on the host, diagnostic (next row f-4)
 There is no CPU fallback: without the HIP library the env cannot be constructed.
 """
 from . import envs, instinct  # noqa: F401

@@ -133,3 +133,20 @@ def test_two_rank_counter_reduction_over_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert all(f"ok {r}" in outs[r] for r in range(2))
+
+
+def test_render_frame_from_exported_state(tmp_path):
+    """f-4: one game's exported state rasterised on the host (no pygame): shapes, colours, dead plane hollow."""
+    from deep_rl_battlespace_amd import render
+    st = dict(px=np.array([200, 900]), py=np.array([300, 500]), pdir=np.array([0.0, 180.0]), php=np.array([4, 0]),
+              base_xy=np.array([100, 400, 1100, 400]), bhp=np.array([5, 5]),
+              bl_live=np.zeros((2, 12), bool), bl_x=np.zeros((2, 12), int), bl_y=np.zeros((2, 12), int))
+    st["bl_live"][0, 3] = True; st["bl_x"][0, 3] = 400; st["bl_y"][0, 3] = 300
+    img = render.frame_from_state(st, 1)
+    assert img.shape == (800, 1200, 3) and img.dtype == np.uint8
+    assert tuple(img[310, 190]) == render.RED and tuple(img[300, 400]) == render.RED       # plane body (off the heading tick), bullet
+    assert tuple(img[300, 215]) == render.BLACK                                             # heading tick of plane0 points +x
+    assert tuple(img[500, 900]) != render.BLUE and tuple(img[500 - 24, 900]) == render.BLUE  # dead plane: outline only
+    assert tuple(img[400, 1100]) == render.BLUE and tuple(img[400, 100]) == render.RED       # bases
+    render.save_ppm(tmp_path / "f.ppm", img)
+    assert (tmp_path / "f.ppm").stat().st_size == 800 * 1200 * 3 + len(b"P6\n1200 800\n255\n")
