@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--n-agents", type=int, default=1, help="planes per team (1 = configs[1], 4 = configs[2])")
+    ap.add_argument("--continuous", action="store_true", help="continuous [speed, turn, shoot] actions (battle_env.py:418-424) instead of discrete")
     ap.add_argument("--mode", choices=("graph", "eager"), default="graph")
     ap.add_argument("--graph-len", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -133,14 +134,18 @@ def main():
     def measure(n, E, K, W, mode, graph_len):
         """K timed step() calls of E games x n-v-n on this rank; returns (env, seconds, kernel ms per launch, graph len)."""
         A = 2 * n
-        env = sharding.make_shard(E * world, rank, world, n_agents=n, device=dev, seed=1234, auto_reset=True)
+        env = sharding.make_shard(E * world, rank, world, n_agents=n, device=dev, seed=1234, auto_reset=True,
+                                  continuous_actions=args.continuous)
         env.reset()
         G = max(1, min(graph_len, K))
         while K % G:
             G -= 1
         gen = torch.Generator(device=dev)
         gen.manual_seed(1234 + rank)
-        actions = torch.randint(0, 4, (G, E, A), generator=gen, device=dev, dtype=torch.int32)
+        if args.continuous:
+            actions = torch.rand((G, E, A, 3), generator=gen, device=dev, dtype=torch.float32) * 2 - 1
+        else:
+            actions = torch.randint(0, 4, (G, E, A), generator=gen, device=dev, dtype=torch.int32)
         if mode == "graph":
             graph, _ = env.capture_steps(actions)
 
@@ -207,13 +212,13 @@ def main():
             "metric": "agent-steps/sec", "value": round(agent_steps / dt, 1), "unit": "agent-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 6),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64/i16", "data": "synthetic",
-            "config": {"workload": f"{E} games x {n}v{n} per GPU, uniform random discrete actions, fused HIP step(), auto-reset "
+            "config": {"workload": f"{E} games x {n}v{n} per GPU, uniform random {'continuous' if args.continuous else 'discrete'} actions, fused HIP step(), auto-reset "
                                    f"(BASELINE.json configs[{1 if n == 1 else 2}]{' x ' + str(world) + ' shards' if world > 1 else ''})",
                        "envs_per_gpu": E, "n_agents_per_team": n, "agents_per_env": A, "launch": args.mode,
                        "graph_len": G if args.mode == "graph" else None, "parallelism": f"{world} independent env shards, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": f"bsx_step_kernel<{n if n <= 4 else 0},false>", "avg_launch_us": round(kernel_ms * 1e3, 3),
+                         "kernel": f"bsx_step_kernel<{n if n <= 4 else 0},{'true' if args.continuous else 'false'}>", "avg_launch_us": round(kernel_ms * 1e3, 3),
                          "algorithmic_bytes_per_launch": round(bytes_per_launch), "bytes_per_agent_step": round(b_alg(n), 2)},
             "games_finished": int(games[0]), "ties": int(games[1]), "red_wins": int(games[2]), "blue_wins": int(games[3]),
         }

@@ -153,13 +153,16 @@ class PolicyRollout:
     Exploration noise is Gaussian on the score vectors (the reference adds OU noise, utils/noise.py; OU state would
     be one more [E, A, 4] tensor updated in the same graph), then clamp(-1, 1) as maddpg/agent.py:31 does."""
 
-    def __init__(self, env, actor, T, noise_std=0.0, fused=True, seed=0):
+    def __init__(self, env, actor, T, noise_std=0.0, fused=True, seed=0, opponent=None):
         """actor: a StackedActor.  fused=True evaluates it with the hand-written HIP kernel (FusedActor), False with
-        torch ops (the fp32 reference of the same op)."""
+        torch ops (the fp32 reference of the same op).  opponent: an `instinct.Team` that plays its team's planes
+        instead of the actor (the reference's training setup, main.py:119-122: learned red vs scripted blue): its
+        one-hot scores overwrite that team's rows of the score tensor each tick, on device."""
         if env.continuous_actions or env._compat or env.rng != "philox":
             raise ValueError("PolicyRollout needs a batched discrete env with rng='philox'")
         self.env, self.actor, self.T, self.noise_std = env, actor, int(T), float(noise_std)
         self.fused = FusedActor(actor, env.n_agents, seed=seed) if fused else None
+        self.opponent = opponent
         self._seq_base = torch.zeros(1, dtype=torch.int64, device=env.device)
         E, A, D, dev = env.n_envs, env._A, env.obs_size, env.device
         self.obs = torch.empty((T + 1, E, A, D), dtype=torch.float32, device=dev)
@@ -174,6 +177,8 @@ class PolicyRollout:
             # graph arguments are frozen: the noise key is (seed, seq_base + t, row) with seq_base a device word that the
             # graph advances by T once per replay (_body)
             self.fused.forward_into(self.obs[t], self.scores[t], self.noise_std, seq=t, seq_base=self._seq_base)
+            if self.opponent is not None:
+                self.opponent.write_actions(out=self.scores[t], obs=self.obs[t])
             self.env._launch(self.scores[t].data_ptr(), _lib.ACT_LOGITS_F32, False, None,
                              self.obs[t + 1].data_ptr(), self.rew[t].data_ptr(), self._done[t].data_ptr())
             return
@@ -182,6 +187,8 @@ class PolicyRollout:
             if self.noise_std > 0.0:
                 s = (s + self.noise_std * torch.randn_like(s)).clamp_(-1.0, 1.0)
             self.scores[t].copy_(s)
+        if self.opponent is not None:
+            self.opponent.write_actions(out=self.scores[t], obs=self.obs[t])
         self.env._launch(self.scores[t].data_ptr(), _lib.ACT_LOGITS_F32, False, None,
                          self.obs[t + 1].data_ptr(), self.rew[t].data_ptr(), self._done[t].data_ptr())
 

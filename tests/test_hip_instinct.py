@@ -105,3 +105,26 @@ def test_dropin_team_surface():
         obs, rew, done, _ = env.step(a)
         steps += 1
     assert env.env_done and env.winner in ("red", "blue", "tie")
+
+
+def test_rollout_with_learned_red_and_scripted_blue():
+    """The reference's training setup on device (main.py:119-122,179): red = actor, blue = instinct.Team; one HIP graph."""
+    from deep_rl_battlespace_amd import instinct
+    from deep_rl_battlespace_amd.rollout import PolicyRollout, StackedActor
+    E, n, T = 1024, 2, 20
+    env = _env(n_agents=n, n_envs=E, seed=9, auto_reset=True); env.reset()
+    torch.manual_seed(0)
+    actor = StackedActor(2 * n, 3 * n + 2, 4, device="cuda")
+    blue = instinct.Team(env.possible_blue, env.possible_red, env)
+    ro = PolicyRollout(env, actor, T, noise_std=0.3, opponent=blue)
+    ro.start(); ro.capture()
+    for rep in range(6):
+        ro.run()
+    torch.cuda.synchronize()
+    blue_scores = ro.scores[:, :, n:]
+    assert bool(((blue_scores == 1).sum(-1) == 1).all()) and bool(((blue_scores == -1).sum(-1) == 3).all())   # one-hot rows
+    want = np.asarray([[ir.discrete_action(o, n) for o in row] for row in ro.obs[3, :64, n:].cpu().numpy()])
+    assert np.array_equal(blue_scores[3, :64].argmax(-1).cpu().numpy(), want)
+    assert not bool(((ro.scores[:, :, :n].abs() == 1).all(-1)).all())                                             # red rows are the actor's
+    c = env.counters().sum(0)
+    assert c[3] > c[2] and c[0] > 0                               # the scripted team beats a random-weight actor
