@@ -122,7 +122,10 @@ def main():
     red_dev = dev if args.backend == "nccl" else torch.device("cpu")
     if world > 1:                                           # used for the barrier / max-time reduction only
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+            try:
+                dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+            except TypeError:                                   # older torch: no device_id argument
+                dist.init_process_group("nccl")
         else:
             dist.init_process_group("gloo")
 
@@ -137,9 +140,7 @@ def main():
         env = sharding.make_shard(E * world, rank, world, n_agents=n, device=dev, seed=1234, auto_reset=True,
                                   continuous_actions=args.continuous)
         env.reset()
-        G = max(1, min(graph_len, K))
-        while K % G:
-            G -= 1
+        G = max(1, min(graph_len, K))                       # steps per graph replay; a remainder runs as plain calls
         gen = torch.Generator(device=dev)
         gen.manual_seed(1234 + rank)
         if args.continuous:
