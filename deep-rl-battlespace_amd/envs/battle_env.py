@@ -22,6 +22,7 @@ Reference quirks are reproduced, not fixed: observation B
 team receives ``lose_punishment``; headings live in [0, 360] inclusive; a discrete action outside 0..3 means "do not
 move"; the time-limit tie fires on call number 10*max_time + 1; a finished game ignores step() until reset().
 """
+import contextlib
 import ctypes
 import random as _stdlib_random
 import warnings
@@ -150,7 +151,8 @@ class parallel_env:
         self._winner = torch.empty(E, dtype=torch.uint8, device=dev)
         self._u = None
         self._reset_nonce = 0
-        _lib.check(self._lib.bsx_state_init(self._state.data_ptr(), E, n, self._stream()), "bsx_state_init")
+        with self._guard():
+            _lib.check(self._lib.bsx_state_init(self._state.data_ptr(), E, n, self._stream()), "bsx_state_init")
         self._env_done.fill_(1)
         self._winner.zero_()
         self._done.fill_(1)
@@ -170,6 +172,13 @@ class parallel_env:
     # ------------------------------------------------------------------ helpers
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _guard(self):
+        """HIP launches go to the calling thread's current device: make that the env's device for the duration of a call
+        (a no-op context when it already is, which is the normal one-process-per-GPU case)."""
+        if torch.cuda.current_device() == self.device.index:
+            return contextlib.nullcontext()
+        return torch.cuda.device(self.device)
 
     def _draw_spawn(self):
         return draw_spawn(self.n_agents)
@@ -208,11 +217,12 @@ class parallel_env:
             if spawn_t.shape != (E, 4 + 3 * A):
                 raise ValueError(f"spawn must have shape ({E}, {4 + 3 * A}), got {tuple(spawn_t.shape)}")
         self._reset_nonce += 1
-        _lib.check(self._lib.bsx_reset(self._state.data_ptr(), E, self.n_agents,
-                                       mask_t.data_ptr() if mask_t is not None else None,
-                                       spawn_t.data_ptr() if spawn_t is not None else None,
-                                       self.seed, self._reset_nonce, self.env_offset, self._obs.data_ptr(),
-                                       self._stream()), "bsx_reset")
+        with self._guard():
+            _lib.check(self._lib.bsx_reset(self._state.data_ptr(), E, self.n_agents,
+                                           mask_t.data_ptr() if mask_t is not None else None,
+                                           spawn_t.data_ptr() if spawn_t is not None else None,
+                                           self.seed, self._reset_nonce, self.env_offset, self._obs.data_ptr(),
+                                           self._stream()), "bsx_reset")
         if mask_t is None:
             self._env_done.zero_(); self._winner.zero_(); self._done.zero_()
         else:
@@ -316,9 +326,10 @@ class parallel_env:
         """Enqueue one fused step kernel on the current stream (no sync, no allocation: graph-capturable)."""
         flags = (_lib.F_AUTO_RESET if self.auto_reset else 0) | (_lib.F_EMPTY_CALL if empty else 0)
         fn = self._lib.bsx_step_continuous if self.continuous_actions else self._lib.bsx_step_discrete
-        _lib.check(fn(self._state.data_ptr(), self.n_envs, self.n_agents, act_ptr, kind, u_ptr,
-                      obs_ptr, rew_ptr, done_ptr, self._env_done.data_ptr(), self._winner.data_ptr(),
-                      ctypes.byref(self._cfg), flags, self.seed, self.env_offset, self._stream()), "bsx_step")
+        with self._guard():
+            _lib.check(fn(self._state.data_ptr(), self.n_envs, self.n_agents, act_ptr, kind, u_ptr,
+                          obs_ptr, rew_ptr, done_ptr, self._env_done.data_ptr(), self._winner.data_ptr(),
+                          ctypes.byref(self._cfg), flags, self.seed, self.env_offset, self._stream()), "bsx_step")
 
     def capture_steps(self, actions, store=False):
         """Capture T consecutive step() launches into ONE HIP graph (the launch-bound inner loop of a rollout).
@@ -423,8 +434,9 @@ class parallel_env:
 
     # ------------------------------------------------------------------ observe (battle_env.py:202-244)
     def observe(self, agent):
-        _lib.check(self._lib.bsx_observe(self._state.data_ptr(), self.n_envs, self.n_agents, self._obs.data_ptr(),
-                                         self._stream()), "bsx_observe")
+        with self._guard():
+            _lib.check(self._lib.bsx_observe(self._state.data_ptr(), self.n_envs, self.n_agents, self._obs.data_ptr(),
+                                             self._stream()), "bsx_observe")
         i = self._idx[agent]
         if self._compat:
             return self._obs[0, i].cpu().numpy().copy()
@@ -488,8 +500,9 @@ class parallel_env:
             dt, shp = self._EXPORT_SPEC[f]
             out[f] = torch.empty((self.n_envs, *shp(self._A)), dtype=dt, device=self.device)
             setattr(ex, f, out[f].data_ptr())
-        _lib.check(self._lib.bsx_export_state(self._state.data_ptr(), self.n_envs, self.n_agents, ctypes.byref(ex),
-                                              self._stream()), "bsx_export_state")
+        with self._guard():
+            _lib.check(self._lib.bsx_export_state(self._state.data_ptr(), self.n_envs, self.n_agents, ctypes.byref(ex),
+                                                  self._stream()), "bsx_export_state")
         return out
 
     def state_dict(self):
