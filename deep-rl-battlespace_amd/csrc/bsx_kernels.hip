@@ -150,11 +150,12 @@ __device__ inline void clamp_plane(int& x, int& y) {
     if (y - PLANE_HH <= 0) y = PLANE_HH;
     if (y + PLANE_HH >= FIELD_H) y = FIELD_H - PLANE_HH;
 }
-// Plane.rotate (sprites.py:99-103): [0, 360] inclusive
+// Plane.rotate (sprites.py:99-103): [0, 360] inclusive.  The reference's two `while` loops run at most once each for
+// |ang| <= 360 (the discrete turn is 15 degrees, the continuous one at most 35), so they are single selects here.
 __device__ inline double rotate_dir(double d, double ang) {
     d += ang;
-    while (d > 360.0) d -= 360.0;
-    while (d < 0.0) d += 360.0;
+    d = d > 360.0 ? d - 360.0 : d;
+    d = d < 0.0 ? d + 360.0 : d;
     return d;
 }
 // rel_angle (battle_env.py:38-52), p0 = observer, p1 = target
