@@ -459,6 +459,19 @@ class parallel_env:
         """Drop-in: 'none' | 'red' | 'blue' | 'tie'.  Batched: uint8 codes 0..3 in that order."""
         return self._winner_name if self._compat else self._winner
 
+    @property
+    def total_time(self):
+        """Game clock in hours (battle_env.py:175,316): the reference adds 0.1 per tick in binary64; reproduced by the same
+        accumulation on the host from the tick counter.  Drop-in: float; batched: float64 numpy array [E]."""
+        ticks = self.export_state(("tick",))["tick"].cpu().numpy()
+        acc = np.zeros(int(ticks.max()) + 1)
+        t = 0
+        for k in range(1, len(acc)):
+            t += self.time_step
+            acc[k] = t
+        out = acc[ticks]
+        return float(out[0]) if self._compat else out
+
     def counters(self):
         """int32 [E, 4] host array: games finished, ties, red wins, blue wins (battle_env.py:169-170,102-103)."""
         return self.export_state(("counters",))["counters"].cpu().numpy().reshape(self.n_envs, 4)
