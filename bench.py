@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--n-agents", type=int, default=1, help="planes per team (1 = configs[1], 4 = configs[2])")
+    ap.add_argument("--action-mix", choices=("uniform", "forward", "shoot"), default="uniform",
+                    help="uniform = i.i.d. over {0,1,2,3} (the headline); forward = nobody ever shoots (traffic calibration: every "
+                         "byte moved is known); shoot = everybody shoots every tick (stress: ~11 live bullets per agent)")
     ap.add_argument("--continuous", action="store_true", help="continuous [speed, turn, shoot] actions (battle_env.py:418-424) instead of discrete")
     ap.add_argument("--mode", choices=("graph", "eager"), default="graph")
     ap.add_argument("--graph-len", type=int, default=100)
@@ -145,8 +148,10 @@ def main():
         gen.manual_seed(1234 + rank)
         if args.continuous:
             actions = torch.rand((G, E, A, 3), generator=gen, device=dev, dtype=torch.float32) * 2 - 1
-        else:
+        elif args.action_mix == "uniform":
             actions = torch.randint(0, 4, (G, E, A), generator=gen, device=dev, dtype=torch.int32)
+        else:
+            actions = torch.full((G, E, A), 0 if args.action_mix == "forward" else 1, device=dev, dtype=torch.int32)
         if mode == "graph":
             graph, _ = env.capture_steps(actions)
 
@@ -213,7 +218,7 @@ def main():
             "metric": "agent-steps/sec", "value": round(agent_steps / dt, 1), "unit": "agent-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 6),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64/i16", "data": "synthetic",
-            "config": {"workload": f"{E} games x {n}v{n} per GPU, uniform random {'continuous' if args.continuous else 'discrete'} actions, fused HIP step(), auto-reset "
+            "config": {"workload": f"{E} games x {n}v{n} per GPU, {'uniform random' if args.action_mix == 'uniform' else 'all-' + args.action_mix} {'continuous' if args.continuous else 'discrete'} actions, fused HIP step(), auto-reset "
                                    f"(BASELINE.json configs[{1 if n == 1 else 2}]{' x ' + str(world) + ' shards' if world > 1 else ''})",
                        "envs_per_gpu": E, "n_agents_per_team": n, "agents_per_env": A, "launch": args.mode,
                        "graph_len": G if args.mode == "graph" else None, "parallelism": f"{world} independent env shards, no collective"},

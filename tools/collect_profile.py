@@ -46,8 +46,8 @@ if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
     tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
     tj[f"E{E}_n{n}"] = {"hbm_bytes_per_launch": int((2 * fetch_kib + write_kib) * 1024), "fetch_size_kib_raw": fetch_kib,
                        "write_size_kib_raw": write_kib, "series": tag,
-                       "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes; KiB units; read side doubled per "
-                               "MI355X_MICROARCH.md (gfx950 FETCH_SIZE = 1/2 of a 16 B/lane coalesced stream); mixed 16-B and 4-B "
-                               "accesses here, so the absolute read figure is uncalibrated (raw values kept alongside)"}
+                       "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes, KiB units; read side x2: calibrated on "
+                               "this kernel with a known-bytes workload (profiles/r01_traffic_calibration.json: true/counter = "
+                               "1.993 for FETCH_SIZE, 1.001 for WRITE_SIZE)"}
     json.dump(tj, open(tpath, "w"), indent=1)
 print(json.dumps(summary, indent=1)[:1500])
