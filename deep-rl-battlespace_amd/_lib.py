@@ -5,7 +5,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libbattlespace_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 BULLET_SLOTS = 12
 MAX_N = 16
 F_AUTO_RESET = 1
@@ -22,6 +22,12 @@ class BsxRewards(ctypes.Structure):
     _fields_ = [("hit_base_reward", ctypes.c_double), ("hit_plane_reward", ctypes.c_double),
                 ("miss_punishment", ctypes.c_double), ("die_punishment", ctypes.c_double),
                 ("lose_punishment", ctypes.c_double)]
+
+
+class BsxActorNoise(ctypes.Structure):
+    _fields_ = [("gaussian_std", ctypes.c_float), ("ou_scale", ctypes.c_float), ("ou_theta", ctypes.c_float),
+                ("ou_sigma", ctypes.c_float), ("ou_mu", ctypes.c_float), ("ou_state", ctypes.c_void_p),
+                ("env_done", ctypes.c_void_p)]
 
 
 EXPORT_FIELDS = ("px", "py", "pdir", "php", "palive", "base_xy", "bhp", "tick", "env_done", "winner",
@@ -48,7 +54,8 @@ SIGNATURES = {
     "bsx_instinct_discrete": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     "bsx_instinct_continuous": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_uint64, c_uint64, c_void_p, c_void_p]),
     "bsx_actor_blob_floats": (c_int, [c_int, ctypes.POINTER(c_int)]),
-    "bsx_actor_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, ctypes.c_float, c_uint64, c_uint64, c_void_p, c_void_p]),
+    "bsx_actor_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, ctypes.POINTER(BsxActorNoise), c_uint64, c_uint64,
+                                  c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -61,7 +61,7 @@ __device__ inline uint4 philox4x32_10(uint4 ctr, uint2 key) {
 
 struct ActorArgs {
     const float* weights; const float* obs; float* scores;
-    int64_t E; int A; int D; float noise_std; uint64_t seed; uint64_t seq; const uint64_t* seq_base;
+    int64_t E; int A; int D; BsxActorNoise nz; uint64_t seed; uint64_t seq; const uint64_t* seq_base;
 };
 
 // LayerNorm over the 64 neurons of each row + ReLU, in place on the accumulator tiles acc[mo][nt] (torch semantics:
@@ -187,8 +187,8 @@ __global__ __launch_bounds__(TPB) void bsx_actor_kernel(const ActorArgs p) {
     const int64_t e = row0 + 32 * hh + c;
     const size_t row = size_t(e < p.E ? e : p.E - 1) * p.A + a;
 
-    // ---- exploration noise + clamp (maddpg/agent.py:30-31), Gaussian via Philox + Box-Muller, keyed by (seed, seq, row)
-    if (p.noise_std > 0.f) {
+    // ---- exploration noise + clamp (maddpg/agent.py:30-31): four normals via Philox + Box-Muller, keyed by (seed, seq, row)
+    if (p.nz.gaussian_std > 0.f || p.nz.ou_scale > 0.f) {
         const uint64_t seq = p.seq + (p.seq_base ? *p.seq_base : 0ull);   // seq_base: device word, so graph replays re-key
         const uint4 r = philox4x32_10(make_uint4(uint32_t(row), uint32_t(uint64_t(row) >> 32), uint32_t(seq), uint32_t(seq >> 32)),
                                       make_uint2(uint32_t(p.seed), uint32_t(p.seed >> 32) ^ 0xA5A5A5A5u));
@@ -198,10 +198,26 @@ __global__ __launch_bounds__(TPB) void bsx_actor_kernel(const ActorArgs p) {
         float s0, c0, s1, c1;
         __sincosf(6.2831853071795864f * u1, &s0, &c0);
         __sincosf(6.2831853071795864f * u3, &s1, &c1);
-        r4.x = fminf(fmaxf(fmaf(p.noise_std, m0 * c0, r4.x), -1.f), 1.f);
-        r4.y = fminf(fmaxf(fmaf(p.noise_std, m0 * s0, r4.y), -1.f), 1.f);
-        r4.z = fminf(fmaxf(fmaf(p.noise_std, m1 * c1, r4.z), -1.f), 1.f);
-        r4.w = fminf(fmaxf(fmaf(p.noise_std, m1 * s1, r4.w), -1.f), 1.f);
+        float4 z = make_float4(m0 * c0, m0 * s0, m1 * c1, m1 * s1);
+        if (p.nz.ou_scale > 0.f) {
+            // Ornstein-Uhlenbeck (utils/noise.py:17-21): x += theta*(mu - x) + sigma*N(0,1); a finished game restarts from mu
+            float4* xs = reinterpret_cast<float4*>(p.nz.ou_state) + row;
+            float4 x = *xs;
+            if (p.nz.env_done && p.nz.env_done[e < p.E ? e : p.E - 1]) x = make_float4(p.nz.ou_mu, p.nz.ou_mu, p.nz.ou_mu, p.nz.ou_mu);
+            x.x += p.nz.ou_theta * (p.nz.ou_mu - x.x) + p.nz.ou_sigma * z.x;
+            x.y += p.nz.ou_theta * (p.nz.ou_mu - x.y) + p.nz.ou_sigma * z.y;
+            x.z += p.nz.ou_theta * (p.nz.ou_mu - x.z) + p.nz.ou_sigma * z.z;
+            x.w += p.nz.ou_theta * (p.nz.ou_mu - x.w) + p.nz.ou_sigma * z.w;
+            if (e < p.E) *xs = x;
+            r4.x = fmaf(p.nz.ou_scale, x.x, r4.x); r4.y = fmaf(p.nz.ou_scale, x.y, r4.y);
+            r4.z = fmaf(p.nz.ou_scale, x.z, r4.z); r4.w = fmaf(p.nz.ou_scale, x.w, r4.w);
+        }
+        if (p.nz.gaussian_std > 0.f) {
+            r4.x = fmaf(p.nz.gaussian_std, z.x, r4.x); r4.y = fmaf(p.nz.gaussian_std, z.y, r4.y);
+            r4.z = fmaf(p.nz.gaussian_std, z.z, r4.z); r4.w = fmaf(p.nz.gaussian_std, z.w, r4.w);
+        }
+        r4.x = fminf(fmaxf(r4.x, -1.f), 1.f); r4.y = fminf(fmaxf(r4.y, -1.f), 1.f);
+        r4.z = fminf(fmaxf(r4.z, -1.f), 1.f); r4.w = fminf(fmaxf(r4.w, -1.f), 1.f);
     }
     if (e < p.E) reinterpret_cast<float4*>(p.scores)[row] = r4;
 }
@@ -218,12 +234,15 @@ int bsx_actor_blob_floats(int obs_len, int* floats_per_agent) {
     return 0;
 }
 
-int bsx_actor_forward(const float* weights, const float* obs, float* scores, int64_t E, int n, float noise_std,
+int bsx_actor_forward(const float* weights, const float* obs, float* scores, int64_t E, int n, const BsxActorNoise* noise,
                       uint64_t seed, uint64_t seq, const uint64_t* seq_base, void* stream) {
     if (!weights || !obs || !scores || E <= 0 || n < 1 || n > BSX_MAX_N) return BSX_E_ARG;
     if (!aligned(weights, 16) || !aligned(scores, 16) || !aligned(obs, 4)) return BSX_E_ALIGN;
+    BsxActorNoise nz = {0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr};
+    if (noise) nz = *noise;
+    if (nz.ou_scale > 0.f && (!nz.ou_state || !aligned(nz.ou_state, 16))) return nz.ou_state ? BSX_E_ALIGN : BSX_E_ARG;
     const int A = 2 * n, D = 3 * n + 2;
-    ActorArgs a{weights, obs, scores, E, A, D, noise_std, seed, seq, seq_base};
+    ActorArgs a{weights, obs, scores, E, A, D, nz, seed, seq, seq_base};
     const int rows_per_block = (TPB / 64) * ROWS_PER_WAVE;
     const dim3 grid(unsigned((E + rows_per_block - 1) / rows_per_block), unsigned(A)), block(TPB);
     hipLaunchKernelGGL(bsx_actor_kernel, grid, block, 0, static_cast<hipStream_t>(stream), a);

@@ -123,15 +123,29 @@ class FusedActor:
     def refresh(self):
         self.actor.pack(out=self.weights)
 
-    def forward_into(self, obs, scores, noise_std=0.0, seq=None, seq_base=None):
+    def forward_into(self, obs, scores, noise_std=0.0, seq=None, seq_base=None, ou=None):
         """obs f32 [E, A, D] (contiguous) -> scores f32 [E, A, 4] (contiguous, 16-byte aligned), on the current stream.
+        noise_std: Gaussian exploration noise.  ou: optional dict(scale, state[, theta, sigma, mu, env_done]) for the
+        reference's Ornstein-Uhlenbeck noise (utils/noise.py): `state` is a float32 [E, A, 4] tensor updated in place,
+        `env_done` a uint8 [E] tensor whose set rows restart the process.
         seq_base: optional int64 device tensor (1 element) added to `seq` in-kernel (for captured graphs)."""
         E = obs.shape[0]
         if seq is None:
             self.seq += 1
             seq = self.seq
+        nz = None
+        if noise_std > 0.0 or ou is not None:
+            nz = _lib.BsxActorNoise(float(noise_std), 0.0, 0.15, 0.2, 0.0, None, None)
+            if ou is not None:
+                st = ou["state"]
+                if st.dtype != torch.float32 or tuple(st.shape) != (E, 2 * self.n, 4) or not st.is_contiguous():
+                    raise ValueError("ou['state'] must be a contiguous float32 [E, A, 4] tensor")
+                nz.ou_scale, nz.ou_theta = float(ou["scale"]), float(ou.get("theta", 0.15))
+                nz.ou_sigma, nz.ou_mu = float(ou.get("sigma", 0.2)), float(ou.get("mu", 0.0))
+                nz.ou_state = st.data_ptr()
+                nz.env_done = ou["env_done"].data_ptr() if ou.get("env_done") is not None else None
         _lib.check(self._lib.bsx_actor_forward(self.weights.data_ptr(), obs.data_ptr(), scores.data_ptr(), E, self.n,
-                                               float(noise_std), self.seed, int(seq),
+                                               _lib.ctypes.byref(nz) if nz is not None else None, self.seed, int(seq),
                                                seq_base.data_ptr() if seq_base is not None else None,
                                                torch.cuda.current_stream(obs.device).cuda_stream), "bsx_actor_forward")
         return scores
@@ -150,10 +164,11 @@ class PolicyRollout:
         ro.obs[t], ro.scores[t], ro.rew[t], ro.done[t], ro.obs[t+1]   # transition t, buffers in HBM
 
     The env must be batched, discrete, rng='philox'; auto_reset is recommended (finished games re-spawn in place).
-    Exploration noise is Gaussian on the score vectors (the reference adds OU noise, utils/noise.py; OU state would
-    be one more [E, A, 4] tensor updated in the same graph), then clamp(-1, 1) as maddpg/agent.py:31 does."""
+    Exploration noise on the score vectors is Gaussian (noise_std) and/or the reference's Ornstein-Uhlenbeck process
+    (ou_scale = main.py's curr_noise; utils/noise.py), whose state is one more [E, A, 4] tensor updated inside the actor
+    kernel and restarted per game; then clamp(-1, 1) as maddpg/agent.py:31 does."""
 
-    def __init__(self, env, actor, T, noise_std=0.0, fused=True, seed=0, opponent=None):
+    def __init__(self, env, actor, T, noise_std=0.0, fused=True, seed=0, opponent=None, ou_scale=0.0):
         """actor: a StackedActor.  fused=True evaluates it with the hand-written HIP kernel (FusedActor), False with
         torch ops (the fp32 reference of the same op).  opponent: an `instinct.Team` that plays its team's planes
         instead of the actor (the reference's training setup, main.py:119-122: learned red vs scripted blue): its
@@ -163,6 +178,14 @@ class PolicyRollout:
         self.env, self.actor, self.T, self.noise_std = env, actor, int(T), float(noise_std)
         self.fused = FusedActor(actor, env.n_agents, seed=seed) if fused else None
         self.opponent = opponent
+        # ou_scale > 0: the reference's Ornstein-Uhlenbeck exploration noise (utils/noise.py; main.py:151-155 scales it per
+        # game and restarts it at every game start) -- fused path only; the process state is one more [E, A, 4] tensor
+        self.ou = None
+        if ou_scale > 0.0:
+            if not fused:
+                raise ValueError("ou_scale needs the fused actor")
+            self.ou = dict(scale=float(ou_scale), env_done=env._env_done,
+                           state=torch.zeros((env.n_envs, env._A, 4), dtype=torch.float32, device=env.device))
         self._seq_base = torch.zeros(1, dtype=torch.int64, device=env.device)
         E, A, D, dev = env.n_envs, env._A, env.obs_size, env.device
         self.obs = torch.empty((T + 1, E, A, D), dtype=torch.float32, device=dev)
@@ -176,7 +199,7 @@ class PolicyRollout:
         if self.fused is not None:
             # graph arguments are frozen: the noise key is (seed, seq_base + t, row) with seq_base a device word that the
             # graph advances by T once per replay (_body)
-            self.fused.forward_into(self.obs[t], self.scores[t], self.noise_std, seq=t, seq_base=self._seq_base)
+            self.fused.forward_into(self.obs[t], self.scores[t], self.noise_std, seq=t, seq_base=self._seq_base, ou=self.ou)
             if self.opponent is not None:
                 self.opponent.write_actions(out=self.scores[t], obs=self.obs[t])
             self.env._launch(self.scores[t].data_ptr(), _lib.ACT_LOGITS_F32, False, None,

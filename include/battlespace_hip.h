@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define BSX_ABI_VERSION 1
+#define BSX_ABI_VERSION 2
 #define BSX_BULLET_SLOTS 12 /* a bullet is removed at the latest on its 12th update (sprites.py:334-337: 12*45 >= 500) */
 #define BSX_MAX_N 16
 
@@ -123,11 +123,20 @@ int bsx_export_state(const void* state, int64_t E, int n, const BsxExport* out, 
  *              W3P[hh 2][mt 2][v 16][4] = W3[nid(mt, v, hh)][0..3];  b3[4]
  *            (W[k][j] multiplies input k into output j, i.e. the transpose of torch's Linear.weight.)
  *   obs      float32[E*A*D] (what bsx_step_* / bsx_reset wrote);  scores float32[E*A*4], 16-byte aligned: feed it to
- *            bsx_step_discrete with BSX_ACT_LOGITS_F32.  Noise is Philox-keyed by (seed, seq + *seq_base, row): pass a new
- *            seq per call, or -- inside a captured HIP graph, whose arguments are frozen -- a device word seq_base (nullable)
- *            that the graph itself advances once per replay. */
+ *            bsx_step_discrete with BSX_ACT_LOGITS_F32.
+ *   noise    nullable.  Exploration noise added to the tanh outputs, then clamp(-1, 1) (maddpg/agent.py:30-31): Gaussian
+ *            and/or the reference's Ornstein-Uhlenbeck process (utils/noise.py:4-21).  Normal draws are Philox-keyed by
+ *            (seed, seq + *seq_base, row): pass a new seq per call, or -- inside a captured HIP graph, whose arguments are
+ *            frozen -- a device word seq_base (nullable) that the graph itself advances once per replay. */
+typedef struct BsxActorNoise {
+    float gaussian_std;       /* > 0: scores += N(0, gaussian_std) */
+    float ou_scale;           /* > 0: x += ou_theta*(ou_mu - x) + ou_sigma*N(0,1);  scores += ou_scale * x   (utils/noise.py:17-21) */
+    float ou_theta, ou_sigma, ou_mu;   /* reference defaults 0.15, 0.2, 0 */
+    float* ou_state;          /* float32[E*A*4] process state x, required when ou_scale > 0 */
+    const uint8_t* env_done;  /* nullable uint8[E]: rows of finished games restart from ou_mu (main.py:155 reset_noise per game) */
+} BsxActorNoise;
 int bsx_actor_blob_floats(int obs_len, int* floats_per_agent);
-int bsx_actor_forward(const float* weights, const float* obs, float* scores, int64_t E, int n, float noise_std,
+int bsx_actor_forward(const float* weights, const float* obs, float* scores, int64_t E, int n, const BsxActorNoise* noise,
                       uint64_t seed, uint64_t seq, const uint64_t* seq_base, void* stream);
 
 /* ---- the reference's scripted opponent on device (instinct/agent.py:10-62, instinct/team.py:3-15): a pure function of
