@@ -236,7 +236,7 @@ int bsx_actor_blob_floats(int obs_len, int* floats_per_agent) {
 
 int bsx_actor_forward(const float* weights, const float* obs, float* scores, int64_t E, int n, const BsxActorNoise* noise,
                       uint64_t seed, uint64_t seq, const uint64_t* seq_base, void* stream) {
-    if (!weights || !obs || !scores || E <= 0 || n < 1 || n > BSX_MAX_N) return BSX_E_ARG;
+    if (!weights || !obs || !scores || E <= 0 || E > BSX_MAX_E || n < 1 || n > BSX_MAX_N) return BSX_E_ARG;
     if (!aligned(weights, 16) || !aligned(scores, 16) || !aligned(obs, 4)) return BSX_E_ALIGN;
     BsxActorNoise nz = {0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr};
     if (noise) nz = *noise;

@@ -863,7 +863,7 @@ template <bool CONT>
 int launch_step(void* state, int64_t E, int n, const void* actions, int action_kind, const double* u, float* obs,
                 float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner, const BsxRewards* cfg, uint32_t flags,
                 uint64_t seed, int64_t env_offset, void* stream) {
-    if (!state || E <= 0 || n < 1 || n > BSX_MAX_N || !obs || !rew || !done || !cfg) return BSX_E_ARG;
+    if (!state || E <= 0 || E > BSX_MAX_E || n < 1 || n > BSX_MAX_N || !obs || !rew || !done || !cfg) return BSX_E_ARG;
     if (!actions && !(flags & BSX_F_EMPTY_CALL)) return BSX_E_ARG;
     if (!aligned(state, 256) || !aligned(obs, 4) || !aligned(rew, 4) || (u && !aligned(u, 8))) return BSX_E_ALIGN;
     if (!CONT && action_kind == BSX_ACT_LOGITS_F32 && !aligned(actions, 16)) return BSX_E_ALIGN;
@@ -906,13 +906,13 @@ int bsx_tie_tick(int n) {
 }
 
 int bsx_state_bytes(int64_t E, int n, size_t* bytes) {
-    if (E <= 0 || n < 1 || n > BSX_MAX_N || !bytes) return BSX_E_ARG;
+    if (E <= 0 || E > BSX_MAX_E || n < 1 || n > BSX_MAX_N || !bytes) return BSX_E_ARG;
     *bytes = make_layout(E, n).total;
     return 0;
 }
 
 int bsx_state_init(void* state, int64_t E, int n, void* stream) {
-    if (!state || E <= 0 || n < 1 || n > BSX_MAX_N) return BSX_E_ARG;
+    if (!state || E <= 0 || E > BSX_MAX_E || n < 1 || n > BSX_MAX_N) return BSX_E_ARG;
     if (!aligned(state, 256)) return BSX_E_ALIGN;
     const Layout L = make_layout(E, n);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -936,7 +936,7 @@ int bsx_state_init(void* state, int64_t E, int n, void* stream) {
 
 int bsx_reset(void* state, int64_t E, int n, const uint8_t* reset_mask, const int32_t* spawn, uint64_t seed,
               uint64_t nonce, int64_t env_offset, float* obs, void* stream) {
-    if (!state || E <= 0 || n < 1 || n > BSX_MAX_N) return BSX_E_ARG;
+    if (!state || E <= 0 || E > BSX_MAX_E || n < 1 || n > BSX_MAX_N) return BSX_E_ARG;
     if (!aligned(state, 256) || (spawn && !aligned(spawn, 4)) || (obs && !aligned(obs, 4))) return BSX_E_ALIGN;
     ResetArgs a{state_ptrs(state, E, n), E, n, reset_mask, spawn, seed, nonce, env_offset, obs, 0};
     hipLaunchKernelGGL(bsx_reset_kernel, dim3(grid_for(E, n)), dim3(TPB), 0, static_cast<hipStream_t>(stream), a);
@@ -958,7 +958,7 @@ int bsx_step_continuous(void* state, int64_t E, int n, const void* actions, int 
 }
 
 int bsx_observe(void* state, int64_t E, int n, float* obs, void* stream) {
-    if (!state || E <= 0 || n < 1 || n > BSX_MAX_N || !obs) return BSX_E_ARG;
+    if (!state || E <= 0 || E > BSX_MAX_E || n < 1 || n > BSX_MAX_N || !obs) return BSX_E_ARG;
     if (!aligned(state, 256) || !aligned(obs, 4)) return BSX_E_ALIGN;
     // same kernel as reset with nothing selected: it only stages the poses and writes the rows (battle_env.py:202-244)
     ResetArgs a{state_ptrs(state, E, n), E, n, nullptr, nullptr, 0, 0, 0, obs, 1};
@@ -967,7 +967,7 @@ int bsx_observe(void* state, int64_t E, int n, float* obs, void* stream) {
 }
 
 int bsx_export_state(const void* state, int64_t E, int n, const BsxExport* out, void* stream) {
-    if (!state || E <= 0 || n < 1 || n > BSX_MAX_N || !out) return BSX_E_ARG;
+    if (!state || E <= 0 || E > BSX_MAX_E || n < 1 || n > BSX_MAX_N || !out) return BSX_E_ARG;
     if (!aligned(state, 256)) return BSX_E_ALIGN;
     ExportArgs a{state_ptrs(const_cast<void*>(state), E, n), E, n, *out, bsx_tie_tick(n)};
     const size_t EA = size_t(E) * 2 * n;
@@ -977,7 +977,7 @@ int bsx_export_state(const void* state, int64_t E, int n, const BsxExport* out, 
 }
 
 int bsx_instinct_discrete(const float* obs, void* actions, int out_kind, int64_t E, int n, int team, void* stream) {
-    if (!obs || !actions || E <= 0 || n < 1 || n > BSX_MAX_N || team < 0 || team > 2) return BSX_E_ARG;
+    if (!obs || !actions || E <= 0 || E > BSX_MAX_E || n < 1 || n > BSX_MAX_N || team < 0 || team > 2) return BSX_E_ARG;
     if (out_kind != BSX_ACT_I32 && out_kind != BSX_ACT_LOGITS_F32) return BSX_E_ARG;
     if (!aligned(obs, 4) || !aligned(actions, out_kind == BSX_ACT_I32 ? 4 : 16)) return BSX_E_ALIGN;
     InstinctArgs a{obs, actions, nullptr, E, n, team, out_kind, 0, 0, 0, nullptr};
@@ -988,7 +988,7 @@ int bsx_instinct_discrete(const float* obs, void* actions, int out_kind, int64_t
 
 int bsx_instinct_continuous(const float* obs, double* actions, const double* rnd, int64_t E, int n, int team,
                             uint64_t seed, uint64_t seq, const uint64_t* seq_base, void* stream) {
-    if (!obs || !actions || E <= 0 || n < 1 || n > BSX_MAX_N || team < 0 || team > 2) return BSX_E_ARG;
+    if (!obs || !actions || E <= 0 || E > BSX_MAX_E || n < 1 || n > BSX_MAX_N || team < 0 || team > 2) return BSX_E_ARG;
     if (!aligned(obs, 4) || !aligned(actions, 8) || (rnd && !aligned(rnd, 8))) return BSX_E_ALIGN;
     InstinctArgs a{obs, actions, rnd, E, n, team, 0, 1, seed, seq, seq_base};
     const size_t EA = size_t(E) * 2 * n;

@@ -27,6 +27,7 @@ extern "C" {
 #define BSX_ABI_VERSION 2
 #define BSX_BULLET_SLOTS 12 /* a bullet is removed at the latest on its 12th update (sprites.py:334-337: 12*45 >= 500) */
 #define BSX_MAX_N 16
+#define BSX_MAX_E (INT64_C(1) << 30)   /* games per call: keeps every grid below 2^31 workgroups; 2^30 games of 1v1 is ~0.8 TB of state */
 
 #define BSX_E_ARG (-1)     /* null pointer / bad size / unsupported n */
 #define BSX_E_ALIGN (-2)   /* a pointer is not aligned as documented */

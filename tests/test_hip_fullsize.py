@@ -97,6 +97,31 @@ def test_deterministic_and_shard_invariant():
         assert torch.equal(outs[0][1], other[1])
 
 
+def test_largest_batch_offsets_past_4GB_play_the_same_games():
+    """Maximum sizes: 16 M + 5 games of 1v1 in ONE batch (12 GB of state; bullet-step rows start beyond 4 GB, the grid is
+    524 289 wavefronts, the last one ragged).  The in-kernel generator is keyed by the global env index, so the last 4 096
+    games of the big batch must be, bit for bit, the games a 4 096-game shard with that env_offset plays."""
+    E, n, T, q = (1 << 24) + 5, 1, 70, 4096
+    big = _env(n_agents=n, n_envs=E, seed=21, auto_reset=True)
+    small = _env(n_agents=n, n_envs=q, seed=21, auto_reset=True, env_offset=E - q)
+    ob = big.reset(); os_ = small.reset()
+    for a in big.possible_agents:
+        assert torch.equal(ob[a][E - q:], os_[a])
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    act = torch.empty((E, 2), dtype=torch.int32, device="cuda")
+    for t in range(T):
+        tail = torch.randint(0, 4, (q, 2), generator=g, device="cuda", dtype=torch.int32)
+        tail = torch.where(torch.rand((q, 2), generator=g, device="cuda") < 0.6, torch.ones_like(tail), tail)
+        act.fill_(1); act[E - q:] = tail                       # everyone else just shoots
+        o1, r1, d1 = big.step_batch(act)
+        o2, r2, d2 = small.step_batch(tail)
+        assert torch.equal(o1[E - q:], o2) and torch.equal(r1[E - q:], r2) and torch.equal(d1[E - q:], d2), f"step {t}"
+    s1 = big.export_state(); s2 = small.export_state()
+    for f in ("px", "py", "pdir", "php", "bhp", "tick", "bl_live", "bl_x", "bl_y", "bl_dir", "counters"):
+        assert torch.equal(s1[f][E - q:], s2[f]), f
+    assert int(s1["bl_live"].sum()) > E // 8                      # bullets in flight all over the batch, not only in the tail
+
+
 def test_state_invariants_at_full_size():
     """Properties that hold for any number of games: poses inside the clamp box, headings in [0, 360], hit points in
     range, live bullets inside the field and younger than 12 updates, observation ranges, done/alive consistency."""

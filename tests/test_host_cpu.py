@@ -36,6 +36,8 @@ def test_state_bytes_and_tie_tick_need_no_gpu():
     per_agent = sz.value / (65536 * 2)
     assert 300 < per_agent < 420                      # 16 plane + 48 bullet xy + 192 displacement + 96 heading + env share
     assert lib.bsx_state_bytes(0, 1, ctypes.byref(sz)) == -1 and lib.bsx_state_bytes(8, 17, ctypes.byref(sz)) == -1
+    assert lib.bsx_state_bytes(1 << 30, 1, ctypes.byref(sz)) == 0 and sz.value > (1 << 30) * 600     # BSX_MAX_E: no overflow
+    assert lib.bsx_state_bytes((1 << 30) + 1, 1, ctypes.byref(sz)) == -1
     assert [lib.bsx_tie_tick(n) for n in (1, 2, 3, 4, 5, 8)] == [121, 141, 161, 181, 200, 260]
 
 
