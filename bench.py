@@ -102,7 +102,7 @@ def main():
                     help="uniform = i.i.d. over {0,1,2,3} (the headline); forward = nobody ever shoots (traffic calibration: every "
                          "byte moved is known); shoot = everybody shoots every tick (stress: ~11 live bullets per agent)")
     ap.add_argument("--continuous", action="store_true", help="continuous [speed, turn, shoot] actions (battle_env.py:418-424) instead of discrete")
-    ap.add_argument("--mode", choices=("graph", "eager"), default="graph")
+    ap.add_argument("--mode", choices=("graph", "eager", "many"), default="graph")
     ap.add_argument("--graph-len", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the two extra (non-headline) measurements")
@@ -160,6 +160,19 @@ def main():
                     graph.replay()
                 for t in range(steps % G):
                     env.step_batch(actions[t])
+        elif mode == "many":
+            # K ticks as K/G multi-tick launches (bsx_step_many_*): every tick's obs / rew / done go to their own slice of
+            # [G, E, A, ...] buffers, nothing is skipped or overwritten within a launch
+            D = env.obs_size
+            outs = (torch.empty((G, E, A, D), dtype=torch.float32, device=dev), torch.empty((G, E, A), dtype=torch.float32, device=dev),
+                    torch.empty((G, E, A), dtype=torch.uint8, device=dev))
+
+            def run(steps):
+                for _ in range(steps // G):
+                    env.step_many(actions, store=True, out=outs)
+                r = steps % G
+                if r:
+                    env.step_many(actions[:r], store=True, out=tuple(o[:r] for o in outs))
         else:
             def run(steps):
                 for t in range(steps):

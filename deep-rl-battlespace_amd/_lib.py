@@ -5,9 +5,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libbattlespace_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 BULLET_SLOTS = 12
 MAX_N = 16
+MAX_T = 65535
 F_AUTO_RESET = 1
 F_EMPTY_CALL = 2
 ACT_I32, ACT_LOGITS_F32 = 0, 1
@@ -48,6 +49,10 @@ SIGNATURES = {
                                   c_void_p, c_void_p, ctypes.POINTER(BsxRewards), c_uint32, c_uint64, c_int64, c_void_p]),
     "bsx_step_continuous": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, ctypes.POINTER(BsxRewards), c_uint32, c_uint64, c_int64, c_void_p]),
+    "bsx_step_many_discrete": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, ctypes.POINTER(BsxRewards), c_uint32, c_int, c_uint64, c_int64, c_void_p]),
+    "bsx_step_many_continuous": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, ctypes.POINTER(BsxRewards), c_uint32, c_int, c_uint64, c_int64, c_void_p]),
     "bsx_observe": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "bsx_export_state": (c_int, [c_void_p, c_int64, c_int, ctypes.POINTER(BsxExport), c_void_p]),
     "bsx_tie_tick": (c_int, [c_int]),

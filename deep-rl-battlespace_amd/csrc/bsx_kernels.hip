@@ -205,6 +205,8 @@ struct StepArgs {
     float* obs; float* rew; uint8_t* done; uint8_t* env_done; uint8_t* winner;
     BsxRewards cfg;
     uint32_t flags; uint64_t seed; int64_t env_offset; int tie_tick;
+    // multi-tick launches (bsx_step_many_*): T ticks, per-tick strides of the action / output arrays (0 = same array every tick)
+    int T; int64_t act_tb /* bytes */, u_ts, obs_ts, rew_ts, done_ts /* elements */;
 };
 
 // Observation row for one agent from the LDS-staged block (battle_env.py:202-244).
@@ -287,7 +289,11 @@ __device__ inline void obs_pair(int x, int y, double dir, int tx, int ty, float&
     oa = obs_angle(x, y, dir, tx, ty);
 }
 
-template <int N, bool CONT>
+// MULTI: the wave walks its games through p.T consecutive calls in one launch.  Games never leave their wave, so the
+// only ordering needed between ticks is this wave's own stores before its own loads (a workgroup-scope fence = a wait,
+// no cache maintenance: same CU, same L1); the state stays in the L2 instead of crossing a kernel boundary (write-back +
+// invalidate + a cold first round trip) every tick.
+template <int N, bool CONT, bool MULTI>
 __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     STAMP(8);                                            // diagnostic builds: kernel entry, before any kernarg load
     const int n = (N > 0) ? N : p.n;
@@ -315,6 +321,12 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     __shared__ volatile int s_bhit[SPB];                 // base hits, index gl + shooter team
     __shared__ __attribute__((aligned(16))) float s_obs[SPB * ((N > 0) ? 3 * N + 2 : 3 * BSX_MAX_N + 2)];   // observation rows of the wave
 
+    for (int tk = 0; tk < (MULTI ? p.T : 1); ++tk) {
+    const void* const actions_t = MULTI ? static_cast<const void*>(static_cast<const char*>(p.actions) + int64_t(tk) * p.act_tb) : p.actions;
+    const double* const u_t = (MULTI && p.u) ? p.u + int64_t(tk) * p.u_ts : p.u;
+    float* const obs_t = MULTI ? p.obs + int64_t(tk) * p.obs_ts : p.obs;
+    float* const rew_t = MULTI ? p.rew + int64_t(tk) * p.rew_ts : p.rew;
+    uint8_t* const done_t = MULTI ? p.done + int64_t(tk) * p.done_ts : p.done;
     STAMP(0);
     // ================= T0: every load that depends on no other load, issued back to back, raw 16-byte words ========
     // (the kernel is latency-bound at 65 536 games -- 2 waves per SIMD -- so memory-level parallelism is what pays)
@@ -323,11 +335,11 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     const uint4 prw = reinterpret_cast<const uint4*>(p.st.plane)[g];
     int act = -1;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, uu_in = 0.0;
-    if (p.actions) {                                     // uniform branch
+    if (actions_t) {                                     // uniform branch
         if (!CONT) {
-            if (p.action_kind == BSX_ACT_I32) act = static_cast<const int32_t*>(p.actions)[g];
+            if (p.action_kind == BSX_ACT_I32) act = static_cast<const int32_t*>(actions_t)[g];
             else {   // np.argmax: first maximum; a NaN compares as the maximum
-                const float4 lg = static_cast<const float4*>(p.actions)[g];
+                const float4 lg = static_cast<const float4*>(actions_t)[g];
                 const float v[4] = {lg.x, lg.y, lg.z, lg.w};
                 act = 0;
 #pragma unroll
@@ -335,14 +347,14 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
                     if (!(v[act] != v[act]) && (v[i] > v[act] || v[i] != v[i])) act = i;
             }
         } else if (p.action_kind == BSX_ACT_F32) {
-            const float* ap = static_cast<const float*>(p.actions) + 3 * g;
+            const float* ap = static_cast<const float*>(actions_t) + 3 * g;
             a0 = double(ap[0]); a1 = double(ap[1]); a2 = double(ap[2]);
         } else {
-            const double* ap = static_cast<const double*>(p.actions) + 3 * g;
+            const double* ap = static_cast<const double*>(actions_t) + 3 * g;
             a0 = ap[0]; a1 = ap[1]; a2 = ap[2];
         }
     }
-    if (p.u) uu_in = p.u[g];                             // uniform branch
+    if (u_t) uu_in = u_t[g];                             // uniform branch
 
     // ================= T1: the one dependent round trip: per-update steps of my LIVE bullets ========================
     int x, y, hp;
@@ -448,7 +460,7 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     spawn = spawn && phys;
     if (spawn) {
         double uu = uu_in;
-        if (!p.u) {
+        if (!u_t) {
             const uint4 r = draw4(p.seed, genv, STREAM_JITTER, uint32_t(games), (uint32_t(tick) << 8) | uint32_t(a));
             uu = uniform53(r.x, r.y);
         }
@@ -631,8 +643,8 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     if (valid) {
         if (mode == M_PHYS || mode == M_RESET)
             reinterpret_cast<uint4*>(p.st.plane)[g] = pack_plane(x, y, live, hp, dir);
-        p.rew[g] = float(rew);
-        p.done[g] = er.done ? uint8_t(1) : uint8_t(alive ? 0 : 1);
+        rew_t[g] = float(rew);
+        done_t[g] = er.done ? uint8_t(1) : uint8_t(alive ? 0 : 1);
     }
     // observation row: a dead observer sees all -1, a dead enemy is [-1,-1,-1] (battle_env.py:215-218,235-242).
     // Rows are staged in LDS ([lane][D], D odd -> conflict-free) and leave as coalesced 16-byte stores: the wave's rows
@@ -661,12 +673,12 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (G == A && (reinterpret_cast<uintptr_t>(p.obs) & 15u) == 0) {
+        if (G == A && (reinterpret_cast<uintptr_t>(obs_t) & 15u) == 0) {
             // rows of this wave: global floats [base, base + rows*D); the wave's offset SPB*D*4 bytes is a multiple of 16
             const int64_t e_first = int64_t(blockIdx.x) * EPB;
             const int64_t rows = min(int64_t(SPB), (p.E - e_first) * A);
             const int64_t nfl = rows * D;                                   // floats to write
-            float* gbase = p.obs + size_t(e_first) * A * D;
+            float* gbase = obs_t + size_t(e_first) * A * D;
             for (int i = tid * 4; i < nfl; i += SPB * 4) {
                 if (i + 4 <= nfl) {
                     *reinterpret_cast<float4*>(gbase + i) = *reinterpret_cast<const float4*>(&s_obs[i]);   // ds_read_b128
@@ -675,7 +687,7 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
                 }
             }
         } else if (valid) {
-            float* out = p.obs + g * size_t(D);
+            float* out = obs_t + g * size_t(D);
             for (int i = 0; i < D; ++i) out[i] = srow[i];
         }
     }
@@ -692,6 +704,12 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
         }
     }
     STAMP(7);
+    if (MULTI) {   // my stores of this tick before my loads of the next one (state rows, counters, LDS rows)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    }   // tick loop
 }
 
 // ---------------------------------------------------------------------------------------------- reset / observe
@@ -859,10 +877,12 @@ inline int grid_for(int64_t E, int n, int tpb = TPB) {
     return int((E + epb - 1) / epb);
 }
 
+// T == 0: one call (bsx_step_*);  T >= 1: bsx_step_many_* -- T calls in one launch, arrays with a leading T axis
 template <bool CONT>
 int launch_step(void* state, int64_t E, int n, const void* actions, int action_kind, const double* u, float* obs,
                 float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner, const BsxRewards* cfg, uint32_t flags,
-                uint64_t seed, int64_t env_offset, void* stream) {
+                uint64_t seed, int64_t env_offset, void* stream, int T = 0, int store_all = 0) {
+    if (T < 0 || T > BSX_MAX_T) return BSX_E_ARG;
     if (!state || E <= 0 || E > BSX_MAX_E || n < 1 || n > BSX_MAX_N || !obs || !rew || !done || !cfg) return BSX_E_ARG;
     if (!actions && !(flags & BSX_F_EMPTY_CALL)) return BSX_E_ARG;
     if (!aligned(state, 256) || !aligned(obs, 4) || !aligned(rew, 4) || (u && !aligned(u, 8))) return BSX_E_ALIGN;
@@ -874,14 +894,29 @@ int launch_step(void* state, int64_t E, int n, const void* actions, int action_k
     a.E = E; a.n = n; a.actions = actions; a.action_kind = action_kind; a.u = u;
     a.obs = obs; a.rew = rew; a.done = done; a.env_done = env_done; a.winner = winner;
     a.cfg = *cfg; a.flags = flags; a.seed = seed; a.env_offset = env_offset; a.tie_tick = bsx_tie_tick(n);
+    const int64_t EA = E * 2 * n;
+    a.T = T;
+    a.act_tb = EA * (CONT ? (action_kind == BSX_ACT_F32 ? 12 : 24) : (action_kind == BSX_ACT_I32 ? 4 : 16));
+    a.u_ts = EA;
+    a.obs_ts = store_all ? EA * (3 * n + 2) : 0; a.rew_ts = store_all ? EA : 0; a.done_ts = store_all ? EA : 0;
     const dim3 grid(grid_for(E, n, SPB)), block(SPB);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    switch (n) {
-        case 1: hipLaunchKernelGGL((bsx_step_kernel<1, CONT>), grid, block, 0, s, a); break;
-        case 2: hipLaunchKernelGGL((bsx_step_kernel<2, CONT>), grid, block, 0, s, a); break;
-        case 3: hipLaunchKernelGGL((bsx_step_kernel<3, CONT>), grid, block, 0, s, a); break;
-        case 4: hipLaunchKernelGGL((bsx_step_kernel<4, CONT>), grid, block, 0, s, a); break;
-        default: hipLaunchKernelGGL((bsx_step_kernel<0, CONT>), grid, block, 0, s, a); break;
+    if (T == 0) {
+        switch (n) {
+            case 1: hipLaunchKernelGGL((bsx_step_kernel<1, CONT, false>), grid, block, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((bsx_step_kernel<2, CONT, false>), grid, block, 0, s, a); break;
+            case 3: hipLaunchKernelGGL((bsx_step_kernel<3, CONT, false>), grid, block, 0, s, a); break;
+            case 4: hipLaunchKernelGGL((bsx_step_kernel<4, CONT, false>), grid, block, 0, s, a); break;
+            default: hipLaunchKernelGGL((bsx_step_kernel<0, CONT, false>), grid, block, 0, s, a); break;
+        }
+    } else {
+        switch (n) {
+            case 1: hipLaunchKernelGGL((bsx_step_kernel<1, CONT, true>), grid, block, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((bsx_step_kernel<2, CONT, true>), grid, block, 0, s, a); break;
+            case 3: hipLaunchKernelGGL((bsx_step_kernel<3, CONT, true>), grid, block, 0, s, a); break;
+            case 4: hipLaunchKernelGGL((bsx_step_kernel<4, CONT, true>), grid, block, 0, s, a); break;
+            default: hipLaunchKernelGGL((bsx_step_kernel<0, CONT, true>), grid, block, 0, s, a); break;
+        }
     }
     return int(hipGetLastError());
 }
@@ -955,6 +990,22 @@ int bsx_step_continuous(void* state, int64_t E, int n, const void* actions, int 
                         const BsxRewards* cfg, uint32_t flags, uint64_t seed, int64_t env_offset, void* stream) {
     return launch_step<true>(state, E, n, actions, action_kind, u, obs, rew, done, env_done, winner, cfg, flags, seed,
                              env_offset, stream);
+}
+
+int bsx_step_many_discrete(void* state, int64_t E, int n, int T, const void* actions, int action_kind, const double* u,
+                           float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner, const BsxRewards* cfg,
+                           uint32_t flags, int store_all, uint64_t seed, int64_t env_offset, void* stream) {
+    if (T < 1 || !actions) return BSX_E_ARG;
+    return launch_step<false>(state, E, n, actions, action_kind, u, obs, rew, done, env_done, winner, cfg, flags, seed,
+                              env_offset, stream, T, store_all);
+}
+
+int bsx_step_many_continuous(void* state, int64_t E, int n, int T, const void* actions, int action_kind, const double* u,
+                             float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner, const BsxRewards* cfg,
+                             uint32_t flags, int store_all, uint64_t seed, int64_t env_offset, void* stream) {
+    if (T < 1 || !actions) return BSX_E_ARG;
+    return launch_step<true>(state, E, n, actions, action_kind, u, obs, rew, done, env_done, winner, cfg, flags, seed,
+                             env_offset, stream, T, store_all);
 }
 
 int bsx_observe(void* state, int64_t E, int n, float* obs, void* stream) {

@@ -331,6 +331,70 @@ class parallel_env:
                           obs_ptr, rew_ptr, done_ptr, self._env_done.data_ptr(), self._winner.data_ptr(),
                           ctypes.byref(self._cfg), flags, self.seed, self.env_offset, self._stream()), "bsx_step")
 
+    def _check_action_series(self, actions):
+        """actions for T calls: [T, E, A] int32 | [T, E, A, 4] float32 | [T, E, A, 3] float32/float64 (continuous)."""
+        E, A = self.n_envs, self._A
+        if not torch.is_tensor(actions) or actions.device != self.device or not actions.is_contiguous() or actions.dim() < 3:
+            raise ValueError("actions must be a contiguous [T, E, A, ...] tensor on the env's device")
+        T = actions.shape[0]
+        if self.continuous_actions:
+            ok, kind = actions.shape == (T, E, A, 3) and actions.dtype in (torch.float32, torch.float64), \
+                (_lib.ACT_F64 if actions.dtype == torch.float64 else _lib.ACT_F32)
+        elif actions.dim() == 4:
+            ok, kind = actions.shape == (T, E, A, 4) and actions.dtype == torch.float32, _lib.ACT_LOGITS_F32
+        else:
+            ok, kind = actions.shape == (T, E, A) and actions.dtype == torch.int32, _lib.ACT_I32
+        if not ok or T < 1:
+            raise ValueError(f"bad actions tensor for {T} calls: shape {tuple(actions.shape)}, dtype {actions.dtype}")
+        return T, kind
+
+    def step_many(self, actions, store=False, out=None, u=None):
+        """T consecutive step() calls in ONE kernel launch (`for t: step(actions[t])` when all actions are known up
+        front: random or scripted play, replays).  Results are those of T step_batch() calls, bit for bit; each
+        wavefront walks its own games through the T ticks, so the state stays in the L2 between ticks instead of
+        crossing a kernel boundary.
+
+        actions: device tensor [T, E, A] int32 | [T, E, A, 4] float32 scores | [T, E, A, 3] float32/64 (continuous)
+        store:   False = obs/rew/done are the env-owned [E, A, ...] tensors and hold the last tick's results;
+                 True  = new (or `out`) [T, E, A, ...] tensors hold every tick's results
+        out:     optional (obs f32 [T,E,A,D], rew f32 [T,E,A], done uint8 [T,E,A]) to fill when store=True
+        u:       optional float64 [T, E, A] random() values for the shots (parity runs); needs rng='philox' otherwise"""
+        if self.rng != "philox" and u is None:
+            raise ValueError("step_many needs rng='philox' (or injected u)")
+        T, kind = self._check_action_series(actions)
+        E, A, D = self.n_envs, self._A, self.obs_size
+        if T > _lib.MAX_T:
+            raise ValueError(f"at most {_lib.MAX_T} ticks per launch")
+        if store:
+            if out is None:
+                out = (torch.empty((T, E, A, D), dtype=torch.float32, device=self.device),
+                       torch.empty((T, E, A), dtype=torch.float32, device=self.device),
+                       torch.empty((T, E, A), dtype=torch.uint8, device=self.device))
+            obs, rew, done = out
+            if (obs.shape != (T, E, A, D) or rew.shape != (T, E, A) or done.shape != (T, E, A) or obs.dtype != torch.float32
+                    or rew.dtype != torch.float32 or done.dtype != torch.uint8
+                    or not (obs.is_contiguous() and rew.is_contiguous() and done.is_contiguous())
+                    or any(t.device != self.device for t in out)):
+                raise ValueError("out must be contiguous (f32 [T,E,A,D], f32 [T,E,A], uint8 [T,E,A]) on the env's device")
+        else:
+            obs, rew, done = self._obs, self._rew, self._done
+        u_ptr = None
+        if u is not None:
+            self._u = torch.as_tensor(u).to(device=self.device, dtype=torch.float64).contiguous()
+            if self._u.shape != (T, E, A):
+                raise ValueError(f"u must have shape ({T}, {E}, {A})")
+            u_ptr = self._u.data_ptr()
+        flags = _lib.F_AUTO_RESET if self.auto_reset else 0
+        fn = self._lib.bsx_step_many_continuous if self.continuous_actions else self._lib.bsx_step_many_discrete
+        with self._guard():
+            _lib.check(fn(self._state.data_ptr(), E, self.n_agents, T, actions.data_ptr(), kind, u_ptr, obs.data_ptr(),
+                          rew.data_ptr(), done.data_ptr(), self._env_done.data_ptr(), self._winner.data_ptr(),
+                          ctypes.byref(self._cfg), flags, 1 if store else 0, self.seed, self.env_offset, self._stream()),
+                       "bsx_step_many")
+        if self._mirror:
+            self._sync_mirror()
+        return obs, rew, done.view(torch.bool)
+
     def capture_steps(self, actions, store=False):
         """Capture T consecutive step() launches into ONE HIP graph (the launch-bound inner loop of a rollout).
 
@@ -343,19 +407,8 @@ class parallel_env:
         Needs rng='philox' (no host draws inside a graph)."""
         if self.rng != "philox":
             raise ValueError("capture_steps needs rng='philox'")
+        T, kind = self._check_action_series(actions)
         E, A, D = self.n_envs, self._A, self.obs_size
-        if not torch.is_tensor(actions) or actions.device != self.device or not actions.is_contiguous():
-            raise ValueError("actions must be a contiguous tensor on the env's device")
-        T = actions.shape[0]
-        if self.continuous_actions:
-            ok, kind = actions.shape == (T, E, A, 3) and actions.dtype in (torch.float32, torch.float64), \
-                (_lib.ACT_F64 if actions.dtype == torch.float64 else _lib.ACT_F32)
-        elif actions.dim() == 4:
-            ok, kind = actions.shape == (T, E, A, 4) and actions.dtype == torch.float32, _lib.ACT_LOGITS_F32
-        else:
-            ok, kind = actions.shape == (T, E, A) and actions.dtype == torch.int32, _lib.ACT_I32
-        if not ok:
-            raise ValueError(f"bad actions tensor for capture: shape {tuple(actions.shape)}, dtype {actions.dtype}")
         if store:
             obs = torch.empty((T, E, A, D), dtype=torch.float32, device=self.device)
             rew = torch.empty((T, E, A), dtype=torch.float32, device=self.device)

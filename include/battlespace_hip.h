@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define BSX_ABI_VERSION 2
+#define BSX_ABI_VERSION 3
 #define BSX_BULLET_SLOTS 12 /* a bullet is removed at the latest on its 12th update (sprites.py:334-337: 12*45 >= 500) */
 #define BSX_MAX_N 16
 #define BSX_MAX_E (INT64_C(1) << 30)   /* games per call: keeps every grid below 2^31 workgroups; 2^30 games of 1v1 is ~0.8 TB of state */
@@ -95,6 +95,23 @@ int bsx_step_discrete(void* state, int64_t E, int n, const void* actions, int ac
 int bsx_step_continuous(void* state, int64_t E, int n, const void* actions, int action_kind, const double* u,
                         float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner,
                         const BsxRewards* cfg, uint32_t flags, uint64_t seed, int64_t env_offset, void* stream);
+
+/* T consecutive parallel_env.step calls in ONE launch (the caller's `for t: step(actions[t])` loop, battle_env.py:281, when
+ * the actions of all T calls are known up front: scripted or random play, replays).  Same arguments and results as T calls
+ * of bsx_step_discrete / bsx_step_continuous, bit for bit; arrays gain a leading T axis: actions [T][E*A] (or [T][E*A*4],
+ * [T][E*A*3]), u [T][E*A] (nullable).  store_all != 0: obs [T][E*A*D], rew [T][E*A], done [T][E*A] hold every call's
+ * results; store_all == 0: obs / rew / done are [E*A...] and hold the LAST call's (each call still writes them).
+ * env_done / winner (nullable, [E]) are the state after the last call.  1 <= T <= BSX_MAX_T.
+ * A wavefront walks its games through the T calls, so between calls the state stays in the L2. */
+#define BSX_MAX_T 65535
+int bsx_step_many_discrete(void* state, int64_t E, int n, int T, const void* actions, int action_kind, const double* u,
+                           float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner,
+                           const BsxRewards* cfg, uint32_t flags, int store_all, uint64_t seed, int64_t env_offset,
+                           void* stream);
+int bsx_step_many_continuous(void* state, int64_t E, int n, int T, const void* actions, int action_kind, const double* u,
+                             float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner,
+                             const BsxRewards* cfg, uint32_t flags, int store_all, uint64_t seed, int64_t env_offset,
+                             void* stream);
 
 /* parallel_env.observe for every agent (battle_env.py:202-244): obs float32[E*A*D].  No state change. */
 int bsx_observe(void* state, int64_t E, int n, float* obs, void* stream);

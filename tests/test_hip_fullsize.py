@@ -168,6 +168,47 @@ def test_graph_replay_equals_eager_steps():
     assert all(torch.equal(sa[k], sb[k]) for k in ("px", "py", "php", "tick", "counters", "bl_live"))
 
 
+@pytest.mark.parametrize("E,n,mode", [(4096, 1, "int"), (1000, 2, "int"), (515, 4, "int"), (300, 6, "int"),
+                                      (2048, 1, "scores"), (1024, 2, "cont32"), (777, 1, "cont64")])
+def test_step_many_equals_consecutive_step_calls(E, n, mode):
+    """bsx_step_many_*: T ticks in ONE launch (a wavefront walks its games through all of them, state through the L2)
+    play the same games as T step_batch() launches, bit for bit -- every tick's outputs and the final state, across
+    auto-resets and the time-limit tie, with long bullet lists (shoot-heavy), in chunks of different lengths."""
+    A = 2 * n
+    cont = mode.startswith("cont")
+    a = _env(n_agents=n, n_envs=E, seed=13, auto_reset=True, continuous_actions=cont); a.reset()
+    b = _env(n_agents=n, n_envs=E, seed=13, auto_reset=True, continuous_actions=cont); b.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(E + n)
+    for T in (1, 7, 150, 64):
+        if mode == "int":
+            acts = _actions(T, E, A, 100 + T, p_shoot=0.7)
+            acts[T // 2, : E // 3] = 9                          # out-of-range indices: the plane does not move
+        elif mode == "scores":
+            acts = torch.randn((T, E, A, 4), generator=g, device="cuda"); acts[..., 1] += 0.9
+        else:
+            acts = (torch.rand((T, E, A, 3), generator=g, device="cuda", dtype=torch.float64) * 2.6 - 1.3)
+            acts = acts.to(torch.float32).contiguous() if mode == "cont32" else acts
+        mo, mr, md = b.step_many(acts, store=True)
+        for t in range(T):
+            o, r, d = a.step_batch(acts[t])
+            assert torch.equal(o, mo[t]) and torch.equal(r, mr[t]) and torch.equal(d, md[t]), (T, t)
+        assert torch.equal(a.env_done, b.env_done) and torch.equal(a.winner, b.winner)
+        sa, sb = a.export_state(), b.export_state()
+        for k in sa:
+            if k.startswith("bl_") and k != "bl_live":
+                m = sa["bl_live"].bool()
+                assert torch.equal(sa[k][m], sb[k][m]), (T, k)
+            else:
+                assert torch.equal(sa[k], sb[k]), (T, k)
+    # store=False: the env-owned tensors hold the last tick
+    acts = (_actions(5, E, A, 1) if mode == "int" else acts[:5].contiguous())
+    o2, r2, d2 = b.step_many(acts)
+    for t in range(5):
+        o, r, d = a.step_batch(acts[t])
+    assert torch.equal(o, o2) and torch.equal(r, r2) and torch.equal(d, d2)
+    assert int(b.counters()[:, 0].sum()) > 0
+
+
 def _compare_generic(E, n, T, seed, cont=False, logits=False, f32=False):
     """HIP vs C oracle in the production configuration for any action encoding; ragged sizes (E not a multiple of the
     games-per-wave count) exercise the clamped-index lanes and the partial last wavefront."""

@@ -83,6 +83,54 @@ def test_hip_reproduces_reference_trace(name):
     assert n_exact >= n_vals * (1 - 1e-3), f"{name}: only {n_exact}/{n_vals} observation values bit-identical"
 
 
+@pytest.mark.parametrize("name", trace_names())
+def test_step_many_reproduces_reference_trace(name):
+    """The multi-tick launch (bsx_step_many_*) against the reference: all plain episodes of a golden trace side by side,
+    EVERY tick of every game in ONE kernel launch (spawns and random() values injected); per-tick observations, rewards and
+    dones against the recorded ones, the final state of each game against its last recorded row."""
+    import torch
+    from trace_util import cmp_state
+    t = load_trace(name)
+    meta = t["meta"]
+    A, cont = meta["A"], meta["continuous"]
+    ptr = t["ep_ptr"]
+    groups = [g for g in episode_groups(t) if not any(t["empty_call"][ptr[e]:ptr[e + 1]].any() for e in g)]
+    assert groups
+    eps = groups[0]
+    E = len(eps)
+    starts = np.asarray([ptr[e] for e in eps]); lens = np.asarray([ptr[e + 1] - ptr[e] for e in eps])
+    T = int(lens.max())
+    if "logits" in t:
+        act = np.zeros((T, E, A, 4), np.float32); src = t["logits"]
+    elif cont:
+        act = np.zeros((T, E, A, 3), np.float64); src = t["actions"]
+    else:
+        act = np.zeros((T, E, A), np.int32); src = t["actions"]
+    u = np.full((T, E, A), np.nan)
+    for i in range(E):
+        act[:lens[i], i] = src[starts[i]:starts[i] + lens[i]]
+        u[:lens[i], i] = t["u"][starts[i]:starts[i] + lens[i]]
+    env = _env(n_envs=E, rng="philox", **meta["cfg"])
+    env.reset(spawn=t["spawn"][eps])
+    obs, rew, done = env.step_many(torch.as_tensor(act).cuda(), store=True, u=u)
+    obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+    n_exact = n_vals = 0
+    for i in range(E):
+        rows = np.arange(starts[i], starts[i] + lens[i])
+        np.testing.assert_allclose(obs[:lens[i], i], t["obs"][rows], rtol=OBS_RTOL, atol=OBS_ATOL, err_msg=f"{name} ep {eps[i]}")
+        np.testing.assert_allclose(rew[:lens[i], i], t["rew"][rows], rtol=1e-6, atol=1e-6)
+        assert np.array_equal(done[:lens[i], i], t["done"][rows]), f"{name} ep {eps[i]}: done"
+        n_exact += int((obs[:lens[i], i] == t["obs"][rows]).sum()); n_vals += obs[:lens[i], i].size
+    assert n_exact >= n_vals * (1 - 1e-3)
+    base = np.zeros((E, 4), np.int64)
+    for i, s0 in enumerate(starts):
+        if s0 > 0:
+            base[i] = [t[f][s0 - 1] for f in ("total_games", "ties", "wins_red", "wins_blue")]
+    st = {f: v.cpu().numpy() for f, v in env.export_state().items()}
+    fin = np.nonzero(t["env_done"][starts + lens - 1])[0]       # a game the trace leaves unfinished plays on with the padding
+    cmp_state(name, st, t, (starts + lens - 1)[fin], fin, base[fin], "after the last tick")
+
+
 @pytest.mark.parametrize("name", ["g5_scripted_1v1", "g1_1v1_instinct", "g4_1v1_cont_instinct"])
 def test_dropin_surface_reproduces_reference_trace(name):
     """Episode by episode through the drop-in (n_envs=None) surface: reference return types, step({}), dones identity."""
