@@ -203,6 +203,17 @@ def main():
     # not the headline: the same kernel on BASELINE.json configs[2] and in the streaming regime (working set > Infinity
     # Cache), a few hundred steps each, so one run shows how the roofline fraction moves with the batch
     others = {}
+    multi = None
+    if world == 1 and not args.no_other_workloads and args.mode != "many":
+        # the same K ticks as K/100 multi-tick launches (bsx_step_many_*: every tick's outputs stored, state carried in
+        # registers / L2 between ticks): what an open-loop caller (random or scripted play) gets without kernel boundaries
+        del env
+        torch.cuda.empty_cache()
+        env, dtm, kmm, Gm = measure(n, E, K, W, "many", 100)
+        achm = b_alg(n) * E * A / (kmm * 1e-3) / 1e9
+        multi = {"agent_steps_per_s": round(E * A * K / dtm, 1), "us_per_tick": round(kmm * 1e3, 3), "ticks_per_launch": Gm,
+                 "roofline_frac": round(achm / HBM_PEAK_GBS, 4), "kernel": f"bsx_step_kernel<{n if n <= 4 else 0},{'true' if args.continuous else 'false'},true>",
+                 "note": "not the headline: north_star asks for one kernel per step"}
     if world == 1 and not args.no_other_workloads and (n, E) == (1, 65536):
         for tag, (n2, E2, K2) in {"configs[2] 65536 x 4v4": (4, 65536, 400), "1048576 x 1v1 (streaming)": (1, 1048576, 200)}.items():
             del env
@@ -237,13 +248,14 @@ def main():
                        "graph_len": G if args.mode == "graph" else None, "parallelism": f"{world} independent env shards, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": f"bsx_step_kernel<{n if n <= 4 else 0},{'true' if args.continuous else 'false'}>", "avg_launch_us": round(kernel_ms * 1e3, 3),
+                         "kernel": f"bsx_step_kernel<{n if n <= 4 else 0},{'true' if args.continuous else 'false'},{'true' if args.mode == 'many' else 'false'}>", "avg_launch_us": round(kernel_ms * 1e3, 3),
                          "algorithmic_bytes_per_launch": round(bytes_per_launch), "bytes_per_agent_step": round(b_alg(n), 2)},
             "games_finished": int(games[0]), "ties": int(games[1]), "red_wins": int(games[2]), "blue_wins": int(games[3]),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         out["other_workloads"] = others
+        out["multi_tick_launch"] = multi
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -16,7 +16,10 @@ LIB = os.path.join(CSRC, "libbattlespace_hip.so")
 COMMON = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # (source, extra flags).  The step path forbids FMA contraction (bit-exact float64 add-then-truncate); the actor MLP
 # has no such contract and wants contraction.
-SOURCES = [(os.path.join(CSRC, "bsx_kernels.hip"), ["-ffp-contract=off"]),
+# -disable-machine-licm: in the multi-tick kernels (a tick loop around the whole step body) machine LICM would hoist every
+# fp64 literal of sincos / atan2 out of the loop into ~110 VGPRs held for the whole tick (256 VGPRs, 1-2 waves per SIMD);
+# the one-call kernels compile to the same code either way.
+SOURCES = [(os.path.join(CSRC, "bsx_kernels.hip"), ["-ffp-contract=off", "-mllvm", "-disable-machine-licm"]),
            (os.path.join(CSRC, "bsx_actor.hip"), ["-ffp-contract=fast"])]
 
 

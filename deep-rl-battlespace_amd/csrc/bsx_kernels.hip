@@ -321,8 +321,46 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     __shared__ volatile int s_bhit[SPB];                 // base hits, index gl + shooter team
     __shared__ __attribute__((aligned(16))) float s_obs[SPB * ((N > 0) ? 3 * N + 2 : 3 * BSX_MAX_N + 2)];   // observation rows of the wave
 
+    // Raw inputs of one call (decoded at the top of the tick that uses them).
+    struct RawIn { int ai; float4 lg; float f0, f1, f2; double c0, c1, c2, uu; };
+    auto load_inputs = [&](int t, RawIn& r) {
+        const void* const at = MULTI ? static_cast<const void*>(static_cast<const char*>(p.actions) + int64_t(t) * p.act_tb) : p.actions;
+        const double* const ut = (MULTI && p.u) ? p.u + int64_t(t) * p.u_ts : p.u;
+        if (at) {                                        // uniform branch
+            if (!CONT) {
+                if (p.action_kind == BSX_ACT_I32) r.ai = static_cast<const int32_t*>(at)[g];
+                else r.lg = static_cast<const float4*>(at)[g];
+            } else if (p.action_kind == BSX_ACT_F32) {
+                const float* ap = static_cast<const float*>(at) + 3 * g;
+                r.f0 = ap[0]; r.f1 = ap[1]; r.f2 = ap[2];
+            } else {
+                const double* ap = static_cast<const double*>(at) + 3 * g;
+                r.c0 = ap[0]; r.c1 = ap[1]; r.c2 = ap[2];
+            }
+        }
+        if (ut) r.uu = ut[g];                            // uniform branch
+    };
+    // MULTI: what one call hands to the next stays in REGISTERS -- my plane, my game's record and episode count (every
+    // lane of a game computes the same record) -- so a later tick starts with its bullet loads instead of a state round
+    // trip, and the inputs of tick t+1 are fetched while tick t computes.  Memory still gets every tick's state.
+    int x = 0, y = 0, hp = 0, games = 0;
+    uint32_t live = 0;
+    double dir = 0.0;
+    EnvU er = {};
+    RawIn rin = {}, rin_next = {};
+    if (MULTI) load_inputs(0, rin_next);
+
     for (int tk = 0; tk < (MULTI ? p.T : 1); ++tk) {
-    const void* const actions_t = MULTI ? static_cast<const void*>(static_cast<const char*>(p.actions) + int64_t(tk) * p.act_tb) : p.actions;
+    // In the tick loop the compiler would hoist everything loop-invariant -- 36 row addresses, the Philox key schedule,
+    // every fp64 constant -- and run out of registers (256 VGPRs, 1-2 waves per SIMD, SGPR spills).  Passing the three
+    // values all of that hangs on through an empty asm makes it per-tick work again, as in the one-call kernel.
+    size_t gt = g, EAt = EA;
+    uint64_t seed_t = p.seed;
+    if (MULTI) {
+        asm volatile("" : "+v"(gt));
+        asm volatile("" : "+s"(EAt));
+        asm volatile("" : "+s"(seed_t));
+    }
     const double* const u_t = (MULTI && p.u) ? p.u + int64_t(tk) * p.u_ts : p.u;
     float* const obs_t = MULTI ? p.obs + int64_t(tk) * p.obs_ts : p.obs;
     float* const rew_t = MULTI ? p.rew + int64_t(tk) * p.rew_ts : p.rew;
@@ -330,38 +368,36 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     STAMP(0);
     // ================= T0: every load that depends on no other load, issued back to back, raw 16-byte words ========
     // (the kernel is latency-bound at 65 536 games -- 2 waves per SIMD -- so memory-level parallelism is what pays)
-    const uint4 erw = reinterpret_cast<const uint4*>(p.st.env)[ec];
-    const int games = reinterpret_cast<const int*>(p.st.cnt)[4 * ec];   // games finished so far = episode id of the RNG streams
-    const uint4 prw = reinterpret_cast<const uint4*>(p.st.plane)[g];
+    if (!MULTI || tk == 0) {
+        const uint4 erw = reinterpret_cast<const uint4*>(p.st.env)[ec];
+        games = reinterpret_cast<const int*>(p.st.cnt)[4 * ec];   // games finished so far = episode id of the RNG streams
+        const uint4 prw = reinterpret_cast<const uint4*>(p.st.plane)[gt];
+        if (!MULTI) load_inputs(0, rin);
+        unpack_plane(prw, x, y, live, hp, dir);
+        er = unpack_env(erw);
+    }
+    if (MULTI) rin = rin_next;
     int act = -1;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, uu_in = 0.0;
-    if (actions_t) {                                     // uniform branch
+    if (p.actions) {                                     // uniform branch
         if (!CONT) {
-            if (p.action_kind == BSX_ACT_I32) act = static_cast<const int32_t*>(actions_t)[g];
+            if (p.action_kind == BSX_ACT_I32) act = rin.ai;
             else {   // np.argmax: first maximum; a NaN compares as the maximum
-                const float4 lg = static_cast<const float4*>(actions_t)[g];
-                const float v[4] = {lg.x, lg.y, lg.z, lg.w};
+                const float v[4] = {rin.lg.x, rin.lg.y, rin.lg.z, rin.lg.w};
                 act = 0;
 #pragma unroll
                 for (int i = 1; i < 4; ++i)
                     if (!(v[act] != v[act]) && (v[i] > v[act] || v[i] != v[i])) act = i;
             }
         } else if (p.action_kind == BSX_ACT_F32) {
-            const float* ap = static_cast<const float*>(actions_t) + 3 * g;
-            a0 = double(ap[0]); a1 = double(ap[1]); a2 = double(ap[2]);
+            a0 = double(rin.f0); a1 = double(rin.f1); a2 = double(rin.f2);
         } else {
-            const double* ap = static_cast<const double*>(actions_t) + 3 * g;
-            a0 = ap[0]; a1 = ap[1]; a2 = ap[2];
+            a0 = rin.c0; a1 = rin.c1; a2 = rin.c2;
         }
     }
-    if (u_t) uu_in = u_t[g];                             // uniform branch
+    if (u_t) uu_in = rin.uu;                             // uniform branch
 
     // ================= T1: the one dependent round trip: per-update steps of my LIVE bullets ========================
-    int x, y, hp;
-    uint32_t live;
-    double dir;
-    unpack_plane(prw, x, y, live, hp, dir);
-    EnvU er = unpack_env(erw);
     const uint32_t live0 = live;
     // Bullets are sparse (uniform random play: 0.6 per agent, 12 at most), and each agent's bullets are a dense list in
     // creation order: entry j of every agent lives in row j, so the lanes of a wave that own a j-th bullet read ONE
@@ -383,9 +419,10 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const bool has = j < cnt0;
-        iw[j] = *(has ? &p.st.bxy[size_t(j) * EA + g] : reinterpret_cast<const uint32_t*>(p.st.lut));
-        idd[j] = *(has ? &p.st.bd[size_t(j) * EA + g] : p.st.lut);
+        iw[j] = *(has ? &p.st.bxy[size_t(j) * EAt + gt] : reinterpret_cast<const uint32_t*>(p.st.lut));
+        idd[j] = *(has ? &p.st.bd[size_t(j) * EAt + gt] : p.st.lut);
     }
+    if (MULTI && tk + 1 < p.T) load_inputs(tk + 1, rin_next);   // behind this tick's own loads: nothing waits for it before the tick ends
     const bool alive0 = valid && hp > 0;
     STAMP(1);
 
@@ -415,12 +452,12 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     if (mode == M_RESET) {
         // re-spawn in place of the inert call; episode id = games played so far
         EnvRec nb; memset(&nb, 0, sizeof(nb));
-        spawn_bases(p.seed, genv, STREAM_AUTORESET, uint32_t(games), nb);
+        spawn_bases(seed_t, genv, STREAM_AUTORESET, uint32_t(games), nb);
         er.brx = nb.brx; er.bry = nb.bry; er.bbx = nb.bbx; er.bby = nb.bby;
         er.bhp_r = er.bhp_b = 5 * n;
         er.tick = 0; er.done = 0; er.winner = BSX_WINNER_NONE;
         tick = 0;
-        spawn_plane(p.seed, genv, STREAM_AUTORESET, uint32_t(games), a < A ? a : A - 1, n, x, y, dir);
+        spawn_plane(seed_t, genv, STREAM_AUTORESET, uint32_t(games), a < A ? a : A - 1, n, x, y, dir);
         hp = PLANE_HP; live = 0;
     } else if (mode == M_PHYS && alive0) {
         // ---- process_action (battle_env.py:383-424)
@@ -461,14 +498,14 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     if (spawn) {
         double uu = uu_in;
         if (!u_t) {
-            const uint4 r = draw4(p.seed, genv, STREAM_JITTER, uint32_t(games), (uint32_t(tick) << 8) | uint32_t(a));
+            const uint4 r = draw4(seed_t, genv, STREAM_JITTER, uint32_t(games), (uint32_t(tick) << 8) | uint32_t(a));
             uu = uniform53(r.x, r.y);
         }
         const double bdir = d0 + (uu * 8.0 - 4.0);
         double sn, cs;
         sincos(-(bdir * DEG2RAD), &sn, &cs);
         nd = make_double2(BULLET_STEP * cs, BULLET_STEP * sn);
-        p.st.bdir[size_t(ks) * EA + g] = bdir;       // ring by birth tick: never moves, read only by bsx_export_state
+        p.st.bdir[size_t(ks) * EAt + gt] = bdir;       // ring by birth tick: never moves, read only by bsx_export_state
     }
 
     STAMP(3);
@@ -542,8 +579,8 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
             ovl[0] |= (ag >> 2) == 0 ? f : 0ull; ovl[OW > 1 ? 1 : 0] |= (ag >> 2) == 1 ? f : 0ull; ovl[OW > 2 ? 2 : 0] |= (ag >> 2) == 2 ? f : 0ull;
         }
         if (keepm) {
-            p.st.bxy[size_t(pos) * EA + g] = pack_bullet(bx, by, age);
-            if (pos != j) p.st.bd[size_t(pos) * EA + g] = dd;           // the entry moved down (or is new): its step moves with it
+            p.st.bxy[size_t(pos) * EAt + gt] = pack_bullet(bx, by, age);
+            if (pos != j) p.st.bd[size_t(pos) * EAt + gt] = dd;           // the entry moved down (or is new): its step moves with it
             posmap |= uint64_t(pos) << (4 * ag);
             pos += 1;
         }
@@ -561,8 +598,8 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 const bool has = base + j < cnt0;
-                rw[j] = *(has ? &p.st.bxy[size_t(base + j) * EA + g] : reinterpret_cast<const uint32_t*>(p.st.lut));
-                rd[j] = *(has ? &p.st.bd[size_t(base + j) * EA + g] : p.st.lut);
+                rw[j] = *(has ? &p.st.bxy[size_t(base + j) * EAt + gt] : reinterpret_cast<const uint32_t*>(p.st.lut));
+                rd[j] = *(has ? &p.st.bd[size_t(base + j) * EAt + gt] : p.st.lut);
             }
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
@@ -607,7 +644,7 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
         while (consumed) {
             const int ag = __builtin_ctz(consumed);
             consumed &= consumed - 1u;
-            p.st.bxy[size_t((posmap >> (4 * ag)) & 15u) * EA + g] = pack_bullet(0, 0, int(TOMBSTONE_AGE));
+            p.st.bxy[size_t((posmap >> (4 * ag)) & 15u) * EAt + gt] = pack_bullet(0, 0, int(TOMBSTONE_AGE));
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -642,9 +679,9 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     // ---- write back
     if (valid) {
         if (mode == M_PHYS || mode == M_RESET)
-            reinterpret_cast<uint4*>(p.st.plane)[g] = pack_plane(x, y, live, hp, dir);
-        rew_t[g] = float(rew);
-        done_t[g] = er.done ? uint8_t(1) : uint8_t(alive ? 0 : 1);
+            reinterpret_cast<uint4*>(p.st.plane)[gt] = pack_plane(x, y, live, hp, dir);
+        rew_t[gt] = float(rew);
+        done_t[gt] = er.done ? uint8_t(1) : uint8_t(alive ? 0 : 1);
     }
     // observation row: a dead observer sees all -1, a dead enemy is [-1,-1,-1] (battle_env.py:215-218,235-242).
     // Rows are staged in LDS ([lane][D], D odd -> conflict-free) and leave as coalesced 16-byte stores: the wave's rows
@@ -687,7 +724,7 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
                 }
             }
         } else if (valid) {
-            float* out = obs_t + g * size_t(D);
+            float* out = obs_t + gt * size_t(D);
             for (int i = 0; i < D; ++i) out[i] = srow[i];
         }
     }
@@ -704,7 +741,8 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
         }
     }
     STAMP(7);
-    if (MULTI) {   // my stores of this tick before my loads of the next one (state rows, counters, LDS rows)
+    if (MULTI) {   // my stores of this tick before my loads of the next one (bullet rows, LDS rows)
+        games += cnt_delta.x;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

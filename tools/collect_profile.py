@@ -32,7 +32,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc"):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(cc[0])):
-        if f"bsx_step_kernel<{n if n <= 4 else 0}, false>" in r["Kernel_Name"] and int(r["Grid_Size"]) == grid_threads:
+        if f"bsx_step_kernel<{n if n <= 4 else 0}, false, false>" in r["Kernel_Name"] and int(r["Grid_Size"]) == grid_threads:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     kt = glob.glob(os.path.join(src, sub, "*", "*_kernel_trace.csv"))
     du = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(kt[0])) if "bsx_step_kernel" in r["Kernel_Name"]]

@@ -8,7 +8,7 @@ SRC=deep-rl-battlespace_amd/csrc
 cp $SRC/libbattlespace_hip.so /tmp/product.so
 hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=fast -I include -c $SRC/bsx_actor.hip -o /tmp/actor.o
 for d in ${1:-"8 1 2"}; do
-  hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=off -DBSX_DIAG=$d -I include -c $SRC/bsx_kernels.hip -o /tmp/k.o
+  hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=off -mllvm -disable-machine-licm -DBSX_DIAG=$d -I include -c $SRC/bsx_kernels.hip -o /tmp/k.o
   hipcc --offload-arch=gfx950 -shared -fPIC /tmp/k.o /tmp/actor.o -o $SRC/libbattlespace_hip.so
   timeout -k 10 120 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-other-workloads > gpurun_out/diag/diag${d}_C2.json
   timeout -k 10 120 python bench.py --steps 300 --warmup 50 --no-cpu-baseline --no-other-workloads --envs-per-gpu 1048576 > gpurun_out/diag/diag${d}_1M.json
