@@ -14,20 +14,23 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "libbattlespace_hip.so")
 COMMON = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
-# (source, extra flags).  The step path forbids FMA contraction (bit-exact float64 add-then-truncate); the actor MLP
-# has no such contract and wants contraction.
+# (source, extra flags).  The step path forbids FMA contraction (bit-exact float64 add-then-truncate).  The actor MLP has no
+# such contract, but its arithmetic is shared with the fused rollout kernel inside bsx_kernels.hip and must give the same
+# bits in both files: one module-wide setting (library code like tanhf is fused or not by it), contraction where wanted
+# through `#pragma clang fp contract(fast)` in bsx_actor_core.h.
 # -disable-machine-licm: in the multi-tick kernels (a tick loop around the whole step body) machine LICM would hoist every
 # fp64 literal of sincos / atan2 out of the loop into ~110 VGPRs held for the whole tick (256 VGPRs, 1-2 waves per SIMD);
 # the one-call kernels compile to the same code either way.
 SOURCES = [(os.path.join(CSRC, "bsx_kernels.hip"), ["-ffp-contract=off", "-mllvm", "-disable-machine-licm"]),
-           (os.path.join(CSRC, "bsx_actor.hip"), ["-ffp-contract=fast"])]
+           (os.path.join(CSRC, "bsx_actor.hip"), ["-ffp-contract=off"])]
 
 
 def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [src for src, _ in SOURCES] + [os.path.join(INCLUDE, "battlespace_hip.h"), os.path.abspath(__file__)]
+    deps = [src for src, _ in SOURCES] + [os.path.join(CSRC, "bsx_actor_core.h"), os.path.join(INCLUDE, "battlespace_hip.h"),
+                                          os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -18,80 +18,30 @@
 //   * LayerNorm needs a row's 64 neurons: 32 registers of the lane plus the partner lane l^32 -> one xor-32 shuffle.
 //   * the 64 -> 4 head is 128 VALU FMAs per lane on the accumulator registers plus the same xor-32 add.
 // A workgroup = 4 waves x 64 rows of ONE agent (blockIdx.y); the small per-neuron vectors and the head weights are
-// staged once in LDS.  Built WITHOUT -ffp-contract=off (checked against a torch fp32 reference, not bit-exact).
+// staged once in LDS.  Checked against a torch fp32 reference (2e-5), not bit-exact with it; bit-exact with the fused
+// rollout kernel, which runs the same per-tile arithmetic (bsx_actor_core.h): both files are built with -ffp-contract=off
+// (so that library code such as tanhf compiles the same in both) and the core functions pin contraction themselves.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "battlespace_hip.h"
+#include "bsx_actor_core.h"
 
 namespace {
 
-constexpr int H = 64;            // fc1_dims = fc2_dims = 64 (main.py:15-16)
-constexpr int NA = 4;            // discrete action scores
+using namespace bsx_actor;       // H, NA, SMALL, blob layout, ln_relu_tile, finish_row (shared with the fused rollout kernel)
+
 constexpr int TPB = 256;
 constexpr int ROWS_PER_WAVE = 64;
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// packed blob per agent (floats); Dp = obs_len rounded up to even
-//   W1A[mo 2][s Dp/2][lane 64]                 W1[k = 2s + (lane>>5)][32*mo + (lane&31)], 0 for k >= D
-//   W2A[mo 2][mt 2][vq 4][lane 64][t 4]        W2[k = nid(mt, 4*vq+t, lane>>5)][32*mo + (lane&31)]
-//   small: b1p g1p be1p b2p g2p be2p, each [hh 2][mo 2][v 16] = value[nid(mo, v, hh)]
-//   W3P[hh 2][mt 2][v 16][4]                   W3[k = nid(mt, v, hh)][0..3]
-//   b3[4]
-// nid(m, v, hh) = 32*m + (v&3) + 8*(v>>2) + 4*hh  -- the neuron held by accumulator register v of tile m in lane half hh
-__host__ __device__ constexpr int dpad(int D) { return (D + 1) & ~1; }
-__host__ __device__ constexpr int off_w2(int D) { return H * dpad(D); }
-__host__ __device__ constexpr int off_small(int D) { return off_w2(D) + H * H; }
-__host__ __device__ constexpr int off_w3(int D) { return off_small(D) + 6 * H; }
-__host__ __device__ constexpr int off_b3(int D) { return off_w3(D) + H * NA; }
-__host__ __device__ constexpr int blob_floats(int D) { return off_b3(D) + NA; }
-
-__device__ inline uint4 philox4x32_10(uint4 ctr, uint2 key) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, ctr.x), lo0 = 0xD2511F53u * ctr.x;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, ctr.z), lo1 = 0xCD9E8D57u * ctr.z;
-        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
-        key.x += 0x9E3779B9u; key.y += 0xBB67AE85u;
-    }
-    return ctr;
-}
 
 struct ActorArgs {
     const float* weights; const float* obs; float* scores;
     int64_t E; int A; int D; BsxActorNoise nz; uint64_t seed; uint64_t seq; const uint64_t* seq_base;
 };
 
-// LayerNorm over the 64 neurons of each row + ReLU, in place on the accumulator tiles acc[mo][nt] (torch semantics:
-// biased variance, eps 1e-5).  gp / bp: this lane half's gain / bias vectors, [mo 2][v 16] floats in LDS.
-__device__ inline void ln_relu_tiles(f32x16 (&acc)[2][2], const float* __restrict__ gp, const float* __restrict__ bp) {
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        float s = 0.f;
-#pragma unroll
-        for (int mo = 0; mo < 2; ++mo)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) s += acc[mo][nt][v];
-        s += __shfl_xor(s, 32);
-        const float mean = s * (1.0f / H);
-        float q = 0.f;
-#pragma unroll
-        for (int mo = 0; mo < 2; ++mo)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) { const float d = acc[mo][nt][v] - mean; q = fmaf(d, d, q); }
-        q += __shfl_xor(q, 32);
-        const float rstd = rsqrtf(q * (1.0f / H) + 1e-5f);
-#pragma unroll
-        for (int mo = 0; mo < 2; ++mo)
-#pragma unroll
-            for (int v = 0; v < 16; ++v)
-                acc[mo][nt][v] = fmaxf(fmaf((acc[mo][nt][v] - mean) * rstd, gp[mo * 16 + v], bp[mo * 16 + v]), 0.f);
-    }
-}
-
 __global__ __launch_bounds__(TPB) void bsx_actor_kernel(const ActorArgs p) {
+#pragma clang fp contract(fast)
     const int D = p.D, Dp = dpad(D);
     const int a = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -99,8 +49,8 @@ __global__ __launch_bounds__(TPB) void bsx_actor_kernel(const ActorArgs p) {
     const float* __restrict__ W = p.weights + size_t(a) * blob_floats(D);
 
     // per-neuron vectors (6 x 64), head weights (256) and head bias (4): once per workgroup into LDS
-    __shared__ __attribute__((aligned(16))) float s_small[6 * H + H * NA + NA];
-    for (int i = tid; i < (6 * H + H * NA + NA) / 4; i += TPB)
+    __shared__ __attribute__((aligned(16))) float s_small[SMALL];
+    for (int i = tid; i < SMALL / 4; i += TPB)
         reinterpret_cast<float4*>(s_small)[i] = reinterpret_cast<const float4*>(W + off_small(D))[i];
 
     // the 64 x 64 layer's A operands: 64 VGPRs, coalesced 16-byte loads, in flight while layer 1 runs
@@ -138,7 +88,8 @@ __global__ __launch_bounds__(TPB) void bsx_actor_kernel(const ActorArgs p) {
         acc1[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc1[1][0], 0, 0, 0);
         acc1[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc1[1][1], 0, 0, 0);
     }
-    ln_relu_tiles(acc1, sm + 1 * H, sm + 2 * H);
+    ln_relu_tile(acc1[0][0], acc1[1][0], sm + 1 * H, sm + 2 * H);
+    ln_relu_tile(acc1[0][1], acc1[1][1], sm + 1 * H, sm + 2 * H);
 
     // ---- layer 2: acc2[mo][nt] = b2 + W2^T * H1^T, the K index running over layer 1's accumulator registers
     f32x16 acc2[2][2];
@@ -158,7 +109,8 @@ __global__ __launch_bounds__(TPB) void bsx_actor_kernel(const ActorArgs p) {
             acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa1, acc1[mt][0][v], acc2[1][0], 0, 0, 0);
             acc2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa1, acc1[mt][1][v], acc2[1][1], 0, 0, 0);
         }
-    ln_relu_tiles(acc2, sm + 4 * H, sm + 5 * H);
+    ln_relu_tile(acc2[0][0], acc2[1][0], sm + 4 * H, sm + 5 * H);
+    ln_relu_tile(acc2[0][1], acc2[1][1], sm + 4 * H, sm + 5 * H);
 
     // ---- head: 64 -> 4 on the vector pipe; each lane sums its 32 neurons, the partner lane l^32 has the other 32
     const float4* w3 = reinterpret_cast<const float4*>(s_small + 6 * H) + hh * 32;   // [hh][mt][v] float4
@@ -183,42 +135,11 @@ __global__ __launch_bounds__(TPB) void bsx_actor_kernel(const ActorArgs p) {
     // lower half finishes the rows of tile 0, upper half those of tile 1: every lane writes one row
     float4 r4 = hh ? o[1] : o[0];
     const float4 b3 = *reinterpret_cast<const float4*>(s_small + 6 * H + H * NA);
-    r4.x = tanhf(r4.x + b3.x); r4.y = tanhf(r4.y + b3.y); r4.z = tanhf(r4.z + b3.z); r4.w = tanhf(r4.w + b3.w);
     const int64_t e = row0 + 32 * hh + c;
     const size_t row = size_t(e < p.E ? e : p.E - 1) * p.A + a;
-
-    // ---- exploration noise + clamp (maddpg/agent.py:30-31): four normals via Philox + Box-Muller, keyed by (seed, seq, row)
-    if (p.nz.gaussian_std > 0.f || p.nz.ou_scale > 0.f) {
-        const uint64_t seq = p.seq + (p.seq_base ? *p.seq_base : 0ull);   // seq_base: device word, so graph replays re-key
-        const uint4 r = philox4x32_10(make_uint4(uint32_t(row), uint32_t(uint64_t(row) >> 32), uint32_t(seq), uint32_t(seq >> 32)),
-                                      make_uint2(uint32_t(p.seed), uint32_t(p.seed >> 32) ^ 0xA5A5A5A5u));
-        const float u0 = (float(r.x >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = float(r.y >> 8) * (1.0f / 16777216.0f);
-        const float u2 = (float(r.z >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = float(r.w >> 8) * (1.0f / 16777216.0f);
-        const float m0 = sqrtf(-2.0f * __logf(u0)), m1 = sqrtf(-2.0f * __logf(u2));
-        float s0, c0, s1, c1;
-        __sincosf(6.2831853071795864f * u1, &s0, &c0);
-        __sincosf(6.2831853071795864f * u3, &s1, &c1);
-        float4 z = make_float4(m0 * c0, m0 * s0, m1 * c1, m1 * s1);
-        if (p.nz.ou_scale > 0.f) {
-            // Ornstein-Uhlenbeck (utils/noise.py:17-21): x += theta*(mu - x) + sigma*N(0,1); a finished game restarts from mu
-            float4* xs = reinterpret_cast<float4*>(p.nz.ou_state) + row;
-            float4 x = *xs;
-            if (p.nz.env_done && p.nz.env_done[e < p.E ? e : p.E - 1]) x = make_float4(p.nz.ou_mu, p.nz.ou_mu, p.nz.ou_mu, p.nz.ou_mu);
-            x.x += p.nz.ou_theta * (p.nz.ou_mu - x.x) + p.nz.ou_sigma * z.x;
-            x.y += p.nz.ou_theta * (p.nz.ou_mu - x.y) + p.nz.ou_sigma * z.y;
-            x.z += p.nz.ou_theta * (p.nz.ou_mu - x.z) + p.nz.ou_sigma * z.z;
-            x.w += p.nz.ou_theta * (p.nz.ou_mu - x.w) + p.nz.ou_sigma * z.w;
-            if (e < p.E) *xs = x;
-            r4.x = fmaf(p.nz.ou_scale, x.x, r4.x); r4.y = fmaf(p.nz.ou_scale, x.y, r4.y);
-            r4.z = fmaf(p.nz.ou_scale, x.z, r4.z); r4.w = fmaf(p.nz.ou_scale, x.w, r4.w);
-        }
-        if (p.nz.gaussian_std > 0.f) {
-            r4.x = fmaf(p.nz.gaussian_std, z.x, r4.x); r4.y = fmaf(p.nz.gaussian_std, z.y, r4.y);
-            r4.z = fmaf(p.nz.gaussian_std, z.z, r4.z); r4.w = fmaf(p.nz.gaussian_std, z.w, r4.w);
-        }
-        r4.x = fminf(fmaxf(r4.x, -1.f), 1.f); r4.y = fminf(fmaxf(r4.y, -1.f), 1.f);
-        r4.z = fminf(fmaxf(r4.z, -1.f), 1.f); r4.w = fminf(fmaxf(r4.w, -1.f), 1.f);
-    }
+    const uint64_t seq = p.seq + (p.seq_base ? *p.seq_base : 0ull);   // seq_base: device word, so graph replays re-key
+    const bool game_over = p.nz.ou_scale > 0.f && p.nz.env_done && p.nz.env_done[e < p.E ? e : p.E - 1];
+    r4 = finish_row(r4, b3, p.nz, p.seed, seq, row, game_over, e < p.E);
     if (e < p.E) reinterpret_cast<float4*>(p.scores)[row] = r4;
 }
 

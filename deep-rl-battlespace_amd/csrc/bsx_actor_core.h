@@ -1,0 +1,172 @@
+// bsx_actor_core.h -- device pieces of the per-agent actor MLP shared by the stand-alone actor kernel (bsx_actor.hip) and
+// the fused rollout kernel (actor -> step in one launch, bsx_kernels.hip).  Reference: maddpg/networks.py:54-85,
+// maddpg/agent.py:25-33, utils/noise.py:4-21.
+//
+// Both translation units must produce the SAME bits (the fused rollout is tested bit-for-bit against the two-kernel
+// one), and bsx_kernels.hip is built with -ffp-contract=off: every function here pins its own contraction mode.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "battlespace_hip.h"
+
+namespace bsx_actor {
+
+constexpr int H = 64;            // fc1_dims = fc2_dims = 64 (main.py:15-16)
+constexpr int NA = 4;            // discrete action scores
+constexpr int SMALL = 6 * H + H * NA + NA;   // per-agent LDS block: b1 g1 be1 b2 g2 be2 | W3P | b3
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// packed blob per agent (floats); Dp = obs_len rounded up to even
+//   W1A[mo 2][s Dp/2][lane 64]                 W1[k = 2s + (lane>>5)][32*mo + (lane&31)], 0 for k >= D
+//   W2A[mo 2][mt 2][vq 4][lane 64][t 4]        W2[k = nid(mt, 4*vq+t, lane>>5)][32*mo + (lane&31)]
+//   small: b1p g1p be1p b2p g2p be2p, each [hh 2][mo 2][v 16] = value[nid(mo, v, hh)]
+//   W3P[hh 2][mt 2][v 16][4]                   W3[k = nid(mt, v, hh)][0..3]
+//   b3[4]
+// nid(m, v, hh) = 32*m + (v&3) + 8*(v>>2) + 4*hh  -- the neuron held by accumulator register v of tile m in lane half hh
+__host__ __device__ constexpr int dpad(int D) { return (D + 1) & ~1; }
+__host__ __device__ constexpr int off_w2(int D) { return H * dpad(D); }
+__host__ __device__ constexpr int off_small(int D) { return off_w2(D) + H * H; }
+__host__ __device__ constexpr int off_w3(int D) { return off_small(D) + 6 * H; }
+__host__ __device__ constexpr int off_b3(int D) { return off_w3(D) + H * NA; }
+__host__ __device__ constexpr int blob_floats(int D) { return off_b3(D) + NA; }
+
+__device__ inline uint4 philox4x32_10(uint4 ctr, uint2 key) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, ctr.x), lo0 = 0xD2511F53u * ctr.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, ctr.z), lo1 = 0xCD9E8D57u * ctr.z;
+        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+        key.x += 0x9E3779B9u; key.y += 0xBB67AE85u;
+    }
+    return ctr;
+}
+
+// LayerNorm over the 64 neurons of each row + ReLU, in place on ONE 32-row tile held as acc[mo] (torch semantics: biased
+// variance, eps 1e-5).  A row's 64 neurons = 32 registers of the lane + the partner lane l^32.  gp / bp: this lane half's
+// gain / bias vectors, [mo 2][v 16] floats in LDS.
+__device__ inline void ln_relu_tile(f32x16& a0, f32x16& a1, const float* __restrict__ gp, const float* __restrict__ bp) {
+#pragma clang fp contract(fast)
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) s += a0[v];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) s += a1[v];
+    s += __shfl_xor(s, 32);
+    const float mean = s * (1.0f / H);
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { const float d = a0[v] - mean; q = fmaf(d, d, q); }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { const float d = a1[v] - mean; q = fmaf(d, d, q); }
+    q += __shfl_xor(q, 32);
+    const float rstd = rsqrtf(q * (1.0f / H) + 1e-5f);
+#pragma unroll
+    for (int v = 0; v < 16; ++v) a0[v] = fmaxf(fmaf((a0[v] - mean) * rstd, gp[v], bp[v]), 0.f);
+#pragma unroll
+    for (int v = 0; v < 16; ++v) a1[v] = fmaxf(fmaf((a1[v] - mean) * rstd, gp[16 + v], bp[16 + v]), 0.f);
+}
+
+// tanh of the head sums + bias, exploration noise, clamp (maddpg/networks.py:85, maddpg/agent.py:30-31) for ONE row.
+// Four normals via Philox + Box-Muller keyed by (seed, seq, row); optional Ornstein-Uhlenbeck state at ou_state[row]
+// (utils/noise.py:17-21), restarted from mu when `game_over` (main.py:155).  `store`: this lane owns a real row.
+__device__ inline float4 finish_row(float4 r4, const float4 b3, const BsxActorNoise& nz, uint64_t seed, uint64_t seq,
+                                    size_t row, bool game_over, bool store) {
+#pragma clang fp contract(fast)
+    r4.x = tanhf(r4.x + b3.x); r4.y = tanhf(r4.y + b3.y); r4.z = tanhf(r4.z + b3.z); r4.w = tanhf(r4.w + b3.w);
+    if (nz.gaussian_std > 0.f || nz.ou_scale > 0.f) {
+        const uint4 r = philox4x32_10(make_uint4(uint32_t(row), uint32_t(uint64_t(row) >> 32), uint32_t(seq), uint32_t(seq >> 32)),
+                                      make_uint2(uint32_t(seed), uint32_t(seed >> 32) ^ 0xA5A5A5A5u));
+        const float u0 = (float(r.x >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = float(r.y >> 8) * (1.0f / 16777216.0f);
+        const float u2 = (float(r.z >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = float(r.w >> 8) * (1.0f / 16777216.0f);
+        const float m0 = sqrtf(-2.0f * __logf(u0)), m1 = sqrtf(-2.0f * __logf(u2));
+        float s0, c0, s1, c1;
+        __sincosf(6.2831853071795864f * u1, &s0, &c0);
+        __sincosf(6.2831853071795864f * u3, &s1, &c1);
+        const float4 z = make_float4(m0 * c0, m0 * s0, m1 * c1, m1 * s1);
+        if (nz.ou_scale > 0.f) {
+            float4* xs = reinterpret_cast<float4*>(nz.ou_state) + row;
+            float4 x = *xs;
+            if (game_over) x = make_float4(nz.ou_mu, nz.ou_mu, nz.ou_mu, nz.ou_mu);
+            x.x += nz.ou_theta * (nz.ou_mu - x.x) + nz.ou_sigma * z.x;
+            x.y += nz.ou_theta * (nz.ou_mu - x.y) + nz.ou_sigma * z.y;
+            x.z += nz.ou_theta * (nz.ou_mu - x.z) + nz.ou_sigma * z.z;
+            x.w += nz.ou_theta * (nz.ou_mu - x.w) + nz.ou_sigma * z.w;
+            if (store) *xs = x;
+            r4.x = fmaf(nz.ou_scale, x.x, r4.x); r4.y = fmaf(nz.ou_scale, x.y, r4.y);
+            r4.z = fmaf(nz.ou_scale, x.z, r4.z); r4.w = fmaf(nz.ou_scale, x.w, r4.w);
+        }
+        if (nz.gaussian_std > 0.f) {
+            r4.x = fmaf(nz.gaussian_std, z.x, r4.x); r4.y = fmaf(nz.gaussian_std, z.y, r4.y);
+            r4.z = fmaf(nz.gaussian_std, z.z, r4.z); r4.w = fmaf(nz.gaussian_std, z.w, r4.w);
+        }
+        r4.x = fminf(fmaxf(r4.x, -1.f), 1.f); r4.y = fminf(fmaxf(r4.y, -1.f), 1.f);
+        r4.z = fminf(fmaxf(r4.z, -1.f), 1.f); r4.w = fminf(fmaxf(r4.w, -1.f), 1.f);
+    }
+    return r4;
+}
+
+// ONE 32-row tile of ONE agent through the three layers, everything transposed (see bsx_actor.hip): returns the four head
+// sums of row (lane & 31), already added across the two lane halves (both halves hold them).
+//   W   the agent's packed blob (global; layer-2 operands are fetched here, 16 x 16-byte loads per lane)
+//   sm  the agent's SMALL block in LDS
+//   xb  xb(k) = this lane's layer-1 B operand: observation value k of row (lane & 31), 0 for k >= D
+template <class XB>
+__device__ inline float4 tile_forward(const float* __restrict__ W, const float* __restrict__ sm_agent, int D, int lane, XB xb) {
+#pragma clang fp contract(fast)
+    const int Dp = dpad(D), hh = lane >> 5;
+    const float* sm = sm_agent + hh * 32;      // this lane half's [mo][v] slice of each 64-float vector ([hh][mo][v])
+    float4 w2[2][2][4];
+#pragma unroll
+    for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int vq = 0; vq < 4; ++vq)
+                w2[mo][mt][vq] = reinterpret_cast<const float4*>(W + off_w2(D))[((mo * 2 + mt) * 4 + vq) * 64 + lane];
+    f32x16 acc1[2];
+#pragma unroll
+    for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc1[mo][v] = sm[0 * H + mo * 16 + v];
+    for (int s = 0; s < Dp / 2; ++s) {
+        const int k = 2 * s + hh;
+        const float a0 = W[(0 * (Dp / 2) + s) * 64 + lane], a1 = W[(1 * (Dp / 2) + s) * 64 + lane];
+        const float b = xb(k);
+        acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc1[0], 0, 0, 0);
+        acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1[1], 0, 0, 0);
+    }
+    ln_relu_tile(acc1[0], acc1[1], sm + 1 * H, sm + 2 * H);
+    f32x16 acc2[2];
+#pragma unroll
+    for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc2[mo][v] = sm[3 * H + mo * 16 + v];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const float4 q0 = w2[0][mt][v >> 2], q1 = w2[1][mt][v >> 2];
+            const float wa0 = (v & 3) == 0 ? q0.x : ((v & 3) == 1 ? q0.y : ((v & 3) == 2 ? q0.z : q0.w));
+            const float wa1 = (v & 3) == 0 ? q1.x : ((v & 3) == 1 ? q1.y : ((v & 3) == 2 ? q1.z : q1.w));
+            acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa0, acc1[mt][v], acc2[0], 0, 0, 0);
+            acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa1, acc1[mt][v], acc2[1], 0, 0, 0);
+        }
+    ln_relu_tile(acc2[0], acc2[1], sm + 4 * H, sm + 5 * H);
+    const float4* w3 = reinterpret_cast<const float4*>(sm_agent + 6 * H) + hh * 32;   // [hh][mt][v] float4
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const float4 ww = w3[mt * 16 + v];
+            const float hv = acc2[mt][v];
+            o.x = fmaf(hv, ww.x, o.x); o.y = fmaf(hv, ww.y, o.y); o.z = fmaf(hv, ww.z, o.z); o.w = fmaf(hv, ww.w, o.w);
+        }
+    o.x += __shfl_xor(o.x, 32); o.y += __shfl_xor(o.y, 32); o.z += __shfl_xor(o.z, 32); o.w += __shfl_xor(o.w, 32);
+    return o;
+}
+
+}  // namespace bsx_actor

@@ -31,6 +31,7 @@
 #include <string.h>
 
 #include "battlespace_hip.h"
+#include "bsx_actor_core.h"
 
 namespace {
 
@@ -207,6 +208,8 @@ struct StepArgs {
     uint32_t flags; uint64_t seed; int64_t env_offset; int tie_tick;
     // multi-tick launches (bsx_step_many_*): T ticks, per-tick strides of the action / output arrays (0 = same array every tick)
     int T; int64_t act_tb /* bytes */, u_ts, obs_ts, rew_ts, done_ts /* elements */;
+    // fused rollout (bsx_rollout_discrete): the actor in front of every tick
+    const float* aw; const float* obs0; float* scores; int64_t scores_ts; BsxActorNoise nz; uint64_t aseed, aseq; const uint64_t* aseq_base;
 };
 
 // Observation row for one agent from the LDS-staged block (battle_env.py:202-244).
@@ -258,6 +261,9 @@ __device__ inline void spawn_plane(uint64_t seed, int64_t genv, uint32_t stream,
 }
 
 enum Mode : int { M_INERT = 0, M_TIE = 1, M_PHYS = 2, M_RESET = 3 };
+#ifndef ROLLOUT_STAGGER
+#define ROLLOUT_STAGGER 3
+#endif
 
 // ---------------------------------------------------------------------------------------------- the step kernel
 // Record (un)packing on raw 16-byte words: keeps the loads as single dwordx4 instructions with no byte shuffling.
@@ -293,7 +299,12 @@ __device__ inline void obs_pair(int x, int y, double dir, int tx, int ty, float&
 // only ordering needed between ticks is this wave's own stores before its own loads (a workgroup-scope fence = a wait,
 // no cache maintenance: same CU, same L1); the state stays in the L2 instead of crossing a kernel boundary (write-back +
 // invalidate + a cold first round trip) every tick.
-template <int N, bool CONT, bool MULTI>
+// ACTOR (1v1, discrete, MULTI): the caller's whole rollout loop `for t: actions = actor(obs); obs, rew, done = step(actions)`
+// (main.py:176-181) in one launch.  A wave's 64 observation rows never leave the CU: the step leaves them in LDS, the
+// actor (bsx_actor_core.h, MFMA) reads them there as its B operands -- tile 0 = the 32 red planes, tile 1 = the 32 blue
+// ones, each with its own weights --, finishes row (lane & 31) of agent (lane >> 5), and one cross-lane move hands every
+// plane its arg-max.
+template <int N, bool CONT, bool MULTI, bool ACTOR = false>
 __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     STAMP(8);                                            // diagnostic builds: kernel entry, before any kernarg load
     const int n = (N > 0) ? N : p.n;
@@ -320,6 +331,7 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     __shared__ volatile int s_x[SPB], s_y[SPB], s_hp[SPB];
     __shared__ volatile int s_bhit[SPB];                 // base hits, index gl + shooter team
     __shared__ __attribute__((aligned(16))) float s_obs[SPB * ((N > 0) ? 3 * N + 2 : 3 * BSX_MAX_N + 2)];   // observation rows of the wave
+    __shared__ __attribute__((aligned(16))) float s_small[ACTOR ? 2 * bsx_actor::SMALL : 4];              // per-neuron vectors + heads of both actors
 
     // Raw inputs of one call (decoded at the top of the tick that uses them).
     struct RawIn { int ai; float4 lg; float f0, f1, f2; double c0, c1, c2, uu; };
@@ -348,7 +360,30 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     double dir = 0.0;
     EnvU er = {};
     RawIn rin = {}, rin_next = {};
-    if (MULTI) load_inputs(0, rin_next);
+    if (MULTI && !ACTOR) load_inputs(0, rin_next);
+    if constexpr (ACTOR) {
+        constexpr int D = 3 * N + 2;
+        for (int i = tid; i < 2 * bsx_actor::SMALL / 4; i += SPB) {
+            const int ag = i / (bsx_actor::SMALL / 4), j = i - ag * (bsx_actor::SMALL / 4);
+            reinterpret_cast<float4*>(s_small)[i] =
+                reinterpret_cast<const float4*>(p.aw + size_t(ag) * bsx_actor::blob_floats(D) + bsx_actor::off_small(D))[j];
+        }
+        // the observations the rollout starts from (obs[0]): this wave's rows are one contiguous block
+        const int64_t e_first = int64_t(blockIdx.x) * EPB;
+        const int64_t nfl = min(int64_t(SPB), (p.E - e_first) * A) * D;
+        for (int i = tid; i < SPB * D; i += SPB) s_obs[i] = i < nfl ? p.obs0[size_t(e_first) * A * D + i] : -1.0f;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // A tick is an MFMA phase (actor) followed by a VALU / memory phase (step), and the waves that share a SIMD start
+        // together and stay in step: both queue for the matrix core, then both for the vector ALU.  Holding back every
+        // second wave slot by about half a tick puts them in opposite phases for the whole launch.
+        uint32_t hw_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        if (hw_id & 1u) {                                // HW_ID[3:0] = wave slot within the SIMD
+            for (int i = 0; i < ROLLOUT_STAGGER; ++i) __builtin_amdgcn_s_sleep(64);   // 64 x 64 cycles each
+        }
+    }
 
     for (int tk = 0; tk < (MULTI ? p.T : 1); ++tk) {
     // In the tick loop the compiler would hoist everything loop-invariant -- 36 row addresses, the Philox key schedule,
@@ -396,6 +431,33 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
         }
     }
     if (u_t) uu_in = rin.uu;                             // uniform branch
+    if constexpr (ACTOR) {
+        // ---- actions = argmax(actor(obs)) (maddpg/agent.py:25-33, battle_env.py:327-328), rows straight from LDS
+        constexpr int D = 3 * N + 2;
+        const int hh = lane >> 5, c = lane & 31;
+        float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma nounroll
+        for (int nt = 0; nt < 2; ++nt) {                 // one tile at a time: its 64 weight registers are reused by the next
+            const float4 o = bsx_actor::tile_forward(p.aw + size_t(nt) * bsx_actor::blob_floats(D), s_small + nt * bsx_actor::SMALL, D, lane,
+                                                     [&](int k) { return k < D ? s_obs[(2 * c + nt) * D + k] : 0.f; });
+            // lower half finishes the red rows, upper half the blue ones: lane l owns row (game c, agent hh)
+            if (hh == nt) r4 = o;
+        }
+        const float4 b3 = *reinterpret_cast<const float4*>(s_small + hh * bsx_actor::SMALL + 6 * bsx_actor::H + bsx_actor::H * bsx_actor::NA);
+        const int64_t er_ = int64_t(blockIdx.x) * EPB + c;
+        const bool row_ok = er_ < p.E;
+        const size_t row = size_t(row_ok ? er_ : p.E - 1) * A + hh;
+        const uint64_t aseq = p.aseq + (p.aseq_base ? *p.aseq_base : 0ull) + uint64_t(tk);
+        const bool game_over = __shfl(er.done, 2 * c) != 0;
+        r4 = bsx_actor::finish_row(r4, b3, p.nz, p.aseed, aseq, row, game_over, row_ok);
+        if (row_ok) reinterpret_cast<float4*>(p.scores + int64_t(tk) * p.scores_ts)[row] = r4;
+        const float v[4] = {r4.x, r4.y, r4.z, r4.w};
+        int am = 0;
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+            if (!(v[am] != v[am]) && (v[i] > v[am] || v[i] != v[i])) am = i;
+        act = __shfl(am, ((lane & 1) << 5) | (lane >> 1));          // plane (game L>>1, agent L&1) <- lane 32*(L&1) + (L>>1)
+    }
 
     // ================= T1: the one dependent round trip: per-update steps of my LIVE bullets ========================
     const uint32_t live0 = live;
@@ -422,7 +484,7 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
         iw[j] = *(has ? &p.st.bxy[size_t(j) * EAt + gt] : reinterpret_cast<const uint32_t*>(p.st.lut));
         idd[j] = *(has ? &p.st.bd[size_t(j) * EAt + gt] : p.st.lut);
     }
-    if (MULTI && tk + 1 < p.T) load_inputs(tk + 1, rin_next);   // behind this tick's own loads: nothing waits for it before the tick ends
+    if (MULTI && !ACTOR && tk + 1 < p.T) load_inputs(tk + 1, rin_next);   // behind this tick's own loads: nothing waits for it before the tick ends
     const bool alive0 = valid && hp > 0;
     STAMP(1);
 
@@ -746,6 +808,7 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        STAMP(9);
     }
     }   // tick loop
 }
@@ -933,6 +996,8 @@ int launch_step(void* state, int64_t E, int n, const void* actions, int action_k
     a.obs = obs; a.rew = rew; a.done = done; a.env_done = env_done; a.winner = winner;
     a.cfg = *cfg; a.flags = flags; a.seed = seed; a.env_offset = env_offset; a.tie_tick = bsx_tie_tick(n);
     const int64_t EA = E * 2 * n;
+    a.aw = nullptr; a.obs0 = nullptr; a.scores = nullptr; a.scores_ts = 0; a.nz = BsxActorNoise{0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr};
+    a.aseed = 0; a.aseq = 0; a.aseq_base = nullptr;
     a.T = T;
     a.act_tb = EA * (CONT ? (action_kind == BSX_ACT_F32 ? 12 : 24) : (action_kind == BSX_ACT_I32 ? 4 : 16));
     a.u_ts = EA;
@@ -1044,6 +1109,31 @@ int bsx_step_many_continuous(void* state, int64_t E, int n, int T, const void* a
     if (T < 1 || !actions) return BSX_E_ARG;
     return launch_step<true>(state, E, n, actions, action_kind, u, obs, rew, done, env_done, winner, cfg, flags, seed,
                              env_offset, stream, T, store_all);
+}
+
+int bsx_rollout_discrete(void* state, int64_t E, int n, int T, const float* weights, float* obs, float* scores, float* rew,
+                         uint8_t* done, uint8_t* env_done, uint8_t* winner, const BsxRewards* cfg, uint32_t flags,
+                         const BsxActorNoise* noise, uint64_t actor_seed, uint64_t seq, const uint64_t* seq_base, uint64_t seed,
+                         int64_t env_offset, void* stream) {
+    if (!state || E <= 0 || E > BSX_MAX_E || n != 1 || T < 1 || T > BSX_MAX_T || !weights || !obs || !scores || !rew || !done || !cfg)
+        return BSX_E_ARG;
+    if (flags & BSX_F_EMPTY_CALL) return BSX_E_ARG;
+    if (!aligned(state, 256) || !aligned(weights, 16) || !aligned(scores, 16) || !aligned(obs, 4) || !aligned(rew, 4)) return BSX_E_ALIGN;
+    BsxActorNoise nz = {0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr};
+    if (noise) nz = *noise;
+    if (nz.ou_scale > 0.f && (!nz.ou_state || !aligned(nz.ou_state, 16))) return nz.ou_state ? BSX_E_ALIGN : BSX_E_ARG;
+    const int64_t EA = E * 2 * n, D = 3 * n + 2;
+    StepArgs a;
+    a.st = state_ptrs(state, E, n);
+    a.E = E; a.n = n; a.actions = nullptr; a.action_kind = BSX_ACT_LOGITS_F32; a.u = nullptr;
+    a.obs = obs + EA * D; a.rew = rew; a.done = done; a.env_done = env_done; a.winner = winner;
+    a.cfg = *cfg; a.flags = flags; a.seed = seed; a.env_offset = env_offset; a.tie_tick = bsx_tie_tick(n);
+    a.T = T; a.act_tb = 0; a.u_ts = 0; a.obs_ts = EA * D; a.rew_ts = EA; a.done_ts = EA;
+    a.aw = weights; a.obs0 = obs; a.scores = scores; a.scores_ts = EA * 4; a.nz = nz; a.aseed = actor_seed; a.aseq = seq;
+    a.aseq_base = seq_base;
+    hipLaunchKernelGGL((bsx_step_kernel<1, false, true, true>), dim3(grid_for(E, n, SPB)), dim3(SPB), 0,
+                       static_cast<hipStream_t>(stream), a);
+    return int(hipGetLastError());
 }
 
 int bsx_observe(void* state, int64_t E, int n, float* obs, void* stream) {

@@ -123,6 +123,21 @@ class FusedActor:
     def refresh(self):
         self.actor.pack(out=self.weights)
 
+    def noise_struct(self, E, noise_std=0.0, ou=None):
+        """BsxActorNoise for E games (None = no noise); validates the OU state tensor."""
+        if not (noise_std > 0.0 or ou is not None):
+            return None
+        nz = _lib.BsxActorNoise(float(noise_std), 0.0, 0.15, 0.2, 0.0, None, None)
+        if ou is not None:
+            st = ou["state"]
+            if st.dtype != torch.float32 or tuple(st.shape) != (E, 2 * self.n, 4) or not st.is_contiguous():
+                raise ValueError("ou['state'] must be a contiguous float32 [E, A, 4] tensor")
+            nz.ou_scale, nz.ou_theta = float(ou["scale"]), float(ou.get("theta", 0.15))
+            nz.ou_sigma, nz.ou_mu = float(ou.get("sigma", 0.2)), float(ou.get("mu", 0.0))
+            nz.ou_state = st.data_ptr()
+            nz.env_done = ou["env_done"].data_ptr() if ou.get("env_done") is not None else None
+        return nz
+
     def forward_into(self, obs, scores, noise_std=0.0, seq=None, seq_base=None, ou=None):
         """obs f32 [E, A, D] (contiguous) -> scores f32 [E, A, 4] (contiguous, 16-byte aligned), on the current stream.
         noise_std: Gaussian exploration noise.  ou: optional dict(scale, state[, theta, sigma, mu, env_done]) for the
@@ -133,17 +148,7 @@ class FusedActor:
         if seq is None:
             self.seq += 1
             seq = self.seq
-        nz = None
-        if noise_std > 0.0 or ou is not None:
-            nz = _lib.BsxActorNoise(float(noise_std), 0.0, 0.15, 0.2, 0.0, None, None)
-            if ou is not None:
-                st = ou["state"]
-                if st.dtype != torch.float32 or tuple(st.shape) != (E, 2 * self.n, 4) or not st.is_contiguous():
-                    raise ValueError("ou['state'] must be a contiguous float32 [E, A, 4] tensor")
-                nz.ou_scale, nz.ou_theta = float(ou["scale"]), float(ou.get("theta", 0.15))
-                nz.ou_sigma, nz.ou_mu = float(ou.get("sigma", 0.2)), float(ou.get("mu", 0.0))
-                nz.ou_state = st.data_ptr()
-                nz.env_done = ou["env_done"].data_ptr() if ou.get("env_done") is not None else None
+        nz = self.noise_struct(E, noise_std, ou)
         _lib.check(self._lib.bsx_actor_forward(self.weights.data_ptr(), obs.data_ptr(), scores.data_ptr(), E, self.n,
                                                _lib.ctypes.byref(nz) if nz is not None else None, self.seed, int(seq),
                                                seq_base.data_ptr() if seq_base is not None else None,
@@ -168,7 +173,7 @@ class PolicyRollout:
     (ou_scale = main.py's curr_noise; utils/noise.py), whose state is one more [E, A, 4] tensor updated inside the actor
     kernel and restarted per game; then clamp(-1, 1) as maddpg/agent.py:31 does."""
 
-    def __init__(self, env, actor, T, noise_std=0.0, fused=True, seed=0, opponent=None, ou_scale=0.0):
+    def __init__(self, env, actor, T, noise_std=0.0, fused=True, seed=0, opponent=None, ou_scale=0.0, one_launch=False):
         """actor: a StackedActor.  fused=True evaluates it with the hand-written HIP kernel (FusedActor), False with
         torch ops (the fp32 reference of the same op).  opponent: an `instinct.Team` that plays its team's planes
         instead of the actor (the reference's training setup, main.py:119-122: learned red vs scripted blue): its
@@ -186,6 +191,12 @@ class PolicyRollout:
                 raise ValueError("ou_scale needs the fused actor")
             self.ou = dict(scale=float(ou_scale), env_done=env._env_done,
                            state=torch.zeros((env.n_envs, env._A, 4), dtype=torch.float32, device=env.device))
+        # one_launch: all T ticks (actor -> step) in ONE kernel (bsx_rollout_discrete) instead of 2T launches in a graph:
+        # observation rows stay in LDS between the step and the actor, game state in registers / L2.  Discrete 1v1, no
+        # scripted opponent; same transitions, bit for bit.
+        self.one_launch = bool(one_launch)
+        if self.one_launch and (not fused or opponent is not None or env.n_agents != 1):
+            raise ValueError("one_launch needs the fused actor, 1v1 and no scripted opponent")
         self._seq_base = torch.zeros(1, dtype=torch.int64, device=env.device)
         E, A, D, dev = env.n_envs, env._A, env.obs_size, env.device
         self.obs = torch.empty((T + 1, E, A, D), dtype=torch.float32, device=dev)
@@ -235,8 +246,13 @@ class PolicyRollout:
 
     def _body(self):
         self.obs[0].copy_(self.obs[self.T])            # continue where the previous rollout ended
-        for t in range(self.T):
-            self._tick(t)
+        if self.one_launch:
+            nz = self.fused.noise_struct(self.env.n_envs, self.noise_std, self.ou)
+            self.env._launch_rollout(self.T, self.fused.weights.data_ptr(), self.obs.data_ptr(), self.scores.data_ptr(),
+                                     self.rew.data_ptr(), self._done.data_ptr(), nz, self.fused.seed, 0, self._seq_base.data_ptr())
+        else:
+            for t in range(self.T):
+                self._tick(t)
         self._seq_base.add_(self.T)                    # fresh exploration-noise keys for the next run
 
     def run(self):

@@ -400,6 +400,43 @@ def test_rollout_with_ou_noise_restarts_per_game():
     assert int(env.counters()[:, 0].sum()) > 0                    # games did finish (and restart) along the way
 
 
+@pytest.mark.parametrize("noise", ["none", "gaussian", "ou"])
+def test_one_launch_rollout_equals_two_kernel_rollout(noise):
+    """bsx_rollout_discrete (T ticks of actor -> step in ONE launch, observation rows handed over in LDS) against the
+    two-kernel form (bsx_actor_forward + bsx_step_discrete per tick): the same transitions bit for bit -- observations,
+    the actors' score vectors (incl. exploration noise and OU state), rewards, dones, final game state -- over several
+    runs, across auto-resets, with a ragged last wavefront."""
+    from deep_rl_battlespace_amd.rollout import PolicyRollout, StackedActor
+    E, n, T = 4100, 1, 50
+    torch.manual_seed(3)
+    actor = StackedActor(2, 5, 4, device="cuda")
+    with torch.no_grad():
+        actor.w3.mul_(60.0); actor.g1.uniform_(0.5, 1.5); actor.h1.uniform_(-0.3, 0.3)
+    kw = dict(noise_std=0.3) if noise == "gaussian" else (dict(ou_scale=0.4) if noise == "ou" else {})
+    ros = []
+    for one in (False, True):
+        env = _env(n_agents=n, n_envs=E, seed=31, auto_reset=True); env.reset()
+        ro = PolicyRollout(env, actor, T, seed=7, one_launch=one, **kw); ro.start()
+        if one:
+            ro.capture()
+        ros.append(ro)
+    a, b = ros
+    for rep in range(4):
+        a.run(); b.run()
+        torch.cuda.synchronize()
+        assert torch.equal(a.obs, b.obs), rep
+        assert torch.equal(a.scores, b.scores), rep
+        assert torch.equal(a.rew, b.rew) and torch.equal(a.done, b.done), rep
+        if noise == "ou":
+            assert torch.equal(a.ou["state"], b.ou["state"]), rep
+    sa, sb = a.env.export_state(), b.env.export_state()
+    for k in ("px", "py", "pdir", "php", "bhp", "tick", "env_done", "winner", "bl_live", "counters"):
+        assert torch.equal(sa[k], sb[k]), k
+    assert torch.equal(a.env.env_done, b.env.env_done)
+    assert int(a.env.counters()[:, 0].sum()) > E                 # the runs crossed game ends
+    assert len(torch.unique(a.scores.argmax(-1))) >= 3
+
+
 def test_rollout_into_replay_buffer_on_device():
     """f-1 -> f-3: a rollout's transitions go into the device replay ring without touching the host; a sampled batch is
     self-consistent (next-state of a stored row is the state the env produced one tick later)."""

@@ -6,7 +6,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/diag
 SRC=deep-rl-battlespace_amd/csrc
 cp $SRC/libbattlespace_hip.so /tmp/product.so
-hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=fast -I include -c $SRC/bsx_actor.hip -o /tmp/actor.o
+hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=off -I include -c $SRC/bsx_actor.hip -o /tmp/actor.o
 for d in ${1:-"8 1 2"}; do
   hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=off -mllvm -disable-machine-licm -DBSX_DIAG=$d -I include -c $SRC/bsx_kernels.hip -o /tmp/k.o
   hipcc --offload-arch=gfx950 -shared -fPIC /tmp/k.o /tmp/actor.o -o $SRC/libbattlespace_hip.so

@@ -7,7 +7,7 @@ lib = os.path.join(src, "libbattlespace_hip.so")
 os.rename(lib, lib + ".product")
 try:
     objs = []
-    for f, extra in (("bsx_kernels.hip", ["-ffp-contract=off", "-mllvm", "-disable-machine-licm", "-DBSX_STAMPS"]), ("bsx_actor.hip", ["-ffp-contract=fast"])):
+    for f, extra in (("bsx_kernels.hip", ["-ffp-contract=off", "-mllvm", "-disable-machine-licm", "-DBSX_STAMPS"]), ("bsx_actor.hip", ["-ffp-contract=off"])):
         o = f"/tmp/stamps_{f}.o"
         subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", *extra, "-I", os.path.join(ROOT, "include"),
                         "-c", os.path.join(src, f), "-o", o], check=True)
@@ -18,6 +18,7 @@ try:
     E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     cont = len(sys.argv) > 3 and sys.argv[3] == 'cont'
+    mode = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] in ("many", "rollout") else "step"
     env = bsx.parallel_env(n_agents=n, n_envs=E, auto_reset=True, seed=1, continuous_actions=cont)
     env.reset()
     L = _lib.load()
@@ -32,10 +33,23 @@ try:
     assert L.bsx_debug_set_stamps(buf.data_ptr()) == 0
     tot = np.zeros(8); span = []; pre = 0.0
     reps = 0
+    if mode == "rollout":
+        from deep_rl_battlespace_amd.rollout import PolicyRollout, StackedActor
+        actor = StackedActor(2 * n, 3 * n + 2, 4, device="cuda")
+        with torch.no_grad():
+            actor.w3.mul_(100.0)
+        ro = PolicyRollout(env, actor, 16, noise_std=0.1, one_launch=True); ro.start()
+    fence = 0.0
     for t in range(60, 64):
-        env.step_batch(acts[t]); torch.cuda.synchronize()
+        if mode == "rollout":
+            ro.run()                      # stamps of the LAST of the 16 ticks survive
+        elif mode == "many":
+            env.step_many(acts[:16].contiguous(), store=True)
+        else:
+            env.step_batch(acts[t])
+        torch.cuda.synchronize()
         s10 = buf.cpu().numpy().reshape(waves, 10).astype(np.float64)
-        s = s10[:, :8]; pre += (s10[:, 0] - s10[:, 8]).mean()
+        s = s10[:, :8]; pre += (s10[:, 0] - s10[:, 8]).mean(); fence += (s10[:, 9] - s10[:, 7]).mean()
         d = np.diff(s, axis=1)
         tot[:7] += d.mean(0); reps += 1
         span.append(((s[:, 7].max() - s[:, 0].min()), (s[:, 7] - s[:, 0]).mean(), (s[:, 0].max() - s[:, 0].min())))
@@ -45,6 +59,8 @@ try:
     print(f"  {'kernel entry -> first kernarg use (p.E)':40s} {pre / reps * 10:9.1f} ns")
     for nme, v in zip(names, tot[:7]):
         print(f"  {nme:40s} {v*10:9.1f} ns")
+    if mode != "step":
+        print(f"  {'end-of-tick fence (stores acknowledged)':40s} {fence / reps * 10:9.1f} ns   [mode {mode}: last tick of 16; the first phase includes the actor in rollout mode]")
     sp = np.asarray(span).mean(0)
     print(f"  wave lifetime mean {sp[1]*10:.0f} ns; first-start to last-end {sp[0]*10:.0f} ns; start skew {sp[2]*10:.0f} ns")
 finally:
