@@ -36,8 +36,9 @@ __host__ __device__ constexpr int blob_floats(int D) { return off_b3(D) + NA; }
 __device__ inline uint4 philox4x32_10(uint4 ctr, uint2 key) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, ctr.x), lo0 = 0xD2511F53u * ctr.x;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, ctr.z), lo1 = 0xCD9E8D57u * ctr.z;
+        // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a mul_hi + mul_lo pair: both are quarter rate
+        const uint64_t p0 = uint64_t(0xD2511F53u) * ctr.x, p1 = uint64_t(0xCD9E8D57u) * ctr.z;
+        const uint32_t hi0 = uint32_t(p0 >> 32), lo0 = uint32_t(p0), hi1 = uint32_t(p1 >> 32), lo1 = uint32_t(p1);
         ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
         key.x += 0x9E3779B9u; key.y += 0xBB67AE85u;
     }
