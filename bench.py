@@ -212,8 +212,12 @@ def main():
         env, dtm, kmm, Gm = measure(n, E, K, W, "many", 100)
         achm = b_alg(n) * E * A / (kmm * 1e-3) / 1e9
         multi = {"agent_steps_per_s": round(E * A * K / dtm, 1), "us_per_tick": round(kmm * 1e3, 3), "ticks_per_launch": Gm,
-                 "roofline_frac": round(achm / HBM_PEAK_GBS, 4), "kernel": f"bsx_step_kernel<{n if n <= 4 else 0},{'true' if args.continuous else 'false'},true>",
+                 "roofline_frac": round(achm / HBM_PEAK_GBS, 4), "kernel": f"bsx_step_kernel<{n if n <= 4 else 0},{'true' if args.continuous else 'false'},true,false>",
                  "note": "not the headline: north_star asks for one kernel per step"}
+        try:
+            multi["traffic_per_tick"] = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[f"E{E}_n{n}_many"]["hbm_bytes_per_tick"]
+        except Exception:
+            multi["traffic_per_tick"] = None
     if world == 1 and not args.no_other_workloads and (n, E) == (1, 65536):
         for tag, (n2, E2, K2) in {"configs[2] 65536 x 4v4": (4, 65536, 400), "1048576 x 1v1 (streaming)": (1, 1048576, 200)}.items():
             del env
@@ -233,9 +237,9 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = f"E{E}_n{n}"
+                key = f"E{E}_n{n}" + ("_many" if args.mode == "many" else "")
                 if key in tj:
-                    traffic = tj[key]["hbm_bytes_per_launch"]
+                    traffic = tj[key]["hbm_bytes_per_tick" if args.mode == "many" else "hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
         out = {
@@ -248,7 +252,7 @@ def main():
                        "graph_len": G if args.mode == "graph" else None, "parallelism": f"{world} independent env shards, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": f"bsx_step_kernel<{n if n <= 4 else 0},{'true' if args.continuous else 'false'},{'true' if args.mode == 'many' else 'false'}>", "avg_launch_us": round(kernel_ms * 1e3, 3),
+                         "kernel": f"bsx_step_kernel<{n if n <= 4 else 0},{'true' if args.continuous else 'false'},{'true' if args.mode == 'many' else 'false'},false>", "avg_launch_us": round(kernel_ms * 1e3, 3),
                          "algorithmic_bytes_per_launch": round(bytes_per_launch), "bytes_per_agent_step": round(b_alg(n), 2)},
             "games_finished": int(games[0]), "ties": int(games[1]), "red_wins": int(games[2]), "blue_wins": int(games[3]),
         }

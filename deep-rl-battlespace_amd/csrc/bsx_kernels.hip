@@ -262,9 +262,6 @@ __device__ inline void spawn_plane(uint64_t seed, int64_t genv, uint32_t stream,
 }
 
 enum Mode : int { M_INERT = 0, M_TIE = 1, M_PHYS = 2, M_RESET = 3 };
-#ifndef ROLLOUT_STAGGER
-#define ROLLOUT_STAGGER 3
-#endif
 
 // ---------------------------------------------------------------------------------------------- the step kernel
 // Record (un)packing on raw 16-byte words: keeps the loads as single dwordx4 instructions with no byte shuffling.
@@ -301,7 +298,7 @@ __device__ inline void obs_pair(int x, int y, double dir, int tx, int ty, float&
 // no cache maintenance: same CU, same L1); the state stays in the L2 instead of crossing a kernel boundary (write-back +
 // invalidate + a cold first round trip) every tick.
 // ACTOR (1v1, discrete, MULTI): the caller's whole rollout loop `for t: actions = actor(obs); obs, rew, done = step(actions)`
-// (main.py:176-181) in one launch.  A wave's 64 observation rows never leave the CU: the step leaves them in LDS, the
+// (main.py:177-181) in one launch.  A wave's 64 observation rows never leave the CU: the step leaves them in LDS, the
 // actor (bsx_actor_core.h, MFMA) reads them there as its B operands -- tile 0 = the 32 red planes, tile 1 = the 32 blue
 // ones, each with its own weights --, finishes row (lane & 31) of agent (lane >> 5), and one cross-lane move hands every
 // plane its arg-max.
@@ -376,14 +373,6 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        // A tick is an MFMA phase (actor) followed by a VALU / memory phase (step), and the waves that share a SIMD start
-        // together and stay in step: both queue for the matrix core, then both for the vector ALU.  Holding back every
-        // second wave slot by about half a tick puts them in opposite phases for the whole launch.
-        uint32_t hw_id;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
-        if (hw_id & 1u) {                                // HW_ID[3:0] = wave slot within the SIMD
-            for (int i = 0; i < ROLLOUT_STAGGER; ++i) __builtin_amdgcn_s_sleep(64);   // 64 x 64 cycles each
-        }
     }
 
     for (int tk = 0; tk < (MULTI ? p.T : 1); ++tk) {

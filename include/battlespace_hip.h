@@ -158,7 +158,7 @@ int bsx_actor_forward(const float* weights, const float* obs, float* scores, int
                       uint64_t seed, uint64_t seq, const uint64_t* seq_base, void* stream);
 
 /* The caller's rollout loop -- `for t in range(T): actions = actor(obs) (+ noise, clamp); obs, rew, done = step(actions)`
- * (main.py:176-181 with maddpg/agent.py:25-33) -- in ONE launch: T x (bsx_actor_forward -> bsx_step_discrete with
+ * (main.py:177-181 with maddpg/agent.py:25-33) -- in ONE launch: T x (bsx_actor_forward -> bsx_step_discrete with
  * BSX_ACT_LOGITS_F32), same results bit for bit.  A wavefront keeps its games' observation rows in LDS (the step writes
  * them, the actor's MFMA reads them), their state in registers / L2, and walks them through all T ticks.
  *   obs     float32 [T+1][E*A*D]: obs[0] = the observations to start from (in), obs[t+1] = after tick t (out)

@@ -32,7 +32,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcc"):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(cc[0])):
-        if f"bsx_step_kernel<{n if n <= 4 else 0}, false, false>" in r["Kernel_Name"] and int(r["Grid_Size"]) == grid_threads:
+        if f"bsx_step_kernel<{n if n <= 4 else 0}, false, false, false>" in r["Kernel_Name"] and int(r["Grid_Size"]) == grid_threads:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     kt = glob.glob(os.path.join(src, sub, "*", "*_kernel_trace.csv"))
     du = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(kt[0])) if "bsx_step_kernel" in r["Kernel_Name"]]
@@ -50,4 +50,26 @@ if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
                                "this kernel with a known-bytes workload (profiles/r01_traffic_calibration.json: true/counter = "
                                "1.993 for FETCH_SIZE, 1.001 for WRITE_SIZE)"}
     json.dump(tj, open(tpath, "w"), indent=1)
+# multi-tick launch and one-launch rollout (tools/profile_many.sh)
+for sub, name in (("many_stats", "many_kernel_stats"), ("rollout_stats", "rollout_kernel_stats")):
+    ks = glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
+    if ks:
+        shutil.copy(ks[0], os.path.join(dst, f"{tag}_{name}.csv"))
+for f in ("many_rollout_pmc_summary.json", "rollout_graph.json", "rollout_one_launch.json", "rollout_graph_4v4.json"):
+    if os.path.exists(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{f}"))
+mp = os.path.join(src, "many_rollout_pmc_summary.json")
+if os.path.exists(mp):
+    mj = json.load(open(mp))
+    if "FETCH_SIZE" in mj.get("many_pmc_fetch", {}) and "WRITE_SIZE" in mj.get("many_pmc_write", {}):
+        ticks = 100                                          # bench.py --mode many: ticks per launch
+        f_kib, w_kib = mj["many_pmc_fetch"]["FETCH_SIZE"]["mean_per_launch"], mj["many_pmc_write"]["WRITE_SIZE"]["mean_per_launch"]
+        tpath = os.path.join(dst, "traffic.json")
+        tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        tj[f"E{E}_n{n}_many"] = {"hbm_bytes_per_launch": int((2 * f_kib + w_kib) * 1024), "ticks_per_launch": ticks,
+                                 "hbm_bytes_per_tick": int((2 * f_kib + w_kib) * 1024 / ticks), "fetch_size_kib_raw": f_kib,
+                                 "write_size_kib_raw": w_kib, "series": tag,
+                                 "note": "bench.py --mode many (bsx_step_many_discrete, 100 ticks per launch, every tick's outputs stored); "
+                                         "same counters and corrections as the per-step entry"}
+        json.dump(tj, open(tpath, "w"), indent=1)
 print(json.dumps(summary, indent=1)[:1500])
