@@ -5,10 +5,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libbattlespace_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 BULLET_SLOTS = 12
 MAX_N = 16
 MAX_T = 65535
+ACTOR_F32, ACTOR_BF16X3 = 0, 1
 F_AUTO_RESET = 1
 F_EMPTY_CALL = 2
 ACT_I32, ACT_LOGITS_F32 = 0, 1
@@ -53,7 +54,7 @@ SIGNATURES = {
                                        c_void_p, c_void_p, ctypes.POINTER(BsxRewards), c_uint32, c_int, c_uint64, c_int64, c_void_p]),
     "bsx_step_many_continuous": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, ctypes.POINTER(BsxRewards), c_uint32, c_int, c_uint64, c_int64, c_void_p]),
-    "bsx_rollout_discrete": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+    "bsx_rollout_discrete": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, ctypes.POINTER(BsxRewards), c_uint32, ctypes.POINTER(BsxActorNoise), c_uint64,
                                      c_uint64, c_void_p, c_uint64, c_int64, c_void_p]),
     "bsx_observe": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
@@ -62,7 +63,7 @@ SIGNATURES = {
     "bsx_instinct_discrete": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     "bsx_instinct_continuous": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_uint64, c_uint64, c_void_p, c_void_p]),
     "bsx_actor_blob_floats": (c_int, [c_int, ctypes.POINTER(c_int)]),
-    "bsx_actor_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, ctypes.POINTER(BsxActorNoise), c_uint64, c_uint64,
+    "bsx_actor_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, ctypes.POINTER(BsxActorNoise), c_uint64, c_uint64,
                                   c_void_p, c_void_p]),
 }
 

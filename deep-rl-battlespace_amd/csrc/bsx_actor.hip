@@ -40,6 +40,9 @@ struct ActorArgs {
     int64_t E; int A; int D; BsxActorNoise nz; uint64_t seed; uint64_t seq; const uint64_t* seq_base;
 };
 
+// BF16X3 = false: exact f32, both 32-row tiles of the wave interleaved (four independent accumulators).
+// BF16X3 = true: the 64 x 64 layer as split-bf16 MFMAs (bsx_actor_core.h), one tile after the other.
+template <bool BF16X3>
 __global__ __launch_bounds__(TPB) void bsx_actor_kernel(const ActorArgs p) {
 #pragma clang fp contract(fast)
     const int D = p.D, Dp = dpad(D);
@@ -53,85 +56,100 @@ __global__ __launch_bounds__(TPB) void bsx_actor_kernel(const ActorArgs p) {
     for (int i = tid; i < SMALL / 4; i += TPB)
         reinterpret_cast<float4*>(s_small)[i] = reinterpret_cast<const float4*>(W + off_small(D))[i];
 
-    // the 64 x 64 layer's A operands: 64 VGPRs, coalesced 16-byte loads, in flight while layer 1 runs
-    float4 w2[2][2][4];
-#pragma unroll
-    for (int mo = 0; mo < 2; ++mo)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int vq = 0; vq < 4; ++vq)
-                w2[mo][mt][vq] = reinterpret_cast<const float4*>(W + off_w2(D))[((mo * 2 + mt) * 4 + vq) * 64 + lane];
-
     const int64_t row0 = (int64_t(blockIdx.x) * (TPB / 64) + wave) * ROWS_PER_WAVE;   // first env of this wave
-    __syncthreads();
-    const float* sm = s_small + hh * 32;      // this lane half's [mo][v] slice of each 64-float vector ([hh][mo][v])
-
-    // ---- layer 1: acc1[mo][nt] = b1 + W1^T * X^T
-    f32x16 acc1[2][2];
-#pragma unroll
-    for (int mo = 0; mo < 2; ++mo)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) { acc1[mo][0][v] = sm[0 * H + mo * 16 + v]; acc1[mo][1][v] = acc1[mo][0][v]; }
-    const float* xrow[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int64_t en = row0 + 32 * nt + c;
-        xrow[nt] = p.obs + (size_t(en < p.E ? en : p.E - 1) * p.A + a) * D;
-    }
-    for (int s = 0; s < Dp / 2; ++s) {
-        const int k = 2 * s + hh;
-        const float a0 = W[(0 * (Dp / 2) + s) * 64 + lane], a1 = W[(1 * (Dp / 2) + s) * 64 + lane];
-        const float b0 = k < D ? xrow[0][k] : 0.f, b1 = k < D ? xrow[1][k] : 0.f;
-        acc1[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc1[0][0], 0, 0, 0);
-        acc1[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc1[0][1], 0, 0, 0);
-        acc1[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc1[1][0], 0, 0, 0);
-        acc1[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc1[1][1], 0, 0, 0);
-    }
-    ln_relu_tile(acc1[0][0], acc1[1][0], sm + 1 * H, sm + 2 * H);
-    ln_relu_tile(acc1[0][1], acc1[1][1], sm + 1 * H, sm + 2 * H);
-
-    // ---- layer 2: acc2[mo][nt] = b2 + W2^T * H1^T, the K index running over layer 1's accumulator registers
-    f32x16 acc2[2][2];
-#pragma unroll
-    for (int mo = 0; mo < 2; ++mo)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) { acc2[mo][0][v] = sm[3 * H + mo * 16 + v]; acc2[mo][1][v] = acc2[mo][0][v]; }
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const float4 q0 = w2[0][mt][v >> 2], q1 = w2[1][mt][v >> 2];
-            const float wa0 = (v & 3) == 0 ? q0.x : ((v & 3) == 1 ? q0.y : ((v & 3) == 2 ? q0.z : q0.w));
-            const float wa1 = (v & 3) == 0 ? q1.x : ((v & 3) == 1 ? q1.y : ((v & 3) == 2 ? q1.z : q1.w));
-            acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa0, acc1[mt][0][v], acc2[0][0], 0, 0, 0);
-            acc2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa0, acc1[mt][1][v], acc2[0][1], 0, 0, 0);
-            acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa1, acc1[mt][0][v], acc2[1][0], 0, 0, 0);
-            acc2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa1, acc1[mt][1][v], acc2[1][1], 0, 0, 0);
+    float4 o[2];
+    if constexpr (BF16X3) {
+        __syncthreads();
+        o[0] = make_float4(0.f, 0.f, 0.f, 0.f); o[1] = o[0];
+#pragma nounroll
+        for (int nt = 0; nt < 2; ++nt) {                 // rolled: one tile's registers at a time
+            const int64_t en = row0 + 32 * nt + c;
+            const float* xr = p.obs + (size_t(en < p.E ? en : p.E - 1) * p.A + a) * D;
+            const float* Wn = W;
+            asm volatile("" : "+s"(Wn));                 // keeps the weight loads inside the loop (hoisted, they double the registers)
+            const float4 t = tile_forward<true>(Wn, s_small, D, lane, [&](int k) { return k < D ? xr[k] : 0.f; });
+            if (nt == 0) o[0] = t; else o[1] = t;
         }
-    ln_relu_tile(acc2[0][0], acc2[1][0], sm + 4 * H, sm + 5 * H);
-    ln_relu_tile(acc2[0][1], acc2[1][1], sm + 4 * H, sm + 5 * H);
+    } else {
+        // the 64 x 64 layer's A operands: 64 VGPRs, coalesced 16-byte loads, in flight while layer 1 runs
+        float4 w2[2][2][4];
+    #pragma unroll
+        for (int mo = 0; mo < 2; ++mo)
+    #pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+    #pragma unroll
+                for (int vq = 0; vq < 4; ++vq)
+                    w2[mo][mt][vq] = reinterpret_cast<const float4*>(W + off_w2(D))[((mo * 2 + mt) * 4 + vq) * 64 + lane];
 
-    // ---- head: 64 -> 4 on the vector pipe; each lane sums its 32 neurons, the partner lane l^32 has the other 32
-    const float4* w3 = reinterpret_cast<const float4*>(s_small + 6 * H) + hh * 32;   // [hh][mt][v] float4
-    float4 o[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const float4 ww = w3[mt * 16 + v];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const float hv = acc2[mt][nt][v];
-                o[nt].x = fmaf(hv, ww.x, o[nt].x); o[nt].y = fmaf(hv, ww.y, o[nt].y);
-                o[nt].z = fmaf(hv, ww.z, o[nt].z); o[nt].w = fmaf(hv, ww.w, o[nt].w);
+        __syncthreads();
+        const float* sm = s_small + hh * 32;      // this lane half's [mo][v] slice of each 64-float vector ([hh][mo][v])
+
+        // ---- layer 1: acc1[mo][nt] = b1 + W1^T * X^T
+        f32x16 acc1[2][2];
+    #pragma unroll
+        for (int mo = 0; mo < 2; ++mo)
+    #pragma unroll
+            for (int v = 0; v < 16; ++v) { acc1[mo][0][v] = sm[0 * H + mo * 16 + v]; acc1[mo][1][v] = acc1[mo][0][v]; }
+        const float* xrow[2];
+    #pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int64_t en = row0 + 32 * nt + c;
+            xrow[nt] = p.obs + (size_t(en < p.E ? en : p.E - 1) * p.A + a) * D;
+        }
+        for (int s = 0; s < Dp / 2; ++s) {
+            const int k = 2 * s + hh;
+            const float a0 = W[(0 * (Dp / 2) + s) * 64 + lane], a1 = W[(1 * (Dp / 2) + s) * 64 + lane];
+            const float b0 = k < D ? xrow[0][k] : 0.f, b1 = k < D ? xrow[1][k] : 0.f;
+            acc1[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc1[0][0], 0, 0, 0);
+            acc1[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc1[0][1], 0, 0, 0);
+            acc1[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc1[1][0], 0, 0, 0);
+            acc1[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc1[1][1], 0, 0, 0);
+        }
+        ln_relu_tile(acc1[0][0], acc1[1][0], sm + 1 * H, sm + 2 * H);
+        ln_relu_tile(acc1[0][1], acc1[1][1], sm + 1 * H, sm + 2 * H);
+
+        // ---- layer 2: acc2[mo][nt] = b2 + W2^T * H1^T, the K index running over layer 1's accumulator registers
+        f32x16 acc2[2][2];
+    #pragma unroll
+        for (int mo = 0; mo < 2; ++mo)
+    #pragma unroll
+            for (int v = 0; v < 16; ++v) { acc2[mo][0][v] = sm[3 * H + mo * 16 + v]; acc2[mo][1][v] = acc2[mo][0][v]; }
+    #pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+    #pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const float4 q0 = w2[0][mt][v >> 2], q1 = w2[1][mt][v >> 2];
+                const float wa0 = (v & 3) == 0 ? q0.x : ((v & 3) == 1 ? q0.y : ((v & 3) == 2 ? q0.z : q0.w));
+                const float wa1 = (v & 3) == 0 ? q1.x : ((v & 3) == 1 ? q1.y : ((v & 3) == 2 ? q1.z : q1.w));
+                acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa0, acc1[mt][0][v], acc2[0][0], 0, 0, 0);
+                acc2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa0, acc1[mt][1][v], acc2[0][1], 0, 0, 0);
+                acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa1, acc1[mt][0][v], acc2[1][0], 0, 0, 0);
+                acc2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa1, acc1[mt][1][v], acc2[1][1], 0, 0, 0);
             }
+        ln_relu_tile(acc2[0][0], acc2[1][0], sm + 4 * H, sm + 5 * H);
+        ln_relu_tile(acc2[0][1], acc2[1][1], sm + 4 * H, sm + 5 * H);
+
+        // ---- head: 64 -> 4 on the vector pipe; each lane sums its 32 neurons, the partner lane l^32 has the other 32
+        const float4* w3 = reinterpret_cast<const float4*>(s_small + 6 * H) + hh * 32;   // [hh][mt][v] float4
+        o[0] = make_float4(0.f, 0.f, 0.f, 0.f); o[1] = o[0];
+    #pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+    #pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const float4 ww = w3[mt * 16 + v];
+    #pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const float hv = acc2[mt][nt][v];
+                    o[nt].x = fmaf(hv, ww.x, o[nt].x); o[nt].y = fmaf(hv, ww.y, o[nt].y);
+                    o[nt].z = fmaf(hv, ww.z, o[nt].z); o[nt].w = fmaf(hv, ww.w, o[nt].w);
+                }
+            }
+    #pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            o[nt].x += __shfl_xor(o[nt].x, 32); o[nt].y += __shfl_xor(o[nt].y, 32);
+            o[nt].z += __shfl_xor(o[nt].z, 32); o[nt].w += __shfl_xor(o[nt].w, 32);
         }
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        o[nt].x += __shfl_xor(o[nt].x, 32); o[nt].y += __shfl_xor(o[nt].y, 32);
-        o[nt].z += __shfl_xor(o[nt].z, 32); o[nt].w += __shfl_xor(o[nt].w, 32);
-    }
+}
     // lower half finishes the rows of tile 0, upper half those of tile 1: every lane writes one row
     float4 r4 = hh ? o[1] : o[0];
     const float4 b3 = *reinterpret_cast<const float4*>(s_small + 6 * H + H * NA);
@@ -155,9 +173,10 @@ int bsx_actor_blob_floats(int obs_len, int* floats_per_agent) {
     return 0;
 }
 
-int bsx_actor_forward(const float* weights, const float* obs, float* scores, int64_t E, int n, const BsxActorNoise* noise,
-                      uint64_t seed, uint64_t seq, const uint64_t* seq_base, void* stream) {
+int bsx_actor_forward(const float* weights, const float* obs, float* scores, int64_t E, int n, int precision,
+                      const BsxActorNoise* noise, uint64_t seed, uint64_t seq, const uint64_t* seq_base, void* stream) {
     if (!weights || !obs || !scores || E <= 0 || E > BSX_MAX_E || n < 1 || n > BSX_MAX_N) return BSX_E_ARG;
+    if (precision != BSX_ACTOR_F32 && precision != BSX_ACTOR_BF16X3) return BSX_E_ARG;
     if (!aligned(weights, 16) || !aligned(scores, 16) || !aligned(obs, 4)) return BSX_E_ALIGN;
     BsxActorNoise nz = {0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr};
     if (noise) nz = *noise;
@@ -166,7 +185,8 @@ int bsx_actor_forward(const float* weights, const float* obs, float* scores, int
     ActorArgs a{weights, obs, scores, E, A, D, nz, seed, seq, seq_base};
     const int rows_per_block = (TPB / 64) * ROWS_PER_WAVE;
     const dim3 grid(unsigned((E + rows_per_block - 1) / rows_per_block), unsigned(A)), block(TPB);
-    hipLaunchKernelGGL(bsx_actor_kernel, grid, block, 0, static_cast<hipStream_t>(stream), a);
+    if (precision == BSX_ACTOR_BF16X3) hipLaunchKernelGGL(bsx_actor_kernel<true>, grid, block, 0, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(bsx_actor_kernel<false>, grid, block, 0, static_cast<hipStream_t>(stream), a);
     return int(hipGetLastError());
 }
 

@@ -210,7 +210,7 @@ struct StepArgs {
     // multi-tick launches (bsx_step_many_*): T ticks, per-tick strides of the action / output arrays (0 = same array every tick)
     int T; int64_t act_tb /* bytes */, u_ts, obs_ts, rew_ts, done_ts /* elements */;
     // fused rollout (bsx_rollout_discrete): the actor in front of every tick
-    const float* aw; const float* obs0; float* scores; int64_t scores_ts; BsxActorNoise nz; uint64_t aseed, aseq; const uint64_t* aseq_base;
+    const float* aw; int aprec; const float* obs0; float* scores; int64_t scores_ts; BsxActorNoise nz; uint64_t aseed, aseq; const uint64_t* aseq_base;
 };
 
 // Observation row for one agent from the LDS-staged block (battle_env.py:202-244).
@@ -428,8 +428,11 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
         float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma nounroll
         for (int nt = 0; nt < 2; ++nt) {                 // one tile at a time: its 64 weight registers are reused by the next
-            const float4 o = bsx_actor::tile_forward(p.aw + size_t(nt) * bsx_actor::blob_floats(D), s_small + nt * bsx_actor::SMALL, D, lane,
-                                                     [&](int k) { return k < D ? s_obs[(2 * c + nt) * D + k] : 0.f; });
+            const float* const Wn = p.aw + size_t(nt) * bsx_actor::blob_floats(D);
+            const float* const smn = s_small + nt * bsx_actor::SMALL;
+            auto xb = [&](int k) { return k < D ? s_obs[(2 * c + nt) * D + k] : 0.f; };
+            const float4 o = p.aprec == BSX_ACTOR_BF16X3 ? bsx_actor::tile_forward<true>(Wn, smn, D, lane, xb)      // uniform branch
+                                                         : bsx_actor::tile_forward<false>(Wn, smn, D, lane, xb);
             // lower half finishes the red rows, upper half the blue ones: lane l owns row (game c, agent hh)
             if (hh == nt) r4 = o;
         }
@@ -986,7 +989,7 @@ int launch_step(void* state, int64_t E, int n, const void* actions, int action_k
     a.obs = obs; a.rew = rew; a.done = done; a.env_done = env_done; a.winner = winner;
     a.cfg = *cfg; a.flags = flags; a.seed = seed; a.env_offset = env_offset; a.tie_tick = bsx_tie_tick(n);
     const int64_t EA = E * 2 * n;
-    a.aw = nullptr; a.obs0 = nullptr; a.scores = nullptr; a.scores_ts = 0; a.nz = BsxActorNoise{0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr};
+    a.aw = nullptr; a.aprec = 0; a.obs0 = nullptr; a.scores = nullptr; a.scores_ts = 0; a.nz = BsxActorNoise{0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr};
     a.aseed = 0; a.aseq = 0; a.aseq_base = nullptr;
     a.T = T;
     a.act_tb = EA * (CONT ? (action_kind == BSX_ACT_F32 ? 12 : 24) : (action_kind == BSX_ACT_I32 ? 4 : 16));
@@ -1101,13 +1104,13 @@ int bsx_step_many_continuous(void* state, int64_t E, int n, int T, const void* a
                              env_offset, stream, T, store_all);
 }
 
-int bsx_rollout_discrete(void* state, int64_t E, int n, int T, const float* weights, float* obs, float* scores, float* rew,
+int bsx_rollout_discrete(void* state, int64_t E, int n, int T, const float* weights, int precision, float* obs, float* scores, float* rew,
                          uint8_t* done, uint8_t* env_done, uint8_t* winner, const BsxRewards* cfg, uint32_t flags,
                          const BsxActorNoise* noise, uint64_t actor_seed, uint64_t seq, const uint64_t* seq_base, uint64_t seed,
                          int64_t env_offset, void* stream) {
     if (!state || E <= 0 || E > BSX_MAX_E || n != 1 || T < 1 || T > BSX_MAX_T || !weights || !obs || !scores || !rew || !done || !cfg)
         return BSX_E_ARG;
-    if (flags & BSX_F_EMPTY_CALL) return BSX_E_ARG;
+    if ((flags & BSX_F_EMPTY_CALL) || (precision != BSX_ACTOR_F32 && precision != BSX_ACTOR_BF16X3)) return BSX_E_ARG;
     if (!aligned(state, 256) || !aligned(weights, 16) || !aligned(scores, 16) || !aligned(obs, 4) || !aligned(rew, 4)) return BSX_E_ALIGN;
     BsxActorNoise nz = {0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr};
     if (noise) nz = *noise;
@@ -1119,7 +1122,7 @@ int bsx_rollout_discrete(void* state, int64_t E, int n, int T, const float* weig
     a.obs = obs + EA * D; a.rew = rew; a.done = done; a.env_done = env_done; a.winner = winner;
     a.cfg = *cfg; a.flags = flags; a.seed = seed; a.env_offset = env_offset; a.tie_tick = bsx_tie_tick(n);
     a.T = T; a.act_tb = 0; a.u_ts = 0; a.obs_ts = EA * D; a.rew_ts = EA; a.done_ts = EA;
-    a.aw = weights; a.obs0 = obs; a.scores = scores; a.scores_ts = EA * 4; a.nz = nz; a.aseed = actor_seed; a.aseq = seq;
+    a.aw = weights; a.aprec = precision; a.obs0 = obs; a.scores = scores; a.scores_ts = EA * 4; a.nz = nz; a.aseed = actor_seed; a.aseq = seq;
     a.aseq_base = seq_base;
     hipLaunchKernelGGL((bsx_step_kernel<1, false, true, true>), dim3(grid_for(E, n, SPB)), dim3(SPB), 0,
                        static_cast<hipStream_t>(stream), a);

@@ -56,6 +56,8 @@ class StackedActor(nn.Module):
           W2A[mo 2][mt 2][vq 4][lane 64][t 4]   = W2[nid(mt, 4 vq + t, lane>>5)][32 mo + (lane&31)]
           b1 g1 be1 b2 g2 be2, each [hh 2][mo 2][v 16] = vec[nid(mo, v, hh)]
           W3P[hh 2][mt 2][v 16][4]              = W3[nid(mt, v, hh)][:]        b3[4]
+          W2B[mo 2][s 4][term 2][lane 64][i 8]  bfloat16: term 0 = bf16(W2), term 1 = bf16(W2 - term 0) of
+                                                W2[nid(s>>1, 8 (s&1) + i, lane>>5)][32 mo + (lane&31)]  (precision="bf16x3")
         with nid(m, v, hh) = 32 m + (v&3) + 8 (v>>2) + 4 hh, the neuron that accumulator register v of 32-neuron tile m
         holds in lane half hh.  float32, contiguous, [n_actors, floats]."""
         if self.w1.shape[2] != 64 or self.w2.shape[2] != 64 or self.n_actions != 4:
@@ -85,7 +87,17 @@ class StackedActor(nn.Module):
         idx = nid(mo3, v16.view(1, 1, 16), hh3).reshape(-1)                      # [hh][mo][v] -> neuron
         small = [x.float().reshape(A, 64)[:, idx] for x in (self.b1, self.g1, self.h1, self.b2, self.g2, self.h2)]
         W3P = self.w3.float()[:, idx, :].reshape(A, -1)                            # [hh][mt][v][4]: same index pattern with mt for mo
-        blob = torch.cat([W1A, W2A, *small, W3P, self.b3.float().reshape(A, -1)], dim=1).contiguous()
+        # W2B[a, mo, s, term, lane, i]: the 64 x 64 layer split in two bfloat16 terms (precision="bf16x3")
+        mo6 = torch.arange(2, device=dev).view(2, 1, 1, 1); s6 = torch.arange(4, device=dev).view(1, 4, 1, 1)
+        l6 = lane.view(1, 1, 64, 1); i6 = torch.arange(8, device=dev).view(1, 1, 1, 8)
+        kb = nid(s6 >> 1, 8 * (s6 & 1) + i6, l6 >> 5).expand(2, 4, 64, 8)
+        jb = (32 * mo6 + (l6 & 31)).expand(2, 4, 64, 8)
+        wsel = self.w2.float()[:, kb, jb]                                          # [A, mo, s, lane, i]
+        wh = wsel.to(torch.bfloat16)
+        wl = (wsel - wh.float()).to(torch.bfloat16)
+        W2B = torch.stack([wh, wl], dim=3).contiguous().view(torch.int16).reshape(A, -1)     # [A, mo, s, term, lane, i]
+        W2B = W2B.view(torch.float32)                                              # 2 bf16 per float slot: [A, 4096]
+        blob = torch.cat([W1A, W2A, *small, W3P, self.b3.float().reshape(A, -1), W2B], dim=1).contiguous()
         if out is not None:
             out.copy_(blob)
             return out
@@ -107,10 +119,17 @@ class FusedActor:
     """The same per-agent actor as ONE hand-written HIP kernel on the matrix cores (csrc/bsx_actor.hip,
     `bsx_actor_forward`: f32 MFMA, exact f32): a row never leaves the register file -- 4*D bytes in, 16 bytes out --
     instead of ~20 memory-bound torch passes over [A, E, 64] activations.  Holds a packed copy of a StackedActor's weights; call `refresh()` after the learner updates them.
-    Optional exploration noise (Gaussian, then clamp(-1, 1) as maddpg/agent.py:31) is drawn in-kernel."""
+    Optional exploration noise (Gaussian, then clamp(-1, 1) as maddpg/agent.py:31) is drawn in-kernel.
+    precision: "f32" = exact float32 everywhere; "bf16x3" = the 64 x 64 layer as three bf16 matrix products of two-term
+    splits of both operands (about 1e-5 on a score, 16x the matrix rate); everything else stays float32."""
 
-    def __init__(self, actor, n_agents_per_team, seed=0):
+    PRECISIONS = {"f32": _lib.ACTOR_F32, "bf16x3": _lib.ACTOR_BF16X3}
+
+    def __init__(self, actor, n_agents_per_team, seed=0, precision="f32"):
         self.actor, self.n = actor, int(n_agents_per_team)
+        if precision not in self.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
+        self.precision = self.PRECISIONS[precision]
         if actor.n_actors != 2 * self.n or actor.obs_len != 3 * self.n + 2:
             raise ValueError("actor shape does not match the env")
         self._lib = _lib.load()
@@ -149,7 +168,7 @@ class FusedActor:
             self.seq += 1
             seq = self.seq
         nz = self.noise_struct(E, noise_std, ou)
-        _lib.check(self._lib.bsx_actor_forward(self.weights.data_ptr(), obs.data_ptr(), scores.data_ptr(), E, self.n,
+        _lib.check(self._lib.bsx_actor_forward(self.weights.data_ptr(), obs.data_ptr(), scores.data_ptr(), E, self.n, self.precision,
                                                _lib.ctypes.byref(nz) if nz is not None else None, self.seed, int(seq),
                                                seq_base.data_ptr() if seq_base is not None else None,
                                                torch.cuda.current_stream(obs.device).cuda_stream), "bsx_actor_forward")
@@ -173,7 +192,8 @@ class PolicyRollout:
     (ou_scale = main.py's curr_noise; utils/noise.py), whose state is one more [E, A, 4] tensor updated inside the actor
     kernel and restarted per game; then clamp(-1, 1) as maddpg/agent.py:31 does."""
 
-    def __init__(self, env, actor, T, noise_std=0.0, fused=True, seed=0, opponent=None, ou_scale=0.0, one_launch=False):
+    def __init__(self, env, actor, T, noise_std=0.0, fused=True, seed=0, opponent=None, ou_scale=0.0, one_launch=False,
+                 precision="f32"):
         """actor: a StackedActor.  fused=True evaluates it with the hand-written HIP kernel (FusedActor), False with
         torch ops (the fp32 reference of the same op).  opponent: an `instinct.Team` that plays its team's planes
         instead of the actor (the reference's training setup, main.py:119-122: learned red vs scripted blue): its
@@ -181,7 +201,7 @@ class PolicyRollout:
         if env.continuous_actions or env._compat or env.rng != "philox":
             raise ValueError("PolicyRollout needs a batched discrete env with rng='philox'")
         self.env, self.actor, self.T, self.noise_std = env, actor, int(T), float(noise_std)
-        self.fused = FusedActor(actor, env.n_agents, seed=seed) if fused else None
+        self.fused = FusedActor(actor, env.n_agents, seed=seed, precision=precision) if fused else None
         self.opponent = opponent
         # ou_scale > 0: the reference's Ornstein-Uhlenbeck exploration noise (utils/noise.py; main.py:151-155 scales it per
         # game and restarts it at every game start) -- fused path only; the process state is one more [E, A, 4] tensor
@@ -248,7 +268,7 @@ class PolicyRollout:
         self.obs[0].copy_(self.obs[self.T])            # continue where the previous rollout ended
         if self.one_launch:
             nz = self.fused.noise_struct(self.env.n_envs, self.noise_std, self.ou)
-            self.env._launch_rollout(self.T, self.fused.weights.data_ptr(), self.obs.data_ptr(), self.scores.data_ptr(),
+            self.env._launch_rollout(self.T, self.fused.weights.data_ptr(), self.fused.precision, self.obs.data_ptr(), self.scores.data_ptr(),
                                      self.rew.data_ptr(), self._done.data_ptr(), nz, self.fused.seed, 0, self._seq_base.data_ptr())
         else:
             for t in range(self.T):

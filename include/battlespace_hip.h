@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define BSX_ABI_VERSION 4
+#define BSX_ABI_VERSION 5
 #define BSX_BULLET_SLOTS 12 /* a bullet is removed at the latest on its 12th update (sprites.py:334-337: 12*45 >= 500) */
 #define BSX_MAX_N 16
 #define BSX_MAX_E (INT64_C(1) << 30)   /* games per call: keeps every grid below 2^31 workgroups; 2^30 games of 1v1 is ~0.8 TB of state */
@@ -139,6 +139,8 @@ int bsx_export_state(const void* state, int64_t E, int n, const BsxExport* out, 
  *              W2A[mo 2][mt 2][vq 4][lane 64][t 4] = W2[nid(mt, 4vq + t, lane>>5)][32mo + (lane&31)]
  *              b1 ln1_gain ln1_bias b2 ln2_gain ln2_bias, each [hh 2][mo 2][v 16] = vec[nid(mo, v, hh)]
  *              W3P[hh 2][mt 2][v 16][4] = W3[nid(mt, v, hh)][0..3];  b3[4]
+ *              W2B[mo 2][s 4][term 2][lane 64][i 8] bfloat16 (4096 floats' worth): term 0 = bf16(W2), term 1 = bf16(W2 - term 0)
+ *                  of W2[nid(s>>1, 8(s&1) + i, lane>>5)][32mo + (lane&31)]  -- read only with BSX_ACTOR_BF16X3
  *            (W[k][j] multiplies input k into output j, i.e. the transpose of torch's Linear.weight.)
  *   obs      float32[E*A*D] (what bsx_step_* / bsx_reset wrote);  scores float32[E*A*4], 16-byte aligned: feed it to
  *            bsx_step_discrete with BSX_ACT_LOGITS_F32.
@@ -153,9 +155,13 @@ typedef struct BsxActorNoise {
     float* ou_state;          /* float32[E*A*4] process state x, required when ou_scale > 0 */
     const uint8_t* env_done;  /* nullable uint8[E]: rows of finished games restart from ou_mu (main.py:155 reset_noise per game) */
 } BsxActorNoise;
+/* precision of the 64 x 64 layer: exact float32 (an fmaf chain, bit for bit), or both operands split in two bf16 terms and
+ * three bf16 matrix products accumulated in float32 (about 1e-5 on a score; 16x the matrix rate).  All else is float32. */
+#define BSX_ACTOR_F32 0
+#define BSX_ACTOR_BF16X3 1
 int bsx_actor_blob_floats(int obs_len, int* floats_per_agent);
-int bsx_actor_forward(const float* weights, const float* obs, float* scores, int64_t E, int n, const BsxActorNoise* noise,
-                      uint64_t seed, uint64_t seq, const uint64_t* seq_base, void* stream);
+int bsx_actor_forward(const float* weights, const float* obs, float* scores, int64_t E, int n, int precision,
+                      const BsxActorNoise* noise, uint64_t seed, uint64_t seq, const uint64_t* seq_base, void* stream);
 
 /* The caller's rollout loop -- `for t in range(T): actions = actor(obs) (+ noise, clamp); obs, rew, done = step(actions)`
  * (main.py:177-181 with maddpg/agent.py:25-33) -- in ONE launch: T x (bsx_actor_forward -> bsx_step_discrete with
@@ -164,11 +170,11 @@ int bsx_actor_forward(const float* weights, const float* obs, float* scores, int
  *   obs     float32 [T+1][E*A*D]: obs[0] = the observations to start from (in), obs[t+1] = after tick t (out)
  *   scores  float32 [T][E*A*4] (out, 16-byte aligned): what the actors produced = the actions taken
  *   rew     float32 [T][E*A], done uint8 [T][E*A] (out); env_done / winner (nullable, [E]): state after the last tick
- *   weights, noise, actor_seed, seq, seq_base: as bsx_actor_forward; tick t uses sequence number seq + *seq_base + t
+ *   weights, precision, noise, actor_seed, seq, seq_base: as bsx_actor_forward; tick t uses sequence number seq + *seq_base + t
  *   cfg, flags, seed, env_offset: as bsx_step_discrete (BSX_F_EMPTY_CALL is refused)
  * This version: n == 1 (1v1: a wavefront's rows are exactly two 32-row MFMA tiles, one per actor); other team sizes
  * return BSX_E_ARG -- use the two-kernel form. */
-int bsx_rollout_discrete(void* state, int64_t E, int n, int T, const float* weights, float* obs, float* scores, float* rew,
+int bsx_rollout_discrete(void* state, int64_t E, int n, int T, const float* weights, int precision, float* obs, float* scores, float* rew,
                          uint8_t* done, uint8_t* env_done, uint8_t* winner, const BsxRewards* cfg, uint32_t flags,
                          const BsxActorNoise* noise, uint64_t actor_seed, uint64_t seq, const uint64_t* seq_base,
                          uint64_t seed, int64_t env_offset, void* stream);

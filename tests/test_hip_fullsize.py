@@ -318,6 +318,31 @@ def test_fused_actor_matches_torch_fp32_reference(n):
     torch.testing.assert_close(fused(obs), actor(obs).detach(), rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("n", [1, 4])
+def test_fused_actor_bf16x3_is_close_to_fp32(n):
+    """precision="bf16x3": the 64 x 64 layer as three bf16 matrix products of two-term splits.  Against the torch fp32
+    reference: 1e-4 absolute on the tanh outputs (measured ~1e-5), far from plain-bf16 accuracy (~4e-3); the arg-max
+    agrees on all but a sliver of rows; and it is NOT the exact-f32 path (some bits differ)."""
+    from deep_rl_battlespace_amd.rollout import FusedActor, StackedActor
+    torch.manual_seed(20 + n)
+    E, A, D = 20000, 2 * n, 3 * n + 2
+    actor = StackedActor(A, D, 4, device="cuda")
+    with torch.no_grad():
+        actor.w3.mul_(50.0); actor.g1.uniform_(0.5, 1.5); actor.h1.uniform_(-0.3, 0.3); actor.g2.uniform_(0.5, 1.5); actor.h2.uniform_(-0.3, 0.3)
+    obs = torch.rand((E, A, D), device="cuda") * 2 - 1
+    with torch.no_grad():
+        want = actor(obs)
+    exact = FusedActor(actor, n)(obs)
+    got = FusedActor(actor, n, precision="bf16x3")(obs)
+    err = float((got - want).abs().max())
+    assert err < 1e-4, err
+    assert float((got - want).abs().mean()) < 1e-5
+    assert float((got.argmax(-1) == want.argmax(-1)).float().mean()) > 0.999
+    assert not torch.equal(got, exact)
+    with pytest.raises(ValueError):
+        FusedActor(actor, n, precision="fp8")
+
+
 def test_fused_actor_noise_is_gaussian_clamped_and_rekeyed():
     from deep_rl_battlespace_amd.rollout import FusedActor, StackedActor
     torch.manual_seed(1)
@@ -400,7 +425,7 @@ def test_rollout_with_ou_noise_restarts_per_game():
     assert int(env.counters()[:, 0].sum()) > 0                    # games did finish (and restart) along the way
 
 
-@pytest.mark.parametrize("noise", ["none", "gaussian", "ou"])
+@pytest.mark.parametrize("noise", ["none", "gaussian", "ou", "gaussian-bf16x3"])
 def test_one_launch_rollout_equals_two_kernel_rollout(noise):
     """bsx_rollout_discrete (T ticks of actor -> step in ONE launch, observation rows handed over in LDS) against the
     two-kernel form (bsx_actor_forward + bsx_step_discrete per tick): the same transitions bit for bit -- observations,
@@ -412,7 +437,9 @@ def test_one_launch_rollout_equals_two_kernel_rollout(noise):
     actor = StackedActor(2, 5, 4, device="cuda")
     with torch.no_grad():
         actor.w3.mul_(60.0); actor.g1.uniform_(0.5, 1.5); actor.h1.uniform_(-0.3, 0.3)
-    kw = dict(noise_std=0.3) if noise == "gaussian" else (dict(ou_scale=0.4) if noise == "ou" else {})
+    kw = dict(noise_std=0.3) if noise.startswith("gaussian") else (dict(ou_scale=0.4) if noise == "ou" else {})
+    if noise.endswith("bf16x3"):
+        kw["precision"] = "bf16x3"
     ros = []
     for one in (False, True):
         env = _env(n_agents=n, n_envs=E, seed=31, auto_reset=True); env.reset()

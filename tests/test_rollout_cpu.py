@@ -72,6 +72,23 @@ def _mfma_32x32x2(avec, bvec, acc):
         acc[v] += Dm[(v & 3) + 8 * (v >> 2) + 4 * (lanes >> 5), lanes & 31]
 
 
+def _mfma_32x32x16(a8, b8, acc):
+    """v_mfma_f32_32x32x16_bf16 on host arrays [lane, 8]: A[i = l&31][k = 8(l>>5) + e], B[k = 8(l>>5) + e][j = l&31], same D map."""
+    lanes = np.arange(64)
+    Am = np.zeros((32, 16)); Bm = np.zeros((16, 32))
+    for e in range(8):
+        Am[lanes & 31, 8 * (lanes >> 5) + e] = a8[:, e]
+        Bm[8 * (lanes >> 5) + e, lanes & 31] = b8[:, e]
+    Dm = Am @ Bm
+    for v in range(16):
+        acc[v] += Dm[(v & 3) + 8 * (v >> 2) + 4 * (lanes >> 5), lanes & 31]
+
+
+def _bf16(x):
+    """round-to-nearest-even float32 -> bfloat16, returned as float64 values"""
+    return torch.as_tensor(np.asarray(x, np.float32)).to(torch.bfloat16).float().numpy().astype(np.float64)
+
+
 @pytest.mark.parametrize("n", [1, 2])
 def test_packed_actor_blob_drives_the_mfma_fragment_arithmetic(n):
     """StackedActor.pack() + the kernel's index arithmetic (csrc/bsx_actor.hip), emulated lane by lane on the host with
@@ -85,7 +102,7 @@ def test_packed_actor_blob_drives_the_mfma_fragment_arithmetic(n):
     blob = act.pack().numpy()
     Dp = (D + 1) & ~1
     ow2 = 64 * Dp; osm = ow2 + 4096; ow3 = osm + 384; ob3 = ow3 + 256
-    assert blob.shape == (A, ob3 + 4)
+    assert blob.shape == (A, ob3 + 4 + 4096)
     obs = torch.rand(64, A, D) * 2 - 1
     want = act(obs).detach().numpy()
     lanes = np.arange(64); hh = lanes >> 5
@@ -125,11 +142,27 @@ def test_packed_actor_blob_drives_the_mfma_fragment_arithmetic(n):
                 for mo in range(2):
                     for nt in range(2):
                         _mfma_32x32x2(w2[mo, mt, v >> 2, :, v & 3], acc1[mt, nt, v], acc2[mo, nt])
-        ln(acc2, 4, 5)
+        # the same layer from the bfloat16 section (precision "bf16x3"): W2B[mo][s][term][lane][i], three products per K step
+        w2b = (W[ob3 + 4:ob3 + 4 + 4096].view(np.uint16).astype(np.uint32) << 16).view(np.float32).astype(np.float64).reshape(2, 4, 2, 64, 8)
+        acc2b = np.zeros((2, 2, 16, 64))
+        for mo in range(2):
+            for nt in range(2):
+                acc2b[mo, nt] = sm[3][hh, mo].T
+        for s4 in range(4):
+            for nt in range(2):
+                x = np.stack([acc1[s4 >> 1, nt, 8 * (s4 & 1) + i] for i in range(8)], axis=1)          # [lane, 8]
+                xh = _bf16(x); xl = _bf16(x - xh)
+                for mo in range(2):
+                    wh, wl = w2b[mo, s4, 0], w2b[mo, s4, 1]
+                    _mfma_32x32x16(wl, xh, acc2b[mo, nt]); _mfma_32x32x16(wh, xl, acc2b[mo, nt]); _mfma_32x32x16(wh, xh, acc2b[mo, nt])
+        err_split = np.abs(acc2b - acc2).max()
+        assert err_split < 2e-4 * max(1.0, np.abs(acc2).max()), err_split         # ~2^-16 relative; plain bf16 would be ~4e-3
+        ln(acc2, 4, 5); ln(acc2b, 4, 5)
         w3 = W[ow3:ow3 + 256].reshape(2, 2, 16, 4); b3 = W[ob3:ob3 + 4]
-        out = np.zeros((64, 4))
-        for nt in range(2):
-            for c in range(32):
-                o = sum(acc2[mt, nt, v, c + 32 * h2] * w3[h2, mt, v] for h2 in range(2) for mt in range(2) for v in range(16))
-                out[32 * nt + c] = np.tanh(o + b3)
-        np.testing.assert_allclose(out, want[:, a, :], atol=2e-5)
+        for acc, tol in ((acc2, 2e-5), (acc2b, 1e-4)):
+            out = np.zeros((64, 4))
+            for nt in range(2):
+                for c in range(32):
+                    o = sum(acc[mt, nt, v, c + 32 * h2] * w3[h2, mt, v] for h2 in range(2) for mt in range(2) for v in range(16))
+                    out[32 * nt + c] = np.tanh(o + b3)
+            np.testing.assert_allclose(out, want[:, a, :], atol=tol)

@@ -13,6 +13,7 @@ ap.add_argument("--envs", type=int, default=65536); ap.add_argument("--n-agents"
 ap.add_argument("--T", type=int, default=32); ap.add_argument("--reps", type=int, default=40)
 ap.add_argument("--noise", type=float, default=0.1); ap.add_argument("--torch-actor", action="store_true")
 ap.add_argument("--one-launch", action="store_true", help="all T ticks in one kernel (bsx_rollout_discrete; 1v1)")
+ap.add_argument("--precision", default="f32", choices=("f32", "bf16x3"), help="the actor's 64 x 64 layer")
 args = ap.parse_args()
 E, n, T = args.envs, args.n_agents, args.T
 A, D = 2 * n, 3 * n + 2
@@ -22,7 +23,7 @@ torch.manual_seed(0)
 actor = StackedActor(A, D, 4, device="cuda")
 with torch.no_grad():
     actor.w3.mul_(100.0)
-ro = PolicyRollout(env, actor, T, noise_std=args.noise, fused=not args.torch_actor, one_launch=args.one_launch)
+ro = PolicyRollout(env, actor, T, noise_std=args.noise, fused=not args.torch_actor, one_launch=args.one_launch, precision=args.precision)
 ro.start(); ro.capture()
 
 
@@ -55,5 +56,5 @@ c = env.counters().sum(0)
 print(json.dumps({"workload": f"{E} games x {n}v{n} + on-device actor (obs {D} -> 64 -> LN -> 64 -> LN -> 4, one per agent), T={T} ticks per graph",
                   "rollout_agent_steps_per_s": round(E * A / t_roll, 1), "rollout_us_per_tick": round(t_roll * 1e6, 2),
                   "env_only_us_per_tick": round(t_env * 1e6, 2), "actor_only_us_per_tick": round(t_act * 1e6, 2),
-                  "actor": "torch ops" if args.torch_actor else "fused HIP kernel (bsx_actor_forward)",
+                  "actor": "torch ops" if args.torch_actor else f"fused HIP kernel (bsx_actor_forward), 64 x 64 layer in {args.precision}",
                   "launch": "one kernel for all T ticks (bsx_rollout_discrete)" if args.one_launch else "HIP graph of 2T kernels", "noise_std": args.noise, "games_finished": int(c[0]), "ties": int(c[1]), "red_wins": int(c[2]), "blue_wins": int(c[3])}))

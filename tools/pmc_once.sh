@@ -3,7 +3,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/pmc_once; rm -rf $O; mkdir -p $O
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc $1 --output-format csv -d $O/p -- python tools/bench_rollout.py --one-launch --reps 10 > /dev/null 2> $O/err.txt
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc $1 --output-format csv -d $O/p -- python tools/bench_rollout.py --one-launch --reps 10 ${BR_ARGS:-} > /dev/null 2> $O/err.txt
 python - <<PY
 import csv, glob, collections
 agg = collections.defaultdict(list)
