@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--envs", type=int, default=65536); ap.add_argument("--n-agents", type=int, default=1)
 ap.add_argument("--steps", type=int, default=1500); ap.add_argument("--check", type=int, default=250)
 ap.add_argument("--policy", choices=("random", "instinct"), default="random"); ap.add_argument("--seed", type=int, default=2024)
+ap.add_argument("--many", type=int, default=0, help="K > 0: the HIP side runs K ticks per launch (bsx_step_many_discrete); random policy only")
 args = ap.parse_args()
 E, n, T = args.envs, args.n_agents, args.steps
 A = 2 * n
@@ -26,6 +27,10 @@ g = torch.Generator(device="cuda"); g.manual_seed(args.seed)
 teams = [instinct.Team(env.possible_red, env.possible_blue, env), instinct.Team(env.possible_blue, env.possible_red, env)]
 acts = torch.zeros((E, A), dtype=torch.int32, device="cuda")
 t0 = time.time(); n_obs = n_exact = 0; max_rel = 0.0
+K = args.many
+if K and args.policy != "random":
+    sys.exit("--many needs --policy random")
+chunk = None
 for t in range(T):
     if args.policy == "instinct":
         for tm in teams:
@@ -33,7 +38,18 @@ for t in range(T):
     else:
         acts = torch.randint(0, 4, (E, A), generator=g, device="cuda", dtype=torch.int32)
         acts = torch.where(torch.rand((E, A), generator=g, device="cuda") < 0.4, torch.ones_like(acts), acts)
-    obs, rew, done = env.step_batch(acts)
+    if K:
+        if t % K == 0:                                   # K ticks of actions, one launch; compared tick by tick below
+            k = min(K, T - t)
+            ca = torch.randint(0, 4, (k, E, A), generator=g, device="cuda", dtype=torch.int32)
+            ca = torch.where(torch.rand((k, E, A), generator=g, device="cuda") < 0.4, torch.ones_like(ca), ca)
+            chunk = (ca, env.step_many(ca, store=True))
+        acts = chunk[0][t % K]
+        obs, rew, done = (x[t % K] for x in chunk[1])
+        if (t % args.check == args.check - 1 or t == T - 1) and (t % K != K - 1 and t != T - 1):
+            sys.exit("--check must fall on launch boundaries (a multiple of --many)")
+    else:
+        obs, rew, done = env.step_batch(acts)
     co, cr, cd = c.step(acts.cpu().numpy())
     o = obs.cpu().numpy()
     if not np.array_equal(done.cpu().numpy(), cd) or not np.array_equal(rew.cpu().numpy().astype(np.float64), cr):
@@ -56,7 +72,7 @@ for t in range(T):
                 print(json.dumps({"mismatch": f, "step": t})); sys.exit(1)
         print(f"step {t + 1}: ok ({time.time() - t0:.0f} s)", file=sys.stderr, flush=True)
 cnt = env.counters().sum(0)
-print(json.dumps({"soak": "ok", "policy": args.policy, "envs": E, "n_per_team": n, "steps": T, "agent_steps": E * A * T,
+print(json.dumps({"soak": "ok", "policy": args.policy, "hip_launch": f"{K} ticks per launch (bsx_step_many_discrete)" if K else "one launch per step", "envs": E, "n_per_team": n, "steps": T, "agent_steps": E * A * T,
                   "observation_values": n_obs, "observation_values_bit_identical": n_exact,
                   "games": int(cnt[0]), "ties": int(cnt[1]), "red_wins": int(cnt[2]), "blue_wins": int(cnt[3]),
                   "seconds": round(time.time() - t0, 1)}))
