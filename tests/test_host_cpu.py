@@ -48,6 +48,14 @@ def test_bad_arguments_are_rejected_before_any_launch():
     assert lib.bsx_reset(None, 4, 1, None, None, 0, 0, 0, None, None) == -1
     assert lib.bsx_observe(None, 4, 1, None, None) == -1
     assert lib.bsx_state_init(ctypes.c_void_p(4096 + 8), 4, 1, None) == -2      # misaligned state base
+    # the multi-tick and rollout entry points: T out of range, team sizes the one-launch rollout is not built for, unknown precision
+    ok = ctypes.c_void_p(4096)
+    assert lib.bsx_step_many_discrete(ok, 4, 1, 0, ok, 0, None, ok, ok, ok, None, None, ctypes.byref(cfg), 0, 1, 0, 0, None) == -1
+    assert lib.bsx_step_many_discrete(ok, 4, 1, 70000, ok, 0, None, ok, ok, ok, None, None, ctypes.byref(cfg), 0, 1, 0, 0, None) == -1
+    assert lib.bsx_step_many_continuous(ok, 4, 1, 5, None, 0, None, ok, ok, ok, None, None, ctypes.byref(cfg), 0, 1, 0, 0, None) == -1
+    assert lib.bsx_rollout_discrete(ok, 4, 2, 8, ok, 0, ok, ok, ok, ok, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1
+    assert lib.bsx_rollout_discrete(ok, 4, 1, 8, ok, 7, ok, ok, ok, ok, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1
+    assert lib.bsx_actor_forward(ok, ok, ok, 4, 1, 7, None, 0, 0, None, None) == -1
 
 
 def test_env_refuses_to_run_without_gpu_or_library():
