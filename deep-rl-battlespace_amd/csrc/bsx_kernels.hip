@@ -352,7 +352,8 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     };
     // MULTI: what one call hands to the next stays in REGISTERS -- my plane, my game's record and episode count (every
     // lane of a game computes the same record) -- so a later tick starts with its bullet loads instead of a state round
-    // trip, and the inputs of tick t+1 are fetched while tick t computes.  Memory still gets every tick's state.
+    // trip, and the inputs of tick t+1 are fetched while tick t computes.  Bullet lists and counters go to memory every
+    // tick, the plane and game records once, after the last one.
     int x = 0, y = 0, hp = 0, games = 0;
     uint32_t live = 0;
     double dir = 0.0;
@@ -731,9 +732,10 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     }
 
     STAMP(6);
-    // ---- write back
+    // ---- write back (MULTI: plane and game records travel in registers; memory gets them once, after the last tick)
+    const bool last_tick = !MULTI || tk == p.T - 1;
     if (valid) {
-        if (mode == M_PHYS || mode == M_RESET)
+        if (MULTI ? last_tick : (mode == M_PHYS || mode == M_RESET))
             reinterpret_cast<uint4*>(p.st.plane)[gt] = pack_plane(x, y, live, hp, dir);
         rew_t[gt] = float(rew);
         done_t[gt] = er.done ? uint8_t(1) : uint8_t(alive ? 0 : 1);
@@ -785,14 +787,16 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     }
     if (valid) {
         if (a == 0) {
-            if (mode != M_INERT) reinterpret_cast<uint4*>(p.st.env)[e] = pack_env(er);
+            if (MULTI ? last_tick : (mode != M_INERT)) reinterpret_cast<uint4*>(p.st.env)[e] = pack_env(er);
             if (cnt_delta.x) {                           // game over: rare read-modify-write of the counters
                 int4 cnt = p.st.cnt[e];
                 cnt.x += cnt_delta.x; cnt.y += cnt_delta.y; cnt.z += cnt_delta.z; cnt.w += cnt_delta.w;
                 p.st.cnt[e] = cnt;
             }
-            if (p.env_done) p.env_done[e] = uint8_t(er.done);
-            if (p.winner) p.winner[e] = uint8_t(er.winner);
+            if (last_tick) {
+                if (p.env_done) p.env_done[e] = uint8_t(er.done);
+                if (p.winner) p.winner[e] = uint8_t(er.winner);
+            }
         }
     }
     STAMP(7);
