@@ -52,27 +52,41 @@ __device__ inline uint4 philox4x32_10(uint4 ctr, uint2 key) {
 
 // LayerNorm over the 64 neurons of each row + ReLU, in place on ONE 32-row tile held as acc[mo] (torch semantics: biased
 // variance, eps 1e-5).  A row's 64 neurons = 32 registers of the lane + the partner lane l^32.  gp / bp: this lane half's
-// gain / bias vectors, [mo 2][v 16] floats in LDS.
+// gain / bias vectors, [mo 2][v 16] floats in LDS (8-byte aligned).  Written on register PAIRS so that the adds, multiplies
+// and FMAs issue as packed-f32 instructions (v_pk_add / v_pk_mul / v_pk_fma_f32: two values per issue slot).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ inline void ln_relu_tile(f32x16& a0, f32x16& a1, const float* __restrict__ gp, const float* __restrict__ bp) {
 #pragma clang fp contract(fast)
-    float s = 0.f;
+    f32x2 s2 = {0.f, 0.f};
 #pragma unroll
-    for (int v = 0; v < 16; ++v) s += a0[v];
+    for (int v = 0; v < 16; v += 2) s2 += f32x2{a0[v], a0[v + 1]};
 #pragma unroll
-    for (int v = 0; v < 16; ++v) s += a1[v];
+    for (int v = 0; v < 16; v += 2) s2 += f32x2{a1[v], a1[v + 1]};
+    float s = s2.x + s2.y;
     s += __shfl_xor(s, 32);
     const float mean = s * (1.0f / H);
-    float q = 0.f;
+    const f32x2 m2 = {mean, mean};
+    f32x2 d0[8], d1[8], q2 = {0.f, 0.f};
 #pragma unroll
-    for (int v = 0; v < 16; ++v) { const float d = a0[v] - mean; q = fmaf(d, d, q); }
+    for (int i = 0; i < 8; ++i) { d0[i] = f32x2{a0[2 * i], a0[2 * i + 1]} - m2; q2 += d0[i] * d0[i]; }
 #pragma unroll
-    for (int v = 0; v < 16; ++v) { const float d = a1[v] - mean; q = fmaf(d, d, q); }
+    for (int i = 0; i < 8; ++i) { d1[i] = f32x2{a1[2 * i], a1[2 * i + 1]} - m2; q2 += d1[i] * d1[i]; }
+    float q = q2.x + q2.y;
     q += __shfl_xor(q, 32);
     const float rstd = rsqrtf(q * (1.0f / H) + 1e-5f);
+    const f32x2 r2 = {rstd, rstd};
+    const f32x2* g2 = reinterpret_cast<const f32x2*>(gp);
+    const f32x2* b2 = reinterpret_cast<const f32x2*>(bp);
 #pragma unroll
-    for (int v = 0; v < 16; ++v) a0[v] = fmaxf(fmaf((a0[v] - mean) * rstd, gp[v], bp[v]), 0.f);
+    for (int i = 0; i < 8; ++i) {
+        const f32x2 y = d0[i] * (r2 * g2[i]) + b2[i];
+        a0[2 * i] = fmaxf(y.x, 0.f); a0[2 * i + 1] = fmaxf(y.y, 0.f);
+    }
 #pragma unroll
-    for (int v = 0; v < 16; ++v) a1[v] = fmaxf(fmaf((a1[v] - mean) * rstd, gp[16 + v], bp[16 + v]), 0.f);
+    for (int i = 0; i < 8; ++i) {
+        const f32x2 y = d1[i] * (r2 * g2[8 + i]) + b2[8 + i];
+        a1[2 * i] = fmaxf(y.x, 0.f); a1[2 * i + 1] = fmaxf(y.y, 0.f);
+    }
 }
 
 // tanh of the head sums + bias, exploration noise, clamp (maddpg/networks.py:85, maddpg/agent.py:30-31) for ONE row.
