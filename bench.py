@@ -113,7 +113,6 @@ def main():
 
     import torch
     import torch.distributed as dist
-    import deep_rl_battlespace_amd as bsx
     from deep_rl_battlespace_amd import sharding
 
     rank, world, local_rank = sharding.rank_world()

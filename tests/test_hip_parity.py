@@ -3,7 +3,6 @@ against the CPU oracle.  Needs an MI355X: run with `pytest -m gpu`.
 
 Bars: integer game state (poses, hit points, bullets, ticks, flags, counters) and float64 headings bit-exact;
 observations within 1e-5 relative (north_star) -- and almost all of them bit-identical; rewards within 1e-6."""
-import math
 import random
 
 import numpy as np
