@@ -5,7 +5,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libbattlespace_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 BULLET_SLOTS = 12
 MAX_N = 16
 MAX_T = 65535
@@ -13,7 +13,7 @@ ACTOR_F32, ACTOR_BF16X3 = 0, 1
 F_AUTO_RESET = 1
 F_EMPTY_CALL = 2
 ACT_I32, ACT_LOGITS_F32 = 0, 1
-ACT_F32, ACT_F64 = 0, 1
+ACT_F32, ACT_F64, ACT_F32X4 = 0, 1, 2
 WINNER_NAMES = ("none", "red", "blue", "tie")
 
 c_void_p, c_int, c_int64, c_uint32, c_uint64, c_size_t = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,

@@ -343,6 +343,9 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
             } else if (p.action_kind == BSX_ACT_F32) {
                 const float* ap = static_cast<const float*>(at) + 3 * g;
                 r.f0 = ap[0]; r.f1 = ap[1]; r.f2 = ap[2];
+            } else if (p.action_kind == BSX_ACT_F32X4) {
+                const float4 v = static_cast<const float4*>(at)[g];
+                r.f0 = v.x; r.f1 = v.y; r.f2 = v.z;
             } else {
                 const double* ap = static_cast<const double*>(at) + 3 * g;
                 r.c0 = ap[0]; r.c1 = ap[1]; r.c2 = ap[2];
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
                 for (int i = 1; i < 4; ++i)
                     if (!(v[act] != v[act]) && (v[i] > v[act] || v[i] != v[i])) act = i;
             }
-        } else if (p.action_kind == BSX_ACT_F32) {
+        } else if (p.action_kind == BSX_ACT_F32 || p.action_kind == BSX_ACT_F32X4) {
             a0 = double(rin.f0); a1 = double(rin.f1); a2 = double(rin.f2);
         } else {
             a0 = rin.c0; a1 = rin.c1; a2 = rin.c2;
@@ -986,7 +989,8 @@ int launch_step(void* state, int64_t E, int n, const void* actions, int action_k
     if (!aligned(state, 256) || !aligned(obs, 4) || !aligned(rew, 4) || (u && !aligned(u, 8))) return BSX_E_ALIGN;
     if (!CONT && action_kind == BSX_ACT_LOGITS_F32 && !aligned(actions, 16)) return BSX_E_ALIGN;
     if (!CONT && action_kind != BSX_ACT_I32 && action_kind != BSX_ACT_LOGITS_F32) return BSX_E_ARG;
-    if (CONT && action_kind != BSX_ACT_F32 && action_kind != BSX_ACT_F64) return BSX_E_ARG;
+    if (CONT && action_kind != BSX_ACT_F32 && action_kind != BSX_ACT_F64 && action_kind != BSX_ACT_F32X4) return BSX_E_ARG;
+    if (CONT && action_kind == BSX_ACT_F32X4 && !aligned(actions, 16)) return BSX_E_ALIGN;
     StepArgs a;
     a.st = state_ptrs(state, E, n);
     a.E = E; a.n = n; a.actions = actions; a.action_kind = action_kind; a.u = u;
@@ -996,7 +1000,7 @@ int launch_step(void* state, int64_t E, int n, const void* actions, int action_k
     a.aw = nullptr; a.aprec = 0; a.obs0 = nullptr; a.scores = nullptr; a.scores_ts = 0; a.nz = BsxActorNoise{0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr};
     a.aseed = 0; a.aseq = 0; a.aseq_base = nullptr;
     a.T = T;
-    a.act_tb = EA * (CONT ? (action_kind == BSX_ACT_F32 ? 12 : 24) : (action_kind == BSX_ACT_I32 ? 4 : 16));
+    a.act_tb = EA * (CONT ? (action_kind == BSX_ACT_F32 ? 12 : (action_kind == BSX_ACT_F64 ? 24 : 16)) : (action_kind == BSX_ACT_I32 ? 4 : 16));
     a.u_ts = EA;
     a.obs_ts = store_all ? EA * (3 * n + 2) : 0; a.rew_ts = store_all ? EA : 0; a.done_ts = store_all ? EA : 0;
     const dim3 grid(grid_for(E, n, SPB)), block(SPB);

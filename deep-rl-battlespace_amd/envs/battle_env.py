@@ -332,12 +332,15 @@ class parallel_env:
                           ctypes.byref(self._cfg), flags, self.seed, self.env_offset, self._stream()), "bsx_step")
 
     def _check_action_series(self, actions):
-        """actions for T calls: [T, E, A] int32 | [T, E, A, 4] float32 | [T, E, A, 3] float32/float64 (continuous)."""
+        """actions for T calls: [T, E, A] int32 | [T, E, A, 4] float32 | [T, E, A, 3] float32/float64 (continuous) |
+        [T, E, A, 4] float32 (continuous: speed, turn, shoot + one ignored column, as an actor writes them)."""
         E, A = self.n_envs, self._A
         if not torch.is_tensor(actions) or actions.device != self.device or not actions.is_contiguous() or actions.dim() < 3:
             raise ValueError("actions must be a contiguous [T, E, A, ...] tensor on the env's device")
         T = actions.shape[0]
-        if self.continuous_actions:
+        if self.continuous_actions and actions.dim() == 4 and actions.shape[3] == 4:     # an actor's 4-wide rows: 3 actions + padding
+            ok, kind = actions.shape == (T, E, A, 4) and actions.dtype == torch.float32, _lib.ACT_F32X4
+        elif self.continuous_actions:
             ok, kind = actions.shape == (T, E, A, 3) and actions.dtype in (torch.float32, torch.float64), \
                 (_lib.ACT_F64 if actions.dtype == torch.float64 else _lib.ACT_F32)
         elif actions.dim() == 4:

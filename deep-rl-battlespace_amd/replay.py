@@ -22,6 +22,7 @@ class ReplayBuffer:
         nA, M = self.n_agents, self.mem_size
         self.actor_states = torch.zeros((M, nA, obs_size), **kw)        # state_mem is the [M, nA*obs] view of this
         self.actor_new_states = torch.zeros((M, nA, obs_size), **kw)
+        self.n_actions = int(n_actions)
         self.action_mem = torch.zeros((M, nA, n_actions), **kw)
         self.rew_mem = torch.zeros((M, nA), **kw)
         self.done_mem = torch.zeros((M, nA), device=device, dtype=torch.bool)
@@ -74,7 +75,7 @@ class ReplayBuffer:
         c = torch.as_tensor(list(columns), device=rollout.obs.device)
         T = rollout.T
         flat = lambda x: x.index_select(2, c).reshape(-1, len(c), *x.shape[3:])   # noqa: E731
-        self._put(flat(rollout.obs[:T]), flat(rollout.scores), flat(rollout.rew), flat(rollout.obs[1:T + 1]), flat(rollout.done))
+        self._put(flat(rollout.obs[:T]), flat(rollout.scores)[..., :self.n_actions], flat(rollout.rew), flat(rollout.obs[1:T + 1]), flat(rollout.done))
 
     def sample(self):
         """buffer.py:49-67 -> (actor_states [nA, B, obs], states [B, nA*obs], actions [nA, B, n_actions], rewards [B, nA],

@@ -60,8 +60,9 @@ class StackedActor(nn.Module):
                                                 W2[nid(s>>1, 8 (s&1) + i, lane>>5)][32 mo + (lane&31)]  (precision="bf16x3")
         with nid(m, v, hh) = 32 m + (v&3) + 8 (v>>2) + 4 hh, the neuron that accumulator register v of 32-neuron tile m
         holds in lane half hh.  float32, contiguous, [n_actors, floats]."""
-        if self.w1.shape[2] != 64 or self.w2.shape[2] != 64 or self.n_actions != 4:
-            raise ValueError("the fused actor kernel is built for fc1 = fc2 = 64 and 4 action scores (main.py:15-16)")
+        if self.w1.shape[2] != 64 or self.w2.shape[2] != 64 or self.n_actions not in (3, 4):
+            raise ValueError("the fused actor kernel is built for fc1 = fc2 = 64 (main.py:15-16) and 4 action scores, or 3 "
+                             "continuous actions (padded to 4 rows: the extra output is tanh(0) = 0)")
         A, D, dev = self.n_actors, self.obs_len, self.w1.device
         Dp = (D + 1) & ~1
         lane = torch.arange(64, device=dev)
@@ -86,7 +87,11 @@ class StackedActor(nn.Module):
         hh3 = torch.arange(2, device=dev).view(2, 1, 1); mo3 = torch.arange(2, device=dev).view(1, 2, 1)
         idx = nid(mo3, v16.view(1, 1, 16), hh3).reshape(-1)                      # [hh][mo][v] -> neuron
         small = [x.float().reshape(A, 64)[:, idx] for x in (self.b1, self.g1, self.h1, self.b2, self.g2, self.h2)]
-        W3P = self.w3.float()[:, idx, :].reshape(A, -1)                            # [hh][mt][v][4]: same index pattern with mt for mo
+        w3, b3 = self.w3.float(), self.b3.float()
+        if self.n_actions == 3:                                                    # continuous: [speed, turn, shoot] + a zero column
+            w3 = torch.cat([w3, torch.zeros_like(w3[:, :, :1])], dim=2)
+            b3 = torch.cat([b3, torch.zeros_like(b3[:, :, :1])], dim=2)
+        W3P = w3[:, idx, :].reshape(A, -1)                                         # [hh][mt][v][4]: same index pattern with mt for mo
         # W2B[a, mo, s, term, lane, i]: the 64 x 64 layer split in two bfloat16 terms (precision="bf16x3")
         mo6 = torch.arange(2, device=dev).view(2, 1, 1, 1); s6 = torch.arange(4, device=dev).view(1, 4, 1, 1)
         l6 = lane.view(1, 1, 64, 1); i6 = torch.arange(8, device=dev).view(1, 1, 1, 8)
@@ -97,7 +102,7 @@ class StackedActor(nn.Module):
         wl = (wsel - wh.float()).to(torch.bfloat16)
         W2B = torch.stack([wh, wl], dim=3).contiguous().view(torch.int16).reshape(A, -1)     # [A, mo, s, term, lane, i]
         W2B = W2B.view(torch.float32)                                              # 2 bf16 per float slot: [A, 4096]
-        blob = torch.cat([W1A, W2A, *small, W3P, self.b3.float().reshape(A, -1), W2B], dim=1).contiguous()
+        blob = torch.cat([W1A, W2A, *small, W3P, b3.reshape(A, -1), W2B], dim=1).contiguous()
         if out is not None:
             out.copy_(blob)
             return out
@@ -198,8 +203,13 @@ class PolicyRollout:
         torch ops (the fp32 reference of the same op).  opponent: an `instinct.Team` that plays its team's planes
         instead of the actor (the reference's training setup, main.py:119-122: learned red vs scripted blue): its
         one-hot scores overwrite that team's rows of the score tensor each tick, on device."""
-        if env.continuous_actions or env._compat or env.rng != "philox":
-            raise ValueError("PolicyRollout needs a batched discrete env with rng='philox'")
+        if env._compat or env.rng != "philox":
+            raise ValueError("PolicyRollout needs a batched env with rng='philox'")
+        self.continuous = bool(env.continuous_actions)
+        if actor.n_actions != (3 if self.continuous else 4):
+            raise ValueError("the actor must have 4 outputs for a discrete env (action scores), 3 for a continuous one")
+        if self.continuous and opponent is not None:
+            raise ValueError("the scripted opponent writes float64 [E, A, 3] actions: not combinable with the actor's rows")
         self.env, self.actor, self.T, self.noise_std = env, actor, int(T), float(noise_std)
         self.fused = FusedActor(actor, env.n_agents, seed=seed, precision=precision) if fused else None
         self.opponent = opponent
@@ -215,12 +225,14 @@ class PolicyRollout:
         # observation rows stay in LDS between the step and the actor, game state in registers / L2.  Discrete 1v1, no
         # scripted opponent; same transitions, bit for bit.
         self.one_launch = bool(one_launch)
-        if self.one_launch and (not fused or opponent is not None or env.n_agents != 1):
-            raise ValueError("one_launch needs the fused actor, 1v1 and no scripted opponent")
+        if self.one_launch and (not fused or opponent is not None or env.n_agents != 1 or env.continuous_actions):
+            raise ValueError("one_launch needs the fused actor, discrete 1v1 and no scripted opponent")
         self._seq_base = torch.zeros(1, dtype=torch.int64, device=env.device)
         E, A, D, dev = env.n_envs, env._A, env.obs_size, env.device
         self.obs = torch.empty((T + 1, E, A, D), dtype=torch.float32, device=dev)
-        self.scores = torch.empty((T, E, A, 4), dtype=torch.float32, device=dev)
+        # discrete: 4 action scores, arg-maxed in the step kernel; continuous: [speed, turn, shoot] + one unused column
+        self.scores = torch.zeros((T, E, A, 4), dtype=torch.float32, device=dev)
+        self._kind = _lib.ACT_F32X4 if self.continuous else _lib.ACT_LOGITS_F32
         self.rew = torch.empty((T, E, A), dtype=torch.float32, device=dev)
         self._done = torch.empty((T, E, A), dtype=torch.uint8, device=dev)
         self.done = self._done.view(torch.bool)
@@ -233,17 +245,17 @@ class PolicyRollout:
             self.fused.forward_into(self.obs[t], self.scores[t], self.noise_std, seq=t, seq_base=self._seq_base, ou=self.ou)
             if self.opponent is not None:
                 self.opponent.write_actions(out=self.scores[t], obs=self.obs[t])
-            self.env._launch(self.scores[t].data_ptr(), _lib.ACT_LOGITS_F32, False, None,
+            self.env._launch(self.scores[t].data_ptr(), self._kind, False, None,
                              self.obs[t + 1].data_ptr(), self.rew[t].data_ptr(), self._done[t].data_ptr())
             return
         with torch.no_grad():
             s = self.actor(self.obs[t])
             if self.noise_std > 0.0:
                 s = (s + self.noise_std * torch.randn_like(s)).clamp_(-1.0, 1.0)
-            self.scores[t].copy_(s)
+            self.scores[t][..., :s.shape[-1]].copy_(s)
         if self.opponent is not None:
             self.opponent.write_actions(out=self.scores[t], obs=self.obs[t])
-        self.env._launch(self.scores[t].data_ptr(), _lib.ACT_LOGITS_F32, False, None,
+        self.env._launch(self.scores[t].data_ptr(), self._kind, False, None,
                          self.obs[t + 1].data_ptr(), self.rew[t].data_ptr(), self._done[t].data_ptr())
 
     def start(self):

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define BSX_ABI_VERSION 5
+#define BSX_ABI_VERSION 6
 #define BSX_BULLET_SLOTS 12 /* a bullet is removed at the latest on its 12th update (sprites.py:334-337: 12*45 >= 500) */
 #define BSX_MAX_N 16
 #define BSX_MAX_E (INT64_C(1) << 30)   /* games per call: keeps every grid below 2^31 workgroups; 2^30 games of 1v1 is ~0.8 TB of state */
@@ -57,6 +57,7 @@ typedef struct BsxRewards {
 /* Action encodings for bsx_step_continuous: [E*A*3] = speed, turn, shoot in [-1,1], clipped in-kernel (battle_env.py:295-297) */
 #define BSX_ACT_F32 0
 #define BSX_ACT_F64 1
+#define BSX_ACT_F32X4 2      /* float32 [E*A*4], 16-byte aligned: speed, turn, shoot + one ignored float -- the 4-wide rows bsx_actor_forward writes */
 
 int bsx_abi_version(void);
 

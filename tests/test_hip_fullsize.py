@@ -464,6 +464,42 @@ def test_one_launch_rollout_equals_two_kernel_rollout(noise):
     assert len(torch.unique(a.scores.argmax(-1))) >= 3
 
 
+@pytest.mark.parametrize("fused", [False, True])
+def test_continuous_policy_rollout(fused):
+    """The env's other action mode on the rollout path: an actor with 3 outputs [speed, turn, shoot] (maddpg/networks.py:75
+    with env.n_actions = 3, battle_env.py:151-153), written as 4-wide rows and read by bsx_step_continuous as BSX_ACT_F32X4.
+    The graph plays what an eager loop plays, and the 4-wide path steps exactly like plain float32 [E, A, 3] actions."""
+    from deep_rl_battlespace_amd.replay import ReplayBuffer
+    from deep_rl_battlespace_amd.rollout import FusedActor, PolicyRollout, StackedActor
+    E, n, T = 3000, 2, 20
+    A, D = 2 * n, 3 * n + 2
+    torch.manual_seed(5)
+    actor = StackedActor(A, D, 3, device="cuda")
+    with torch.no_grad():
+        actor.w3.mul_(80.0)
+    env = _env(n_agents=n, n_envs=E, seed=9, auto_reset=True, continuous_actions=True); env.reset()
+    twin = _env(n_agents=n, n_envs=E, seed=9, auto_reset=True, continuous_actions=True); twin.reset()
+    ro = PolicyRollout(env, actor, T, noise_std=0.2 if fused else 0.0, fused=fused, seed=3); ro.start(); ro.capture()
+    for rep in range(3):
+        ro.run()
+        torch.cuda.synchronize()
+        assert float(ro.scores[..., 3].abs().max()) <= (1.0 if fused else 0.0)       # the padding column: tanh(0) (+ noise), never read
+        for t in range(T):
+            o, r, d = twin.step_batch(ro.scores[t][..., :3].contiguous())
+            assert torch.equal(o, ro.obs[t + 1]) and torch.equal(r, ro.rew[t]) and torch.equal(d, ro.done[t]), (rep, t)
+    if fused:
+        with torch.no_grad():
+            want = actor(ro.obs[3])
+        got = FusedActor(actor, n)(ro.obs[3])
+        torch.testing.assert_close(got[..., :3], want, rtol=0, atol=2e-5)
+        assert float(got[..., 3].abs().max()) == 0.0
+    buf = ReplayBuffer(100000, 64, env.possible_red, env.obs_size, env.obs_size * n, 3, device="cuda")
+    buf.store_rollout(ro, range(n))
+    assert buf.mem_cntr == T * E and torch.equal(buf.action_mem[5], ro.scores[0, 5, :n, :3])
+    with pytest.raises(ValueError):
+        PolicyRollout(env, StackedActor(A, D, 4, device="cuda"), T)                 # discrete head on a continuous env
+
+
 def test_rollout_into_replay_buffer_on_device():
     """f-1 -> f-3: a rollout's transitions go into the device replay ring without touching the host; a sampled batch is
     self-consistent (next-state of a stored row is the state the env produced one tick later)."""
