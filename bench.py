@@ -42,6 +42,16 @@ def b_alg(n):
     return (13 + 146 + 13 / A) + (13 + 50 + 5 / A) + (4 + 4 * (3 * n + 2) + 4 + 1)
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(seconds_target=12.0):
     """configs[0]: the oracle's step() on 1 game of 1v1, uniform random actions (seed 1234), reset on done; 1 core."""
     import random
@@ -87,7 +97,7 @@ def cpu_baseline(seconds_target=12.0):
         extra = {"c_port_all_cores": {"error": str(exc)[:120]}}
     return {**extra, "value": round(calls * 2 / dt, 1), "unit": "agent-steps/s", "cores": 1, "kind": "port",
             "sample": f"{calls} step() calls of 1 game x 1v1 (configs[0]), uniform random actions seed 1234, "
-                      f"reset on done, {dt:.1f} s on 1 of {os.cpu_count()} host cores ({platform.processor() or platform.machine()}, "
+                      f"reset on done, {dt:.1f} s on 1 of {os.cpu_count()} host cores ({_cpu_model()}, {platform.machine()}, "
                       f"CPython {platform.python_version()}); oracle/battlespace_ref.py"}
 
 
@@ -217,11 +227,34 @@ def main():
             multi["traffic_per_tick"] = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[f"E{E}_n{n}_many"]["hbm_bytes_per_tick"]
         except Exception:
             multi["traffic_per_tick"] = None
+    loop_sampling = None
+    if world == 1 and not args.no_other_workloads and not args.continuous:
+        # the same loop with the actions SAMPLED inside it (one torch.randint + one step() call per
+        # tick from Python, no graph): what a caller that draws random actions tick by tick sees
+        del env
+        torch.cuda.empty_cache()
+        env = sharding.make_shard(E, 0, 1, n_agents=n, device=dev, seed=1234, auto_reset=True)
+        env.reset()
+        gen2 = torch.Generator(device=dev); gen2.manual_seed(1234)
+        Ks = min(K, 500)
+        for _ in range(50):
+            env.step_batch(torch.randint(0, 4, (E, A), generator=gen2, device=dev, dtype=torch.int32))
+        torch.cuda.synchronize(dev); t0 = time.perf_counter()
+        for _ in range(Ks):
+            env.step_batch(torch.randint(0, 4, (E, A), generator=gen2, device=dev, dtype=torch.int32))
+        torch.cuda.synchronize(dev); dts = time.perf_counter() - t0
+        loop_sampling = {"agent_steps_per_s": round(E * A * Ks / dts, 1), "us_per_step": round(dts / Ks * 1e6, 2), "steps": Ks,
+                         "note": "eager Python loop: torch.randint + step_batch per tick"}
     if world == 1 and not args.no_other_workloads and (n, E) == (1, 65536):
-        for tag, (n2, E2, K2) in {"configs[2] 65536 x 4v4": (4, 65536, 400), "1048576 x 1v1 (streaming)": (1, 1048576, 200)}.items():
+        for tag, (n2, E2, K2) in {"configs[2] 65536 x 4v4": (4, 65536, 400), "1048576 x 1v1 (streaming)": (1, 1048576, 200),
+                                  "65536 x 1v1, all-shoot stress (action = 1 every tick, ~11 live bullets per agent)": (1, 65536, 400)}.items():
             del env
             torch.cuda.empty_cache()
+            saved_mix = args.action_mix
+            if "all-shoot" in tag:
+                args.action_mix = "shoot"
             env, dt2, km2, _ = measure(n2, E2, K2, 50, args.mode, 100)
+            args.action_mix = saved_mix
             ach = b_alg(n2) * E2 * 2 * n2 / (km2 * 1e-3) / 1e9
             others[tag] = {"agent_steps_per_s": round(E2 * 2 * n2 * K2 / dt2, 1), "avg_launch_us": round(km2 * 1e3, 2),
                            "roofline_frac": round(ach / HBM_PEAK_GBS, 4)}
@@ -252,13 +285,21 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": f"bsx_step_kernel<{n if n <= 4 else 0},{'true' if args.continuous else 'false'},{'true' if args.mode == 'many' else 'false'},false>", "avg_launch_us": round(kernel_ms * 1e3, 3),
-                         "algorithmic_bytes_per_launch": round(bytes_per_launch), "bytes_per_agent_step": round(b_alg(n), 2)},
+                         "algorithmic_bytes_per_launch": round(bytes_per_launch), "bytes_per_agent_step": round(b_alg(n), 2),
+                         # SURVEY.md section 8d asks for these beside it: the API-only lower bound (action in; obs, reward, done out)
+                         # and the fraction on the bytes that actually reached HBM (PMC)
+                         "io_only_bytes_per_agent_step": 4 + 4 * (3 * n + 2) + 4 + 1,
+                         "io_only_frac": round((4 + 4 * (3 * n + 2) + 4 + 1) * E * A / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "traffic_frac": round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
+                         "regime": "latency-bound at this size: 2 wavefronts per SIMD, working set 48 MB inside the 256 MB Infinity Cache "
+                                   "(DESIGN.md section 6)" if (n, E) == (1, 65536) and args.mode != "many" else None},
             "games_finished": int(games[0]), "ties": int(games[1]), "red_wins": int(games[2]), "blue_wins": int(games[3]),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         out["other_workloads"] = others
         out["multi_tick_launch"] = multi
+        out["loop_incl_action_sampling"] = loop_sampling
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
