@@ -301,11 +301,12 @@ class parallel_env:
                     u[e, i] = _stdlib_random.random()
         return u
 
-    def step_batch(self, actions, u=None):
+    def step_batch(self, actions, u=None, copy=False):
         """One tick for all games.  actions: int [E, A] | float [E, A, 4] score vectors (arg-maxed in-kernel) |
         float [E, A, 3] when continuous | {} (every running game ties).  u: optional float64 [E, A] of random()
         values to use for this call's shots instead of the generator.  Returns the env-owned tensors
-        (obs [E, A, D] f32, rew [E, A] f32, done [E, A] bool), overwritten by the next call."""
+        (obs [E, A, D] f32, rew [E, A] f32, done [E, A] bool), overwritten by the next call; copy=True returns fresh
+        tensors instead (the reference hands out fresh arrays every step, battle_env.py:374-381)."""
         act_t, kind, empty = self._pack_actions(actions)
         if u is None and self.rng == "python":
             u = self._draw_jitter(act_t, kind, empty)
@@ -320,6 +321,8 @@ class parallel_env:
                      self._obs.data_ptr(), self._rew.data_ptr(), self._done.data_ptr())
         if self._mirror:
             self._sync_mirror()
+        if copy:
+            return self._obs.clone(), self._rew.clone(), self._done.view(torch.bool).clone()
         return self._obs, self._rew, self._done.view(torch.bool)
 
     def _launch(self, act_ptr, kind, empty, u_ptr, obs_ptr, rew_ptr, done_ptr):
@@ -450,11 +453,12 @@ class parallel_env:
         self._h_tick = st["tick"].cpu().numpy().astype(np.int64)
         self._h_done = st["env_done"].cpu().numpy().astype(bool)
 
-    def step(self, actions, u=None):
-        """The reference's 4-tuple: (observations, rewards, dones, infos), each a dict keyed by agent id."""
+    def step(self, actions, u=None, copy=False):
+        """The reference's 4-tuple: (observations, rewards, dones, infos), each a dict keyed by agent id.  Batched mode:
+        the dict values are views of the env-owned tensors (overwritten by the next call) unless copy=True."""
         if self._compat:
             return self._step_compat(actions, u)
-        obs, rew, done = self.step_batch(actions, u)
+        obs, rew, done = self.step_batch(actions, u, copy=copy)
         return (self._agent_views(obs), self._agent_views(rew), self._agent_views(done),
                 {a: {} for a in self.possible_agents})
 

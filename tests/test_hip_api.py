@@ -34,6 +34,17 @@ def test_dict_api_is_a_view_of_the_batched_tensors():
     assert a.env_done.dtype == torch.bool and a.winner.dtype == torch.uint8 and a.agents == a.possible_agents
 
 
+def test_copy_option_returns_tensors_that_survive_the_next_call():
+    env = _env(n_agents=1, n_envs=64, seed=2); env.reset()
+    a = torch.ones((64, 2), dtype=torch.int32, device="cuda")
+    o1, r1, d1 = env.step_batch(a, copy=True)
+    keep = (o1.clone(), r1.clone(), d1.clone())
+    o2, _, _ = env.step_batch(a)
+    assert o1.data_ptr() != o2.data_ptr() and torch.equal(o1, keep[0]) and torch.equal(r1, keep[1]) and torch.equal(d1, keep[2])
+    od, _, _, _ = env.step({f"plane{i}": a[:, i] for i in range(2)}, copy=True)
+    assert od["plane0"].data_ptr() != env._obs.data_ptr()
+
+
 def test_inert_after_done_inside_a_batch_and_masked_reset():
     """auto_reset=False: finished games ignore step() (battle_env.py:303-306) while the others keep playing; a masked
     reset re-spawns only the selected games and keeps every counter (battle_env.py:246-279)."""

@@ -168,7 +168,7 @@ def test_graph_replay_equals_eager_steps():
     assert all(torch.equal(sa[k], sb[k]) for k in ("px", "py", "php", "tick", "counters", "bl_live"))
 
 
-@pytest.mark.parametrize("E,n,mode", [(4096, 1, "int"), (1000, 2, "int"), (515, 4, "int"), (300, 6, "int"),
+@pytest.mark.parametrize("E,n,mode", [(4096, 1, "int"), (1000, 2, "int"), (515, 4, "int"), (300, 6, "int"), (33, 16, "int"), (70, 3, "cont64"),
                                       (2048, 1, "scores"), (1024, 2, "cont32"), (777, 1, "cont64")])
 def test_step_many_equals_consecutive_step_calls(E, n, mode):
     """bsx_step_many_*: T ticks in ONE launch (a wavefront walks its games through all of them, state through the L2)
