@@ -55,7 +55,8 @@ for sub, name in (("many_stats", "many_kernel_stats"), ("rollout_stats", "rollou
     ks = glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
     if ks:
         shutil.copy(ks[0], os.path.join(dst, f"{tag}_{name}.csv"))
-for f in ("many_rollout_pmc_summary.json", "rollout_graph.json", "rollout_one_launch.json", "rollout_graph_4v4.json"):
+for f in ("many_rollout_pmc_summary.json", "rollout_graph.json", "rollout_one_launch.json", "rollout_graph_4v4.json",
+          "rollout_graph_bf16x3.json", "rollout_one_launch_bf16x3.json", "rollout_graph_4v4_bf16x3.json"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{f}"))
 mp = os.path.join(src, "many_rollout_pmc_summary.json")
