@@ -210,7 +210,7 @@ struct StepArgs {
     // multi-tick launches (bsx_step_many_*): T ticks, per-tick strides of the action / output arrays (0 = same array every tick)
     int T; int64_t act_tb /* bytes */, u_ts, obs_ts, rew_ts, done_ts /* elements */;
     // fused rollout (bsx_rollout_discrete): the actor in front of every tick
-    const float* aw; int aprec; const float* obs0; float* scores; int64_t scores_ts; BsxActorNoise nz; uint64_t aseed, aseq; const uint64_t* aseq_base;
+    const float* aw; int aprec; int scripted_team /* -1 none, 0 red, 1 blue */; const float* obs0; float* scores; int64_t scores_ts; BsxActorNoise nz; uint64_t aseed, aseq; const uint64_t* aseq_base;
 };
 
 // Observation row for one agent from the LDS-staged block (battle_env.py:202-244).
@@ -262,6 +262,26 @@ __device__ inline void spawn_plane(uint64_t seed, int64_t genv, uint32_t stream,
 }
 
 enum Mode : int { M_INERT = 0, M_TIE = 1, M_PHYS = 2, M_RESET = 3 };
+
+// The scripted opponent's target choice and discrete action (instinct/agent.py:10-39,56-62) from one observation row,
+// ob(k) = value k of the row: score every target by dist * |angle| (base first, strict '<' keeps the first minimum, a dead
+// enemy scores 1e6), shoot inside 250 px and 20 degrees, else turn toward it.  binary64 on the float32 values, as the
+// reference computes under its pinned numpy.  Also returns the chosen target's distance / angle (continuous branch).
+template <class OB>
+__device__ inline int instinct_choose(OB ob, int n, double& td, double& ta) {
+    td = (double(ob(0)) + 1.0) / 2.0 * FIELD_DIAG;               // agent.py:15-16
+    ta = double(ob(1)) * 360.0;
+    double best = td * fabs(ta);
+    for (int j = 0; j < n; ++j) {                                // agent.py:20-39
+        const double d = (double(ob(3 + 3 * j)) + 1.0) / 2.0 * FIELD_DIAG, an = double(ob(4 + 3 * j)) * 360.0;
+        const double sc = (ob(2 + 3 * j) == 1.0f) ? d * fabs(an) : 1000000.0;
+        if (sc < best) { best = sc; td = d; ta = an; }
+    }
+    return (td < 250.0 && fabs(ta) < 20.0) ? 1 : (ta > 0.0 ? 3 : 2);   // agent.py:56-62
+}
+__device__ inline float4 one_hot_scores(int act) {               // what the score-vector step path arg-maxes back to `act`
+    return make_float4(act == 0 ? 1.f : -1.f, act == 1 ? 1.f : -1.f, act == 2 ? 1.f : -1.f, act == 3 ? 1.f : -1.f);
+}
 
 // ---------------------------------------------------------------------------------------------- the step kernel
 // Record (un)packing on raw 16-byte words: keeps the loads as single dwordx4 instructions with no byte shuffling.
@@ -432,6 +452,7 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
         float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma nounroll
         for (int nt = 0; nt < 2; ++nt) {                 // one tile at a time: its 64 weight registers are reused by the next
+            if (p.scripted_team == nt) continue;         // that team is played by the scripted opponent: no actor for its rows
             const float* const Wn = p.aw + size_t(nt) * bsx_actor::blob_floats(D);
             const float* const smn = s_small + nt * bsx_actor::SMALL;
             auto xb = [&](int k) { return k < D ? s_obs[(2 * c + nt) * D + k] : 0.f; };
@@ -446,7 +467,12 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
         const size_t row = size_t(row_ok ? er_ : p.E - 1) * A + hh;
         const uint64_t aseq = p.aseq + (p.aseq_base ? *p.aseq_base : 0ull) + uint64_t(tk);
         const bool game_over = __shfl(er.done, 2 * c) != 0;
-        r4 = bsx_actor::finish_row(r4, b3, p.nz, p.aseed, aseq, row, game_over, row_ok);
+        if (p.scripted_team == hh) {                     // instinct/team.py:13-15 for this team's rows, as one-hot score rows
+            double td_, ta_;
+            r4 = one_hot_scores(instinct_choose([&](int k) { return s_obs[(2 * c + hh) * D + k]; }, N, td_, ta_));
+        } else {
+            r4 = bsx_actor::finish_row(r4, b3, p.nz, p.aseed, aseq, row, game_over, row_ok);
+        }
         if (row_ok) reinterpret_cast<float4*>(p.scores + int64_t(tk) * p.scores_ts)[row] = r4;
         const float v[4] = {r4.x, r4.y, r4.z, r4.w};
         int am = 0;
@@ -937,18 +963,11 @@ __global__ __launch_bounds__(TPB) void bsx_instinct_kernel(const InstinctArgs p)
     const int tm = a < p.n ? 0 : 1;
     if (p.team != 2 && p.team != tm) return;
     const float* o = p.obs + g * D;
-    double td = (double(o[0]) + 1.0) / 2.0 * FIELD_DIAG;          // agent.py:15-16
-    double ta = double(o[1]) * 360.0;
-    double best = td * fabs(ta);
-    for (int j = 0; j < p.n; ++j) {                               // agent.py:20-39: strict '<' keeps the first minimum
-        const double d = (double(o[3 + 3 * j]) + 1.0) / 2.0 * FIELD_DIAG, an = double(o[4 + 3 * j]) * 360.0;
-        const double sc = (o[2 + 3 * j] == 1.0f) ? d * fabs(an) : 1000000.0;
-        if (sc < best) { best = sc; td = d; ta = an; }
-    }
-    if (!p.continuous) {                                          // agent.py:56-62
-        const int act = (td < 250.0 && fabs(ta) < 20.0) ? 1 : (ta > 0.0 ? 3 : 2);
+    double td, ta;
+    const int act = instinct_choose([&](int k) { return o[k]; }, p.n, td, ta);
+    if (!p.continuous) {
         if (p.out_kind == BSX_ACT_I32) static_cast<int32_t*>(p.actions)[g] = act;
-        else static_cast<float4*>(p.actions)[g] = make_float4(act == 0 ? 1.f : -1.f, act == 1 ? 1.f : -1.f, act == 2 ? 1.f : -1.f, act == 3 ? 1.f : -1.f);
+        else static_cast<float4*>(p.actions)[g] = one_hot_scores(act);
         return;
     }
     double r0, n0, n1, n2;                                        // agent.py:41-54
@@ -997,7 +1016,7 @@ int launch_step(void* state, int64_t E, int n, const void* actions, int action_k
     a.obs = obs; a.rew = rew; a.done = done; a.env_done = env_done; a.winner = winner;
     a.cfg = *cfg; a.flags = flags; a.seed = seed; a.env_offset = env_offset; a.tie_tick = bsx_tie_tick(n);
     const int64_t EA = E * 2 * n;
-    a.aw = nullptr; a.aprec = 0; a.obs0 = nullptr; a.scores = nullptr; a.scores_ts = 0; a.nz = BsxActorNoise{0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr};
+    a.aw = nullptr; a.aprec = 0; a.scripted_team = -1; a.obs0 = nullptr; a.scores = nullptr; a.scores_ts = 0; a.nz = BsxActorNoise{0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr};
     a.aseed = 0; a.aseq = 0; a.aseq_base = nullptr;
     a.T = T;
     a.act_tb = EA * (CONT ? (action_kind == BSX_ACT_F32 ? 12 : (action_kind == BSX_ACT_F64 ? 24 : 16)) : (action_kind == BSX_ACT_I32 ? 4 : 16));
@@ -1112,13 +1131,13 @@ int bsx_step_many_continuous(void* state, int64_t E, int n, int T, const void* a
                              env_offset, stream, T, store_all);
 }
 
-int bsx_rollout_discrete(void* state, int64_t E, int n, int T, const float* weights, int precision, float* obs, float* scores, float* rew,
+int bsx_rollout_discrete(void* state, int64_t E, int n, int T, const float* weights, int precision, int scripted_team, float* obs, float* scores, float* rew,
                          uint8_t* done, uint8_t* env_done, uint8_t* winner, const BsxRewards* cfg, uint32_t flags,
                          const BsxActorNoise* noise, uint64_t actor_seed, uint64_t seq, const uint64_t* seq_base, uint64_t seed,
                          int64_t env_offset, void* stream) {
     if (!state || E <= 0 || E > BSX_MAX_E || n != 1 || T < 1 || T > BSX_MAX_T || !weights || !obs || !scores || !rew || !done || !cfg)
         return BSX_E_ARG;
-    if ((flags & BSX_F_EMPTY_CALL) || (precision != BSX_ACTOR_F32 && precision != BSX_ACTOR_BF16X3)) return BSX_E_ARG;
+    if ((flags & BSX_F_EMPTY_CALL) || (precision != BSX_ACTOR_F32 && precision != BSX_ACTOR_BF16X3) || scripted_team < -1 || scripted_team > 1) return BSX_E_ARG;
     if (!aligned(state, 256) || !aligned(weights, 16) || !aligned(scores, 16) || !aligned(obs, 4) || !aligned(rew, 4)) return BSX_E_ALIGN;
     BsxActorNoise nz = {0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr};
     if (noise) nz = *noise;
@@ -1130,7 +1149,7 @@ int bsx_rollout_discrete(void* state, int64_t E, int n, int T, const float* weig
     a.obs = obs + EA * D; a.rew = rew; a.done = done; a.env_done = env_done; a.winner = winner;
     a.cfg = *cfg; a.flags = flags; a.seed = seed; a.env_offset = env_offset; a.tie_tick = bsx_tie_tick(n);
     a.T = T; a.act_tb = 0; a.u_ts = 0; a.obs_ts = EA * D; a.rew_ts = EA; a.done_ts = EA;
-    a.aw = weights; a.aprec = precision; a.obs0 = obs; a.scores = scores; a.scores_ts = EA * 4; a.nz = nz; a.aseed = actor_seed; a.aseq = seq;
+    a.aw = weights; a.aprec = precision; a.scripted_team = scripted_team; a.obs0 = obs; a.scores = scores; a.scores_ts = EA * 4; a.nz = nz; a.aseed = actor_seed; a.aseq = seq;
     a.aseq_base = seq_base;
     hipLaunchKernelGGL((bsx_step_kernel<1, false, true, true>), dim3(grid_for(E, n, SPB)), dim3(SPB), 0,
                        static_cast<hipStream_t>(stream), a);

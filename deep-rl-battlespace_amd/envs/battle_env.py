@@ -401,14 +401,16 @@ class parallel_env:
             self._sync_mirror()
         return obs, rew, done.view(torch.bool)
 
-    def _launch_rollout(self, T, weights_ptr, precision, obs_ptr, scores_ptr, rew_ptr, done_ptr, noise, actor_seed, seq, seq_base_ptr):
+    def _launch_rollout(self, T, weights_ptr, precision, scripted_team, obs_ptr, scores_ptr, rew_ptr, done_ptr, noise, actor_seed, seq,
+                        seq_base_ptr):
         """Enqueue bsx_rollout_discrete: T ticks of (actor -> step) in one launch (used by rollout.PolicyRollout)."""
         if self.continuous_actions or self.n_agents != 1:
             raise ValueError("the one-launch rollout is built for discrete 1v1")
         flags = _lib.F_AUTO_RESET if self.auto_reset else 0
         with self._guard():
             _lib.check(self._lib.bsx_rollout_discrete(
-                self._state.data_ptr(), self.n_envs, self.n_agents, int(T), weights_ptr, int(precision), obs_ptr, scores_ptr, rew_ptr, done_ptr,
+                self._state.data_ptr(), self.n_envs, self.n_agents, int(T), weights_ptr, int(precision), int(scripted_team), obs_ptr, scores_ptr,
+                rew_ptr, done_ptr,
                 self._env_done.data_ptr(), self._winner.data_ptr(), ctypes.byref(self._cfg), flags,
                 ctypes.byref(noise) if noise is not None else None, int(actor_seed), int(seq), seq_base_ptr, self.seed,
                 self.env_offset, self._stream()), "bsx_rollout_discrete")

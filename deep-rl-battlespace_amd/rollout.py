@@ -222,11 +222,13 @@ class PolicyRollout:
             self.ou = dict(scale=float(ou_scale), env_done=env._env_done,
                            state=torch.zeros((env.n_envs, env._A, 4), dtype=torch.float32, device=env.device))
         # one_launch: all T ticks (actor -> step) in ONE kernel (bsx_rollout_discrete) instead of 2T launches in a graph:
-        # observation rows stay in LDS between the step and the actor, game state in registers / L2.  Discrete 1v1, no
-        # scripted opponent; same transitions, bit for bit.
+        # observation rows stay in LDS between the step and the actor, game state in registers / L2.  Discrete 1v1; a scripted
+        # opponent (instinct.Team of one side) is played in-kernel and its actor is skipped; same transitions, bit for bit.
         self.one_launch = bool(one_launch)
-        if self.one_launch and (not fused or opponent is not None or env.n_agents != 1 or env.continuous_actions):
-            raise ValueError("one_launch needs the fused actor, discrete 1v1 and no scripted opponent")
+        if self.one_launch and (not fused or env.n_agents != 1 or env.continuous_actions):
+            raise ValueError("one_launch needs the fused actor and a discrete 1v1 env")
+        if self.one_launch and opponent is not None and getattr(opponent, "team", None) not in (0, 1):
+            raise ValueError("one_launch plays a scripted opponent in-kernel: it must be an instinct.Team of one side")
         self._seq_base = torch.zeros(1, dtype=torch.int64, device=env.device)
         E, A, D, dev = env.n_envs, env._A, env.obs_size, env.device
         self.obs = torch.empty((T + 1, E, A, D), dtype=torch.float32, device=dev)
@@ -280,7 +282,8 @@ class PolicyRollout:
         self.obs[0].copy_(self.obs[self.T])            # continue where the previous rollout ended
         if self.one_launch:
             nz = self.fused.noise_struct(self.env.n_envs, self.noise_std, self.ou)
-            self.env._launch_rollout(self.T, self.fused.weights.data_ptr(), self.fused.precision, self.obs.data_ptr(), self.scores.data_ptr(),
+            self.env._launch_rollout(self.T, self.fused.weights.data_ptr(), self.fused.precision,
+                                     -1 if self.opponent is None else self.opponent.team, self.obs.data_ptr(), self.scores.data_ptr(),
                                      self.rew.data_ptr(), self._done.data_ptr(), nz, self.fused.seed, 0, self._seq_base.data_ptr())
         else:
             for t in range(self.T):

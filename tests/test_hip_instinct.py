@@ -128,3 +128,37 @@ def test_rollout_with_learned_red_and_scripted_blue():
     assert not bool(((ro.scores[:, :, :n].abs() == 1).all(-1)).all())                                             # red rows are the actor's
     c = env.counters().sum(0)
     assert c[3] > c[2] and c[0] > 0                               # the scripted team beats a random-weight actor
+
+
+@pytest.mark.parametrize("scripted", ["blue", "red"])
+def test_one_launch_rollout_plays_the_scripted_opponent_in_kernel(scripted):
+    """bsx_rollout_discrete with scripted_team: the reference's training setup (main.py:119-122: learned team vs
+    instinct.Team) as ONE launch -- the scripted side's rows are decided in-kernel from the observation rows in LDS and
+    its actor is skipped.  Same transitions, bit for bit, as the two-kernel rollout with `opponent.write_actions`."""
+    from deep_rl_battlespace_amd import instinct
+    from deep_rl_battlespace_amd.rollout import PolicyRollout, StackedActor
+    E, n, T = 4100, 1, 40
+    torch.manual_seed(1)
+    actor = StackedActor(2, 5, 4, device="cuda")
+    with torch.no_grad():
+        actor.w3.mul_(60.0)
+    ros = []
+    for one in (False, True):
+        env = _env(n_agents=n, n_envs=E, seed=17, auto_reset=True); env.reset()
+        opp = (instinct.Team(env.possible_blue, env.possible_red, env) if scripted == "blue"
+               else instinct.Team(env.possible_red, env.possible_blue, env))
+        ro = PolicyRollout(env, actor, T, noise_std=0.2, seed=5, opponent=opp, one_launch=one); ro.start(); ro.capture()
+        ros.append(ro)
+    a, b = ros
+    for rep in range(5):
+        a.run(); b.run()
+        torch.cuda.synchronize()
+        assert torch.equal(a.obs, b.obs) and torch.equal(a.scores, b.scores), rep
+        assert torch.equal(a.rew, b.rew) and torch.equal(a.done, b.done), rep
+    col = 1 if scripted == "blue" else 0
+    assert bool(((b.scores[:, :, col] == 1).sum(-1) == 1).all()) and bool(((b.scores[:, :, col].abs() == 1).all()))
+    sa, sb = a.env.export_state(), b.env.export_state()
+    for k in ("px", "py", "pdir", "php", "bhp", "tick", "env_done", "winner", "bl_live", "counters"):
+        assert torch.equal(sa[k], sb[k]), k
+    c = b.env.counters().sum(0)
+    assert c[0] > 0 and (c[3] > c[2] if scripted == "blue" else c[2] > c[3])    # the scripted side wins more often

@@ -14,6 +14,7 @@ ap.add_argument("--T", type=int, default=32); ap.add_argument("--reps", type=int
 ap.add_argument("--noise", type=float, default=0.1); ap.add_argument("--torch-actor", action="store_true")
 ap.add_argument("--one-launch", action="store_true", help="all T ticks in one kernel (bsx_rollout_discrete; 1v1)")
 ap.add_argument("--precision", default="f32", choices=("f32", "bf16x3"), help="the actor's 64 x 64 layer")
+ap.add_argument("--scripted-blue", action="store_true", help="blue is the scripted opponent (instinct.Team), red the actor: main.py:119-122")
 args = ap.parse_args()
 E, n, T = args.envs, args.n_agents, args.T
 A, D = 2 * n, 3 * n + 2
@@ -23,7 +24,12 @@ torch.manual_seed(0)
 actor = StackedActor(A, D, 4, device="cuda")
 with torch.no_grad():
     actor.w3.mul_(100.0)
-ro = PolicyRollout(env, actor, T, noise_std=args.noise, fused=not args.torch_actor, one_launch=args.one_launch, precision=args.precision)
+opp = None
+if args.scripted_blue:
+    from deep_rl_battlespace_amd import instinct
+    opp = instinct.Team(env.possible_blue, env.possible_red, env)
+ro = PolicyRollout(env, actor, T, noise_std=args.noise, fused=not args.torch_actor, one_launch=args.one_launch, precision=args.precision,
+                   opponent=opp)
 ro.start(); ro.capture()
 
 
@@ -57,4 +63,5 @@ print(json.dumps({"workload": f"{E} games x {n}v{n} + on-device actor (obs {D} -
                   "rollout_agent_steps_per_s": round(E * A / t_roll, 1), "rollout_us_per_tick": round(t_roll * 1e6, 2),
                   "env_only_us_per_tick": round(t_env * 1e6, 2), "actor_only_us_per_tick": round(t_act * 1e6, 2),
                   "actor": "torch ops" if args.torch_actor else f"fused HIP kernel (bsx_actor_forward), 64 x 64 layer in {args.precision}",
-                  "launch": "one kernel for all T ticks (bsx_rollout_discrete)" if args.one_launch else "HIP graph of 2T kernels", "noise_std": args.noise, "games_finished": int(c[0]), "ties": int(c[1]), "red_wins": int(c[2]), "blue_wins": int(c[3])}))
+                  "launch": "one kernel for all T ticks (bsx_rollout_discrete)" if args.one_launch else "HIP graph of 2T kernels", "opponent": "blue = scripted instinct.Team, red = actor" if args.scripted_blue else "both teams act by their actors",
+                  "noise_std": args.noise, "games_finished": int(c[0]), "ties": int(c[1]), "red_wins": int(c[2]), "blue_wins": int(c[3])}))
