@@ -5,7 +5,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libbattlespace_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 BULLET_SLOTS = 12
 MAX_N = 16
 MAX_T = 65535

@@ -317,22 +317,28 @@ __device__ inline void obs_pair(int x, int y, double dir, int tx, int ty, float&
 // only ordering needed between ticks is this wave's own stores before its own loads (a workgroup-scope fence = a wait,
 // no cache maintenance: same CU, same L1); the state stays in the L2 instead of crossing a kernel boundary (write-back +
 // invalidate + a cold first round trip) every tick.
-// ACTOR (1v1, discrete, MULTI): the caller's whole rollout loop `for t: actions = actor(obs); obs, rew, done = step(actions)`
-// (main.py:177-181) in one launch.  A wave's 64 observation rows never leave the CU: the step leaves them in LDS, the
-// actor (bsx_actor_core.h, MFMA) reads them there as its B operands -- tile 0 = the 32 red planes, tile 1 = the 32 blue
-// ones, each with its own weights --, finishes row (lane & 31) of agent (lane >> 5), and one cross-lane move hands every
-// plane its arg-max.
+// ACTOR (discrete, MULTI, n <= 4): the caller's whole rollout loop `for t: actions = actor(obs); obs, rew, done = step(actions)`
+// (main.py:177-181) in one launch.  The observation rows never leave the CU: the step leaves them in LDS, the actor
+// (bsx_actor_core.h, MFMA) reads them there as its B operands.  An MFMA tile is 32 rows of ONE actor, so a workgroup is
+// 32 games = G/2 waves (1v1: one wave, 2v2: two, 3v3 / 4v4: four) and holds one tile per plane id; wave w runs the tiles of
+// planes w and w + G/2 (tile 0 in its lower lane half's name, tile 1 in the upper's), lane l finishes row (game l & 31 of the
+// workgroup, that plane), and the arg-max travels back to the plane's own lane through LDS (one cross-lane move for 1v1).
+// Everything else stays private to a wave exactly as in the other variants: a wave still only touches its own games.
 template <int N, bool CONT, bool MULTI, bool ACTOR = false>
-__global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
+__global__ __launch_bounds__(SPB * (ACTOR ? group_width(N > 0 ? N : 1) / 2 : 1)) __attribute__((amdgpu_waves_per_eu((ACTOR && N > 1) ? 2 : 1)))
+void bsx_step_kernel(const StepArgs p) {
     STAMP(8);                                            // diagnostic builds: kernel entry, before any kernarg load
+    constexpr int WAVES = ACTOR ? group_width(N > 0 ? N : 1) / 2 : 1;
     const int n = (N > 0) ? N : p.n;
     const int A = 2 * n;
     const int G = group_width(n);
     const int EPB = SPB / G;
-    const int tid = threadIdx.x;
+    const int wave = (WAVES > 1) ? int(threadIdx.x >> 6) : 0;
+    const int tid = (WAVES > 1) ? int(threadIdx.x & 63) : int(threadIdx.x);   // position in my wave = LDS index in its private arrays
+    const int64_t wblk = (WAVES > 1) ? int64_t(blockIdx.x) * WAVES + wave : int64_t(blockIdx.x);   // which 64 lanes of the job I am
     const int a = tid & (G - 1);
     const int gl = tid & ~(G - 1);                       // first thread of my env's group
-    const int64_t e = int64_t(blockIdx.x) * EPB + (tid / G);
+    const int64_t e = wblk * EPB + (tid / G);
     const bool env_ok = e < p.E;
     const bool valid = env_ok && a < A;
     const size_t EA = size_t(p.E) * size_t(A);
@@ -346,10 +352,18 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
 
     // LDS is private to this wavefront: accesses are volatile (program order) and the hardware runs one wave's LDS
     // operations in order, so cross-lane hand-offs need no s_barrier -- only a compiler scheduling fence.
-    __shared__ volatile int s_x[SPB], s_y[SPB], s_hp[SPB];
-    __shared__ volatile int s_bhit[SPB];                 // base hits, index gl + shooter team
-    __shared__ __attribute__((aligned(16))) float s_obs[SPB * ((N > 0) ? 3 * N + 2 : 3 * BSX_MAX_N + 2)];   // observation rows of the wave
-    __shared__ __attribute__((aligned(16))) float s_small[ACTOR ? 2 * bsx_actor::SMALL : 4];              // per-neuron vectors + heads of both actors
+    constexpr int DROW = (N > 0) ? 3 * N + 2 : 3 * BSX_MAX_N + 2;
+    __shared__ volatile int s_x_all[WAVES * SPB], s_y_all[WAVES * SPB], s_hp_all[WAVES * SPB];
+    __shared__ volatile int s_bhit_all[WAVES * SPB];     // base hits, index gl + shooter team
+    __shared__ __attribute__((aligned(16))) float s_obs_all[WAVES * SPB * DROW];   // observation rows, [wave][lane][D]
+    __shared__ __attribute__((aligned(16))) float s_small[ACTOR ? 2 * (N > 0 ? N : 1) * bsx_actor::SMALL : 4];   // per-neuron vectors + heads of the actors
+    __shared__ int s_act_all[(ACTOR && WAVES > 1) ? WAVES * SPB : 1];                // arg-max per row, ACTOR with several waves
+    __shared__ int s_gdone_all[(ACTOR && WAVES > 1) ? 32 : 1];                       // game-over flag per game of the workgroup
+    volatile int* const s_x = s_x_all + wave * SPB;
+    volatile int* const s_y = s_y_all + wave * SPB;
+    volatile int* const s_hp = s_hp_all + wave * SPB;
+    volatile int* const s_bhit = s_bhit_all + wave * SPB;
+    float* const s_obs = s_obs_all + wave * SPB * DROW;
 
     // Raw inputs of one call (decoded at the top of the tick that uses them).
     struct RawIn { int ai; float4 lg; float f0, f1, f2; double c0, c1, c2, uu; };
@@ -385,17 +399,21 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     if (MULTI && !ACTOR) load_inputs(0, rin_next);
     if constexpr (ACTOR) {
         constexpr int D = 3 * N + 2;
-        for (int i = tid; i < 2 * bsx_actor::SMALL / 4; i += SPB) {
+        for (int i = int(threadIdx.x); i < 2 * N * bsx_actor::SMALL / 4; i += SPB * WAVES) {
             const int ag = i / (bsx_actor::SMALL / 4), j = i - ag * (bsx_actor::SMALL / 4);
             reinterpret_cast<float4*>(s_small)[i] =
                 reinterpret_cast<const float4*>(p.aw + size_t(ag) * bsx_actor::blob_floats(D) + bsx_actor::off_small(D))[j];
         }
         // the observations the rollout starts from (obs[0]): this wave's rows are one contiguous block
-        const int64_t e_first = int64_t(blockIdx.x) * EPB;
+        const int64_t e_first = wblk * EPB;
         const int64_t nfl = min(int64_t(SPB), (p.E - e_first) * A) * D;
-        for (int i = tid; i < SPB * D; i += SPB) s_obs[i] = i < nfl ? p.obs0[size_t(e_first) * A * D + i] : -1.0f;
+        if (G == A) {
+            for (int i = tid; i < SPB * D; i += SPB) s_obs[i] = i < nfl ? p.obs0[size_t(e_first) * A * D + i] : -1.0f;
+        } else {                                         // 3v3: lanes 6, 7 of a group own no row
+            for (int k = 0; k < D; ++k) s_obs[tid * D + k] = valid ? p.obs0[g * D + k] : -1.0f;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        if (WAVES > 1) __syncthreads(); else __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 
@@ -447,29 +465,38 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
     if (u_t) uu_in = rin.uu;                             // uniform branch
     if constexpr (ACTOR) {
         // ---- actions = argmax(actor(obs)) (maddpg/agent.py:25-33, battle_env.py:327-328), rows straight from LDS
-        constexpr int D = 3 * N + 2;
-        const int hh = lane >> 5, c = lane & 31;
+        constexpr int D = 3 * N + 2, A_ = 2 * N, G_ = group_width(N);
+        if (WAVES > 1) {                                 // every wave's rows (written at the end of the last tick) and game flags
+            if (a == 0) s_gdone_all[wave * (SPB / G_) + tid / G_] = er.done;
+            __syncthreads();
+        }
+        const int hh = lane >> 5, c = lane & 31;         // I finish row (game c of the workgroup, plane id `mine`)
+        const int mine = wave + hh * WAVES;
+        const bool has_row = mine < A_;                  // 3v3: waves 2 and 3 have one tile only
+        const int mine_c = has_row ? mine : A_ - 1;
         float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma nounroll
-        for (int nt = 0; nt < 2; ++nt) {                 // one tile at a time: its 64 weight registers are reused by the next
-            if (p.scripted_team == nt) continue;         // that team is played by the scripted opponent: no actor for its rows
-            const float* const Wn = p.aw + size_t(nt) * bsx_actor::blob_floats(D);
-            const float* const smn = s_small + nt * bsx_actor::SMALL;
-            auto xb = [&](int k) { return k < D ? s_obs[(2 * c + nt) * D + k] : 0.f; };
+        for (int ti = 0; ti < 2; ++ti) {                 // one tile at a time: its 64 weight registers are reused by the next
+            const int ag = wave + ti * WAVES;            // wave-uniform
+            if (ag >= A_ || p.scripted_team == (ag >= N ? 1 : 0)) continue;   // no such plane / played by the scripted opponent
+            const float* const Wn = p.aw + size_t(ag) * bsx_actor::blob_floats(D);
+            const float* const smn = s_small + ag * bsx_actor::SMALL;
+            auto xb = [&](int k) { return k < D ? s_obs_all[(c * G_ + ag) * D + k] : 0.f; };
             const float4 o = p.aprec == BSX_ACTOR_BF16X3 ? bsx_actor::tile_forward<true>(Wn, smn, D, lane, xb)      // uniform branch
                                                          : bsx_actor::tile_forward<false>(Wn, smn, D, lane, xb);
-            // lower half finishes the red rows, upper half the blue ones: lane l owns row (game c, agent hh)
-            if (hh == nt) r4 = o;
+            if (hh == ti) r4 = o;                        // lower half finishes the wave's first tile, upper half the second
         }
-        const float4 b3 = *reinterpret_cast<const float4*>(s_small + hh * bsx_actor::SMALL + 6 * bsx_actor::H + bsx_actor::H * bsx_actor::NA);
-        const int64_t er_ = int64_t(blockIdx.x) * EPB + c;
-        const bool row_ok = er_ < p.E;
-        const size_t row = size_t(row_ok ? er_ : p.E - 1) * A + hh;
+        const float4 b3 = *reinterpret_cast<const float4*>(s_small + mine_c * bsx_actor::SMALL + 6 * bsx_actor::H + bsx_actor::H * bsx_actor::NA);
+        const int64_t er_ = int64_t(blockIdx.x) * 32 + c;
+        const bool row_ok = has_row && er_ < p.E;
+        const size_t row = size_t(er_ < p.E ? er_ : p.E - 1) * A + mine_c;
         const uint64_t aseq = p.aseq + (p.aseq_base ? *p.aseq_base : 0ull) + uint64_t(tk);
-        const bool game_over = __shfl(er.done, 2 * c) != 0;
-        if (p.scripted_team == hh) {                     // instinct/team.py:13-15 for this team's rows, as one-hot score rows
+        bool game_over;
+        if (WAVES > 1) game_over = s_gdone_all[c] != 0;
+        else game_over = __shfl(er.done, 2 * c) != 0;
+        if (p.scripted_team == (mine_c >= N ? 1 : 0)) {  // instinct/team.py:13-15 for this team's rows, as one-hot score rows
             double td_, ta_;
-            r4 = one_hot_scores(instinct_choose([&](int k) { return s_obs[(2 * c + hh) * D + k]; }, N, td_, ta_));
+            r4 = one_hot_scores(instinct_choose([&](int k) { return s_obs_all[(c * G_ + mine_c) * D + k]; }, N, td_, ta_));
         } else {
             r4 = bsx_actor::finish_row(r4, b3, p.nz, p.aseed, aseq, row, game_over, row_ok);
         }
@@ -479,7 +506,13 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
 #pragma unroll
         for (int i = 1; i < 4; ++i)
             if (!(v[am] != v[am]) && (v[i] > v[am] || v[i] != v[i])) am = i;
-        act = __shfl(am, ((lane & 1) << 5) | (lane >> 1));          // plane (game L>>1, agent L&1) <- lane 32*(L&1) + (L>>1)
+        if (WAVES > 1) {                                 // plane (game, id) sits in lane game*G + id of the workgroup
+            if (has_row) s_act_all[c * G_ + mine] = am;
+            __syncthreads();
+            act = s_act_all[wave * SPB + tid];
+        } else {
+            act = __shfl(am, ((lane & 1) << 5) | (lane >> 1));      // plane (game L>>1, agent L&1) <- lane 32*(L&1) + (L>>1)
+        }
     }
 
     // ================= T1: the one dependent round trip: per-update steps of my LIVE bullets ========================
@@ -798,7 +831,7 @@ __global__ __launch_bounds__(SPB) void bsx_step_kernel(const StepArgs p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (G == A && (reinterpret_cast<uintptr_t>(obs_t) & 15u) == 0) {
             // rows of this wave: global floats [base, base + rows*D); the wave's offset SPB*D*4 bytes is a multiple of 16
-            const int64_t e_first = int64_t(blockIdx.x) * EPB;
+            const int64_t e_first = wblk * EPB;
             const int64_t rows = min(int64_t(SPB), (p.E - e_first) * A);
             const int64_t nfl = rows * D;                                   // floats to write
             float* gbase = obs_t + size_t(e_first) * A * D;
@@ -1135,7 +1168,7 @@ int bsx_rollout_discrete(void* state, int64_t E, int n, int T, const float* weig
                          uint8_t* done, uint8_t* env_done, uint8_t* winner, const BsxRewards* cfg, uint32_t flags,
                          const BsxActorNoise* noise, uint64_t actor_seed, uint64_t seq, const uint64_t* seq_base, uint64_t seed,
                          int64_t env_offset, void* stream) {
-    if (!state || E <= 0 || E > BSX_MAX_E || n != 1 || T < 1 || T > BSX_MAX_T || !weights || !obs || !scores || !rew || !done || !cfg)
+    if (!state || E <= 0 || E > BSX_MAX_E || n < 1 || n > 4 || T < 1 || T > BSX_MAX_T || !weights || !obs || !scores || !rew || !done || !cfg)
         return BSX_E_ARG;
     if ((flags & BSX_F_EMPTY_CALL) || (precision != BSX_ACTOR_F32 && precision != BSX_ACTOR_BF16X3) || scripted_team < -1 || scripted_team > 1) return BSX_E_ARG;
     if (!aligned(state, 256) || !aligned(weights, 16) || !aligned(scores, 16) || !aligned(obs, 4) || !aligned(rew, 4)) return BSX_E_ALIGN;
@@ -1151,8 +1184,14 @@ int bsx_rollout_discrete(void* state, int64_t E, int n, int T, const float* weig
     a.T = T; a.act_tb = 0; a.u_ts = 0; a.obs_ts = EA * D; a.rew_ts = EA; a.done_ts = EA;
     a.aw = weights; a.aprec = precision; a.scripted_team = scripted_team; a.obs0 = obs; a.scores = scores; a.scores_ts = EA * 4; a.nz = nz; a.aseed = actor_seed; a.aseq = seq;
     a.aseq_base = seq_base;
-    hipLaunchKernelGGL((bsx_step_kernel<1, false, true, true>), dim3(grid_for(E, n, SPB)), dim3(SPB), 0,
-                       static_cast<hipStream_t>(stream), a);
+    const dim3 grid(unsigned((E + 31) / 32));            // a workgroup = 32 games = G/2 waves
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (n) {
+        case 1: hipLaunchKernelGGL((bsx_step_kernel<1, false, true, true>), grid, dim3(SPB * 1), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((bsx_step_kernel<2, false, true, true>), grid, dim3(SPB * 2), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((bsx_step_kernel<3, false, true, true>), grid, dim3(SPB * 4), 0, s, a); break;
+        default: hipLaunchKernelGGL((bsx_step_kernel<4, false, true, true>), grid, dim3(SPB * 4), 0, s, a); break;
+    }
     return int(hipGetLastError());
 }
 

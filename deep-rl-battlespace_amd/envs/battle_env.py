@@ -404,8 +404,8 @@ class parallel_env:
     def _launch_rollout(self, T, weights_ptr, precision, scripted_team, obs_ptr, scores_ptr, rew_ptr, done_ptr, noise, actor_seed, seq,
                         seq_base_ptr):
         """Enqueue bsx_rollout_discrete: T ticks of (actor -> step) in one launch (used by rollout.PolicyRollout)."""
-        if self.continuous_actions or self.n_agents != 1:
-            raise ValueError("the one-launch rollout is built for discrete 1v1")
+        if self.continuous_actions or self.n_agents > 4:
+            raise ValueError("the one-launch rollout is built for discrete 1v1 ... 4v4")
         flags = _lib.F_AUTO_RESET if self.auto_reset else 0
         with self._guard():
             _lib.check(self._lib.bsx_rollout_discrete(

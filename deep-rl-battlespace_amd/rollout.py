@@ -222,11 +222,11 @@ class PolicyRollout:
             self.ou = dict(scale=float(ou_scale), env_done=env._env_done,
                            state=torch.zeros((env.n_envs, env._A, 4), dtype=torch.float32, device=env.device))
         # one_launch: all T ticks (actor -> step) in ONE kernel (bsx_rollout_discrete) instead of 2T launches in a graph:
-        # observation rows stay in LDS between the step and the actor, game state in registers / L2.  Discrete 1v1; a scripted
+        # observation rows stay in LDS between the step and the actor, game state in registers / L2.  Discrete, up to 4v4; a scripted
         # opponent (instinct.Team of one side) is played in-kernel and its actor is skipped; same transitions, bit for bit.
         self.one_launch = bool(one_launch)
-        if self.one_launch and (not fused or env.n_agents != 1 or env.continuous_actions):
-            raise ValueError("one_launch needs the fused actor and a discrete 1v1 env")
+        if self.one_launch and (not fused or env.n_agents > 4 or env.continuous_actions):
+            raise ValueError("one_launch needs the fused actor and a discrete env of 1v1 ... 4v4")
         if self.one_launch and opponent is not None and getattr(opponent, "team", None) not in (0, 1):
             raise ValueError("one_launch plays a scripted opponent in-kernel: it must be an instinct.Team of one side")
         self._seq_base = torch.zeros(1, dtype=torch.int64, device=env.device)

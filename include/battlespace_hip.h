@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define BSX_ABI_VERSION 7
+#define BSX_ABI_VERSION 8
 #define BSX_BULLET_SLOTS 12 /* a bullet is removed at the latest on its 12th update (sprites.py:334-337: 12*45 >= 500) */
 #define BSX_MAX_N 16
 #define BSX_MAX_E (INT64_C(1) << 30)   /* games per call: keeps every grid below 2^31 workgroups; 2^30 games of 1v1 is ~0.8 TB of state */
@@ -176,8 +176,9 @@ int bsx_actor_forward(const float* weights, const float* obs, float* scores, int
  *            is not evaluated, their score rows are the one-hot rows bsx_instinct_discrete writes, no noise
  *   weights, precision, noise, actor_seed, seq, seq_base: as bsx_actor_forward; tick t uses sequence number seq + *seq_base + t
  *   cfg, flags, seed, env_offset: as bsx_step_discrete (BSX_F_EMPTY_CALL is refused)
- * This version: n == 1 (1v1: a wavefront's rows are exactly two 32-row MFMA tiles, one per actor); other team sizes
- * return BSX_E_ARG -- use the two-kernel form. */
+ * n = 1 .. 4.  An MFMA tile is 32 rows of one actor, so a workgroup is 32 games = G/2 wavefronts (1v1: one wave whose rows are
+ * exactly two tiles; 2v2: two waves; 3v3 / 4v4: four) that exchange observation rows and arg-maxes through LDS.  Larger teams
+ * return BSX_E_ARG -- use the per-tick form. */
 int bsx_rollout_discrete(void* state, int64_t E, int n, int T, const float* weights, int precision, int scripted_team, float* obs, float* scores, float* rew,
                          uint8_t* done, uint8_t* env_done, uint8_t* winner, const BsxRewards* cfg, uint32_t flags,
                          const BsxActorNoise* noise, uint64_t actor_seed, uint64_t seq, const uint64_t* seq_base,

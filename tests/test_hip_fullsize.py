@@ -425,16 +425,17 @@ def test_rollout_with_ou_noise_restarts_per_game():
     assert int(env.counters()[:, 0].sum()) > 0                    # games did finish (and restart) along the way
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 4])
 @pytest.mark.parametrize("noise", ["none", "gaussian", "ou", "gaussian-bf16x3"])
-def test_one_launch_rollout_equals_two_kernel_rollout(noise):
+def test_one_launch_rollout_equals_two_kernel_rollout(noise, n):
     """bsx_rollout_discrete (T ticks of actor -> step in ONE launch, observation rows handed over in LDS) against the
     two-kernel form (bsx_actor_forward + bsx_step_discrete per tick): the same transitions bit for bit -- observations,
     the actors' score vectors (incl. exploration noise and OU state), rewards, dones, final game state -- over several
     runs, across auto-resets, with a ragged last wavefront."""
     from deep_rl_battlespace_amd.rollout import PolicyRollout, StackedActor
-    E, n, T = 4100, 1, 50
+    E, T = (4100 if n == 1 else 1030), 50
     torch.manual_seed(3)
-    actor = StackedActor(2, 5, 4, device="cuda")
+    actor = StackedActor(2 * n, 3 * n + 2, 4, device="cuda")
     with torch.no_grad():
         actor.w3.mul_(60.0); actor.g1.uniform_(0.5, 1.5); actor.h1.uniform_(-0.3, 0.3)
     kw = dict(noise_std=0.3) if noise.startswith("gaussian") else (dict(ou_scale=0.4) if noise == "ou" else {})
@@ -460,7 +461,7 @@ def test_one_launch_rollout_equals_two_kernel_rollout(noise):
     for k in ("px", "py", "pdir", "php", "bhp", "tick", "env_done", "winner", "bl_live", "counters"):
         assert torch.equal(sa[k], sb[k]), k
     assert torch.equal(a.env.env_done, b.env.env_done)
-    assert int(a.env.counters()[:, 0].sum()) > E                 # the runs crossed game ends
+    assert int(a.env.counters()[:, 0].sum()) >= E                # the runs crossed game ends
     assert len(torch.unique(a.scores.argmax(-1))) >= 3
 
 

@@ -130,16 +130,17 @@ def test_rollout_with_learned_red_and_scripted_blue():
     assert c[3] > c[2] and c[0] > 0                               # the scripted team beats a random-weight actor
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 4])
 @pytest.mark.parametrize("scripted", ["blue", "red"])
-def test_one_launch_rollout_plays_the_scripted_opponent_in_kernel(scripted):
+def test_one_launch_rollout_plays_the_scripted_opponent_in_kernel(scripted, n):
     """bsx_rollout_discrete with scripted_team: the reference's training setup (main.py:119-122: learned team vs
     instinct.Team) as ONE launch -- the scripted side's rows are decided in-kernel from the observation rows in LDS and
     its actor is skipped.  Same transitions, bit for bit, as the two-kernel rollout with `opponent.write_actions`."""
     from deep_rl_battlespace_amd import instinct
     from deep_rl_battlespace_amd.rollout import PolicyRollout, StackedActor
-    E, n, T = 4100, 1, 40
+    E, T = (4100 if n == 1 else 1030), 40
     torch.manual_seed(1)
-    actor = StackedActor(2, 5, 4, device="cuda")
+    actor = StackedActor(2 * n, 3 * n + 2, 4, device="cuda")
     with torch.no_grad():
         actor.w3.mul_(60.0)
     ros = []
@@ -155,8 +156,8 @@ def test_one_launch_rollout_plays_the_scripted_opponent_in_kernel(scripted):
         torch.cuda.synchronize()
         assert torch.equal(a.obs, b.obs) and torch.equal(a.scores, b.scores), rep
         assert torch.equal(a.rew, b.rew) and torch.equal(a.done, b.done), rep
-    col = 1 if scripted == "blue" else 0
-    assert bool(((b.scores[:, :, col] == 1).sum(-1) == 1).all()) and bool(((b.scores[:, :, col].abs() == 1).all()))
+    cols = slice(n, 2 * n) if scripted == "blue" else slice(0, n)
+    assert bool(((b.scores[:, :, cols] == 1).sum(-1) == 1).all()) and bool(((b.scores[:, :, cols].abs() == 1).all()))
     sa, sb = a.env.export_state(), b.env.export_state()
     for k in ("px", "py", "pdir", "php", "bhp", "tick", "env_done", "winner", "bl_live", "counters"):
         assert torch.equal(sa[k], sb[k]), k

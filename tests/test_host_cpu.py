@@ -53,7 +53,7 @@ def test_bad_arguments_are_rejected_before_any_launch():
     assert lib.bsx_step_many_discrete(ok, 4, 1, 0, ok, 0, None, ok, ok, ok, None, None, ctypes.byref(cfg), 0, 1, 0, 0, None) == -1
     assert lib.bsx_step_many_discrete(ok, 4, 1, 70000, ok, 0, None, ok, ok, ok, None, None, ctypes.byref(cfg), 0, 1, 0, 0, None) == -1
     assert lib.bsx_step_many_continuous(ok, 4, 1, 5, None, 0, None, ok, ok, ok, None, None, ctypes.byref(cfg), 0, 1, 0, 0, None) == -1
-    assert lib.bsx_rollout_discrete(ok, 4, 2, 8, ok, 0, -1, ok, ok, ok, ok, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1
+    assert lib.bsx_rollout_discrete(ok, 4, 5, 8, ok, 0, -1, ok, ok, ok, ok, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1
     assert lib.bsx_rollout_discrete(ok, 4, 1, 8, ok, 7, -1, ok, ok, ok, ok, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1
     assert lib.bsx_rollout_discrete(ok, 4, 1, 8, ok, 0, 2, ok, ok, ok, ok, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1
     assert lib.bsx_actor_forward(ok, ok, ok, 4, 1, 7, None, 0, 0, None, None) == -1
