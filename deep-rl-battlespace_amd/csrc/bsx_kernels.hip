@@ -171,6 +171,20 @@ __device__ inline double rel_angle(int x0, int y0, double a0, int x1, int y1) {
     if (r > 180.0) r -= 360.0;
     return r;
 }
+// rel_angle's second half: from rads (already reduced to [0, 2 pi)) to the wrapped difference with the observer's heading
+__device__ inline double rel_from_rads(double rads, double a0) {
+    const double degs = rads * RAD2DEG;
+    double r = (180.0 + a0) - (360.0 - degs);
+    if (r < -180.0) r += 360.0;
+    if (r > 180.0) r -= 360.0;
+    return r;
+}
+__device__ inline double pair_rads(int x0, int y0, int x1, int y1) {   // rel_angle's first half: atan2 % 2 pi, observer p0
+    double rads = atan2(double(y0 - y1), double(x0 - x1));
+    if (rads < 0.0) rads += TWO_PI;
+    else if (rads == 0.0) rads = 0.0;
+    return rads;
+}
 // The two divisions by constants (battle_env.py:230-231) are multiplications by the float64 reciprocal here: the
 // float64 result can differ in its last bit, which survives the single rounding to float32 with probability ~2^-29.
 __device__ inline float obs_dist(int x0, int y0, int x1, int y1) {
@@ -359,6 +373,11 @@ void bsx_step_kernel(const StepArgs p) {
     __shared__ __attribute__((aligned(16))) float s_small[ACTOR ? 2 * (N > 0 ? N : 1) * bsx_actor::SMALL : 4];   // per-neuron vectors + heads of the actors
     __shared__ int s_act_all[(ACTOR && WAVES > 1) ? WAVES * SPB : 1];                // arg-max per row, ACTOR with several waves
     __shared__ int s_gdone_all[(ACTOR && WAVES > 1) ? 32 : 1];                       // game-over flag per game of the workgroup
+    // n >= 2: every plane-to-plane pair is computed ONCE, by one of its two planes, and handed to the other through these
+    __shared__ float s_pd_all[(N >= 2) ? WAVES * SPB * N : 1];      // range (symmetric)
+    __shared__ double s_pr_all[(N >= 2) ? WAVES * SPB * N : 1];     // the owner's bearing in radians, [0, 2 pi)
+    float* const s_pd = s_pd_all + ((N >= 2) ? wave * SPB * N : 0);
+    double* const s_pr = s_pr_all + ((N >= 2) ? wave * SPB * N : 0);
     volatile int* const s_x = s_x_all + wave * SPB;
     volatile int* const s_y = s_y_all + wave * SPB;
     volatile int* const s_hp = s_hp_all + wave * SPB;
@@ -634,12 +653,46 @@ void bsx_step_kernel(const StepArgs p) {
     float oe_d[NE], oe_a[NE];
     int ex[NE], ey[NE];
     if (!(DIAG & 1u)) obs_pair(x, y, dir, obx, oby, ob_d, ob_a);
-    if (N > 0) {
+    if constexpr (N == 1) {
+        ex[0] = s_x[eb]; ey[0] = s_y[eb];
+        oe_d[0] = -1.0f; oe_a[0] = -1.0f;
+        if (!(DIAG & 1u)) obs_pair(x, y, dir, ex[0], ey[0], oe_d[0], oe_a[0]);
+    } else if constexpr (N >= 2) {
+        // The range of a pair is symmetric and its bearing differs by pi between the two ends, so each red-blue pair is
+        // worked out once -- by red plane i for blue j when i + j is even, by blue j otherwise -- in (N + 1) / 2 rounds of
+        // one sqrt + atan2 per lane instead of N, and the other end derives its bearing: rads +- pi (coincident planes: 0,
+        // as atan2(+0, +0) gives both ends).  The derived value can differ from a direct atan2 in its last bits (<= ~4 ulp
+        // of float64), which survives the single rounding to float32 with probability ~1e-8, like the libm difference.
+        constexpr double PI_D = 3.14159265358979323846;
+        const int mi = min(team == 0 ? a : a - N, N - 1);            // my index inside my team (lanes beyond A: clamped, never write)
 #pragma unroll
-        for (int j = 0; j < NE; ++j) {
-            ex[j] = s_x[eb + j]; ey[j] = s_y[eb + j];
-            oe_d[j] = -1.0f; oe_a[j] = -1.0f;
-            if (!(DIAG & 1u)) obs_pair(x, y, dir, ex[j], ey[j], oe_d[j], oe_a[j]);
+        for (int j = 0; j < NE; ++j) { ex[j] = s_x[eb + j]; ey[j] = s_y[eb + j]; oe_d[j] = -1.0f; oe_a[j] = -1.0f; }
+        if (!(DIAG & 1u)) {
+#pragma unroll
+            for (int r = 0; r < (N + 1) / 2; ++r) {
+                const int oj = (team == 0 ? (mi & 1) : ((mi + 1) & 1)) + 2 * r;   // the enemy I own in this round
+                const bool own = oj < N && a < A;
+                const int ojc = min(oj, N - 1);
+                const int tx = s_x[eb + ojc], ty = s_y[eb + ojc];
+                const float d = obs_dist(x, y, tx, ty);
+                const double rads = pair_rads(x, y, tx, ty);
+                const int slot = (gl + (team == 0 ? mi : ojc)) * N + (team == 0 ? ojc : mi);   // [red plane of my game][blue index]
+                if (own) { s_pd[slot] = d; s_pr[slot] = rads; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                const int ri = team == 0 ? mi : j, bi = team == 0 ? j : mi;
+                const int slot = (gl + ri) * N + bi;
+                const bool mine = (team == 0) == (((ri + bi) & 1) == 0);
+                const double r0 = s_pr[slot];
+                const bool same = ex[j] == x && ey[j] == y;
+                const double rads = mine ? r0 : (same ? 0.0 : (r0 < PI_D ? r0 + PI_D : r0 - PI_D));
+                oe_d[j] = s_pd[slot];
+                oe_a[j] = float(rel_from_rads(rads, dir) * (1.0 / 360.0));
+            }
         }
     }
 
