@@ -378,10 +378,12 @@ void bsx_step_kernel(const StepArgs p) {
     __shared__ double s_pr_all[(N >= 2) ? WAVES * SPB * N : 1];     // the owner's bearing in radians, [0, 2 pi)
     float* const s_pd = s_pd_all + ((N >= 2) ? wave * SPB * N : 0);
     double* const s_pr = s_pr_all + ((N >= 2) ? wave * SPB * N : 0);
-    volatile int* const s_x = s_x_all + wave * SPB;
-    volatile int* const s_y = s_y_all + wave * SPB;
-    volatile int* const s_hp = s_hp_all + wave * SPB;
-    volatile int* const s_bhit = s_bhit_all + wave * SPB;
+    // (explicit LDS address space: a volatile access through a generic pointer compiles to flat_load / flat_store)
+    typedef __attribute__((address_space(3))) volatile int lds_vint;
+    lds_vint* const s_x = (lds_vint*)(uintptr_t)(s_x_all) + wave * SPB;
+    lds_vint* const s_y = (lds_vint*)(uintptr_t)(s_y_all) + wave * SPB;
+    lds_vint* const s_hp = (lds_vint*)(uintptr_t)(s_hp_all) + wave * SPB;
+    lds_vint* const s_bhit = (lds_vint*)(uintptr_t)(s_bhit_all) + wave * SPB;
     float* const s_obs = s_obs_all + wave * SPB * DROW;
 
     // Raw inputs of one call (decoded at the top of the tick that uses them).
@@ -781,7 +783,7 @@ void bsx_step_kernel(const StepArgs p) {
         }
         // this call's shot is the newest bullet: appended last
         update_item(-1, x0, y0, 0, nd, (spawn ? -1 : 0) & physm);
-        if (nbase) atomicAdd(const_cast<int*>(&s_bhit[gl + team]), nbase);
+        if (nbase) __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)(&s_bhit[gl + team]), nbase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (phys) live = uint32_t(pos);
     }
     STAMP(5);
