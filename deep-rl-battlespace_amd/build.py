@@ -21,8 +21,10 @@ COMMON = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-
 # -disable-machine-licm: in the multi-tick kernels (a tick loop around the whole step body) machine LICM would hoist every
 # fp64 literal of sincos / atan2 out of the loop into ~110 VGPRs held for the whole tick (256 VGPRs, 1-2 waves per SIMD);
 # the one-call kernels compile to the same code either way.
-SOURCES = [(os.path.join(CSRC, "bsx_kernels.hip"), ["-ffp-contract=off", "-mllvm", "-disable-machine-licm"]),
-           (os.path.join(CSRC, "bsx_actor.hip"), ["-ffp-contract=off"])]
+# -amdgpu-mfma-vgpr-form: MFMA accumulators in ordinary VGPRs (every kernel here fits 256 of them at two waves per SIMD);
+# the default puts them in AGPRs and pays a v_accvgpr_read per value the LayerNorm / head then touches (11 % of the actor).
+SOURCES = [(os.path.join(CSRC, "bsx_kernels.hip"), ["-ffp-contract=off", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-mfma-vgpr-form"]),
+           (os.path.join(CSRC, "bsx_actor.hip"), ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form"])]
 
 
 def _stale():
