@@ -391,11 +391,16 @@ void bsx_step_kernel(const StepArgs p) {
     auto load_inputs = [&](int t, RawIn& r) {
         const void* const at = MULTI ? static_cast<const void*>(static_cast<const char*>(p.actions) + int64_t(t) * p.act_tb) : p.actions;
         const double* const ut = (MULTI && p.u) ? p.u + int64_t(t) * p.u_ts : p.u;
-        if (at) {                                        // uniform branch
-            if (!CONT) {
-                if (p.action_kind == BSX_ACT_I32) r.ai = static_cast<const int32_t*>(at)[g];
-                else r.lg = static_cast<const float4*>(at)[g];
-            } else if (p.action_kind == BSX_ACT_F32) {
+        if (!CONT) {
+            // Both encodings are read by unconditional loads -- the one not in use from the heading table's first line (L1-hot) --
+            // because a load under a branch makes the compiler's wait-count pass drain EVERYTHING in flight before the other
+            // branch's load (it merges the register state of both paths): the action then cost a second full round trip.
+            const bool is_i32 = at && p.action_kind == BSX_ACT_I32, is_lg = at && p.action_kind != BSX_ACT_I32;
+            const char* const dummy = reinterpret_cast<const char*>(p.st.lut);
+            r.ai = *reinterpret_cast<const int32_t*>(is_i32 ? static_cast<const char*>(at) + g * 4 : dummy);
+            r.lg = *reinterpret_cast<const float4*>(is_lg ? static_cast<const char*>(at) + g * 16 : dummy);
+        } else if (at) {                                 // uniform branch
+            if (p.action_kind == BSX_ACT_F32) {
                 const float* ap = static_cast<const float*>(at) + 3 * g;
                 r.f0 = ap[0]; r.f1 = ap[1]; r.f2 = ap[2];
             } else if (p.action_kind == BSX_ACT_F32X4) {
