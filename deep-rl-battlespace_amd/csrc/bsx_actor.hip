@@ -71,16 +71,6 @@ __global__ __launch_bounds__(TPB) void bsx_actor_kernel(const ActorArgs p) {
             if (nt == 0) o[0] = t; else o[1] = t;
         }
     } else {
-        // the 64 x 64 layer's A operands: 64 VGPRs, coalesced 16-byte loads, in flight while layer 1 runs
-        float4 w2[2][2][4];
-    #pragma unroll
-        for (int mo = 0; mo < 2; ++mo)
-    #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-    #pragma unroll
-                for (int vq = 0; vq < 4; ++vq)
-                    w2[mo][mt][vq] = reinterpret_cast<const float4*>(W + off_w2(D))[((mo * 2 + mt) * 4 + vq) * 64 + lane];
-
         __syncthreads();
         const float* sm = s_small + hh * 32;      // this lane half's [mo][v] slice of each 64-float vector ([hh][mo][v])
 
@@ -105,6 +95,16 @@ __global__ __launch_bounds__(TPB) void bsx_actor_kernel(const ActorArgs p) {
             acc1[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc1[1][0], 0, 0, 0);
             acc1[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc1[1][1], 0, 0, 0);
         }
+        // the 64 x 64 layer's A operands: 64 VGPRs, coalesced 16-byte loads, issued behind layer 1's own loads (vmcnt is in-order), in flight under the LayerNorm
+        float4 w2[2][2][4];
+    #pragma unroll
+        for (int mo = 0; mo < 2; ++mo)
+    #pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+    #pragma unroll
+                for (int vq = 0; vq < 4; ++vq)
+                    w2[mo][mt][vq] = reinterpret_cast<const float4*>(W + off_w2(D))[((mo * 2 + mt) * 4 + vq) * 64 + lane];
+
         ln_relu_tile(acc1[0][0], acc1[1][0], sm + 1 * H, sm + 2 * H);
         ln_relu_tile(acc1[0][1], acc1[1][1], sm + 1 * H, sm + 2 * H);
 

@@ -144,14 +144,6 @@ __device__ inline float4 tile_forward(const float* __restrict__ W, const float* 
 #pragma clang fp contract(fast)
     const int Dp = dpad(D), hh = lane >> 5;
     const float* sm = sm_agent + hh * 32;      // this lane half's [mo][v] slice of each 64-float vector ([hh][mo][v])
-    float4 w2[2][2][4];                        // f32: [mo][mt][vq] x 4 k-steps;  bf16x3: the same 64 registers hold [mo][s][term] x 8 bf16
-#pragma unroll
-    for (int mo = 0; mo < 2; ++mo)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int vq = 0; vq < 4; ++vq)
-                w2[mo][mt][vq] = reinterpret_cast<const float4*>(W + (BF16X3 ? off_w2b(D) : off_w2(D)))[((mo * 2 + mt) * 4 + vq) * 64 + lane];
     f32x16 acc1[2];
 #pragma unroll
     for (int mo = 0; mo < 2; ++mo)
@@ -164,6 +156,16 @@ __device__ inline float4 tile_forward(const float* __restrict__ W, const float* 
         acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc1[0], 0, 0, 0);
         acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1[1], 0, 0, 0);
     }
+    // The 64 x 64 layer's operands are fetched HERE, behind layer 1's own loads: vmcnt counts in order, so any load issued
+    // after these would have to wait for all 16 KB of them; the LayerNorm below (~1 k cycles of VALU) covers their latency.
+    float4 w2[2][2][4];                        // f32: [mo][mt][vq] x 4 k-steps;  bf16x3: the same 64 registers hold [mo][s][term] x 8 bf16
+#pragma unroll
+    for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int vq = 0; vq < 4; ++vq)
+                w2[mo][mt][vq] = reinterpret_cast<const float4*>(W + (BF16X3 ? off_w2b(D) : off_w2(D)))[((mo * 2 + mt) * 4 + vq) * 64 + lane];
     ln_relu_tile(acc1[0], acc1[1], sm + 1 * H, sm + 2 * H);
     f32x16 acc2[2];
 #pragma unroll
