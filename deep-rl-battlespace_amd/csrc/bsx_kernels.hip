@@ -765,6 +765,10 @@ void bsx_step_kernel(const StepArgs p) {
     };
     {
         const int physm = phys ? -1 : 0;
+        // All item loads have long arrived (the observation geometry ran in between); say so once.  Loads and stores share
+        // the in-order vmcnt on gfx9: without this the per-item waits the compiler derives (vmcnt(5), (4), ... (0)) end up
+        // waiting for the survivor STORES of earlier items to be acknowledged before a later item may start.
+        __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0); expcnt / lgkmcnt untouched
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int age0 = bullet_age(iw[j]);                                     // a tombstone (plane hit last call) is dropped
