@@ -328,9 +328,9 @@ __device__ inline void obs_pair(int x, int y, double dir, int tx, int ty, float&
 }
 
 // MULTI: the wave walks its games through p.T consecutive calls in one launch.  Games never leave their wave, so the
-// only ordering needed between ticks is this wave's own stores before its own loads (a workgroup-scope fence = a wait,
-// no cache maintenance: same CU, same L1); the state stays in the L2 instead of crossing a kernel boundary (write-back +
-// invalidate + a cold first round trip) every tick.
+// only ordering needed between ticks is a lane's own stores before its own loads (program order through one L1: a
+// wavefront-scope fence, no wait, no cache maintenance); the state stays in the L2 instead of crossing a kernel boundary
+// (write-back + invalidate + a cold first round trip) every tick.
 // ACTOR (discrete, MULTI, n <= 4): the caller's whole rollout loop `for t: actions = actor(obs); obs, rew, done = step(actions)`
 // (main.py:177-181) in one launch.  The observation rows never leave the CU: the step leaves them in LDS, the actor
 // (bsx_actor_core.h, MFMA) reads them there as its B operands.  An MFMA tile is 32 rows of ONE actor, so a workgroup is
@@ -926,11 +926,15 @@ void bsx_step_kernel(const StepArgs p) {
         }
     }
     STAMP(7);
-    if (MULTI) {   // my stores of this tick before my loads of the next one (bullet rows, LDS rows)
+    if (MULTI) {
         games += cnt_delta.x;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // The only memory one tick hands to the next is what a LANE stored itself and reloads itself (its bullet rows; the
+        // game counters' read-modify-write) plus this wave's LDS rows.  A wavefront's vector memory operations are performed
+        // in order through the one L1 of its CU, so wavefront scope is enough: a compiler ordering point, no s_waitcnt -- this
+        // tick's stores (observation rows included) drain while the next tick computes.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         STAMP(9);
     }
     }   // tick loop
