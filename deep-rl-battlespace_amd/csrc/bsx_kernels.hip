@@ -340,7 +340,11 @@ __device__ inline void obs_pair(int x, int y, double dir, int tx, int ty, float&
 // Everything else stays private to a wave exactly as in the other variants: a wave still only touches its own games.
 template <int N, bool CONT, bool MULTI, bool ACTOR = false>
 __global__ __launch_bounds__(SPB * (ACTOR ? group_width(N > 0 ? N : 1) / 2 : 1)) __attribute__((amdgpu_waves_per_eu((ACTOR && N > 1) ? 2 : 1)))
-void bsx_step_kernel(const StepArgs p) {
+void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* const cnt_, const PlaneRec* const plane_, const void* const act_,
+                     const int kind_, const StepArgs p) {
+    // The six leading arguments repeat p.E, p.st.env, p.st.cnt, p.st.plane, p.actions, p.action_kind: eleven dwords that the
+    // dispatcher preloads into SGPRs (-amdgpu-kernarg-preload-count), so that a wave's first loads need nothing from the
+    // kernarg segment and do not queue behind its cold scalar-cache fetch.
     STAMP(8);                                            // diagnostic builds: kernel entry, before any kernarg load
     constexpr int WAVES = ACTOR ? group_width(N > 0 ? N : 1) / 2 : 1;
     const int n = (N > 0) ? N : p.n;
@@ -353,11 +357,11 @@ void bsx_step_kernel(const StepArgs p) {
     const int a = tid & (G - 1);
     const int gl = tid & ~(G - 1);                       // first thread of my env's group
     const int64_t e = wblk * EPB + (tid / G);
-    const bool env_ok = e < p.E;
+    const bool env_ok = e < E_;
     const bool valid = env_ok && a < A;
-    const size_t EA = size_t(p.E) * size_t(A);
+    const size_t EA = size_t(E_) * size_t(A);
     // out-of-range lanes read a valid row (the last one) and never store: loads stay unconditional
-    const int64_t ec = env_ok ? e : p.E - 1;
+    const int64_t ec = env_ok ? e : E_ - 1;
     const size_t g = size_t(ec) * A + (a < A ? a : A - 1);
     const int lane = tid;
     const int team = (a < n) ? 0 : 1;                    // 0 red, 1 blue
@@ -389,21 +393,21 @@ void bsx_step_kernel(const StepArgs p) {
     // Raw inputs of one call (decoded at the top of the tick that uses them).
     struct RawIn { int ai; float4 lg; float f0, f1, f2; double c0, c1, c2, uu; };
     auto load_inputs = [&](int t, RawIn& r) {
-        const void* const at = MULTI ? static_cast<const void*>(static_cast<const char*>(p.actions) + int64_t(t) * p.act_tb) : p.actions;
+        const void* const at = MULTI ? static_cast<const void*>(static_cast<const char*>(act_) + int64_t(t) * p.act_tb) : act_;
         const double* const ut = (MULTI && p.u) ? p.u + int64_t(t) * p.u_ts : p.u;
         if (!CONT) {
             // Both encodings are read by unconditional loads -- the one not in use from the heading table's first line (L1-hot) --
             // because a load under a branch makes the compiler's wait-count pass drain EVERYTHING in flight before the other
             // branch's load (it merges the register state of both paths): the action then cost a second full round trip.
-            const bool is_i32 = at && p.action_kind == BSX_ACT_I32, is_lg = at && p.action_kind != BSX_ACT_I32;
-            const char* const dummy = reinterpret_cast<const char*>(p.st.lut);
+            const bool is_i32 = at && kind_ == BSX_ACT_I32, is_lg = at && kind_ != BSX_ACT_I32;
+            const char* const dummy = reinterpret_cast<const char*>(env_);      // any mapped line will do: the first game record
             r.ai = *reinterpret_cast<const int32_t*>(is_i32 ? static_cast<const char*>(at) + g * 4 : dummy);
             r.lg = *reinterpret_cast<const float4*>(is_lg ? static_cast<const char*>(at) + g * 16 : dummy);
         } else if (at) {                                 // uniform branch
-            if (p.action_kind == BSX_ACT_F32) {
+            if (kind_ == BSX_ACT_F32) {
                 const float* ap = static_cast<const float*>(at) + 3 * g;
                 r.f0 = ap[0]; r.f1 = ap[1]; r.f2 = ap[2];
-            } else if (p.action_kind == BSX_ACT_F32X4) {
+            } else if (kind_ == BSX_ACT_F32X4) {
                 const float4 v = static_cast<const float4*>(at)[g];
                 r.f0 = v.x; r.f1 = v.y; r.f2 = v.z;
             } else {
@@ -432,7 +436,7 @@ void bsx_step_kernel(const StepArgs p) {
         }
         // the observations the rollout starts from (obs[0]): this wave's rows are one contiguous block
         const int64_t e_first = wblk * EPB;
-        const int64_t nfl = min(int64_t(SPB), (p.E - e_first) * A) * D;
+        const int64_t nfl = min(int64_t(SPB), (E_ - e_first) * A) * D;
         if (G == A) {
             for (int i = tid; i < SPB * D; i += SPB) s_obs[i] = i < nfl ? p.obs0[size_t(e_first) * A * D + i] : -1.0f;
         } else {                                         // 3v3: lanes 6, 7 of a group own no row
@@ -462,9 +466,9 @@ void bsx_step_kernel(const StepArgs p) {
     // ================= T0: every load that depends on no other load, issued back to back, raw 16-byte words ========
     // (the kernel is latency-bound at 65 536 games -- 2 waves per SIMD -- so memory-level parallelism is what pays)
     if (!MULTI || tk == 0) {
-        const uint4 erw = reinterpret_cast<const uint4*>(p.st.env)[ec];
-        games = reinterpret_cast<const int*>(p.st.cnt)[4 * ec];   // games finished so far = episode id of the RNG streams
-        const uint4 prw = reinterpret_cast<const uint4*>(p.st.plane)[gt];
+        const uint4 erw = reinterpret_cast<const uint4*>(env_)[ec];
+        games = reinterpret_cast<const int*>(cnt_)[4 * ec];   // games finished so far = episode id of the RNG streams
+        const uint4 prw = reinterpret_cast<const uint4*>(plane_)[gt];
         if (!MULTI) load_inputs(0, rin);
         unpack_plane(prw, x, y, live, hp, dir);
         er = unpack_env(erw);
@@ -472,9 +476,9 @@ void bsx_step_kernel(const StepArgs p) {
     if (MULTI) rin = rin_next;
     int act = -1;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, uu_in = 0.0;
-    if (p.actions) {                                     // uniform branch
+    if (act_) {                                          // uniform branch
         if (!CONT) {
-            if (p.action_kind == BSX_ACT_I32) act = rin.ai;
+            if (kind_ == BSX_ACT_I32) act = rin.ai;
             else {   // np.argmax: first maximum; a NaN compares as the maximum
                 const float v[4] = {rin.lg.x, rin.lg.y, rin.lg.z, rin.lg.w};
                 act = 0;
@@ -482,7 +486,7 @@ void bsx_step_kernel(const StepArgs p) {
                 for (int i = 1; i < 4; ++i)
                     if (!(v[act] != v[act]) && (v[i] > v[act] || v[i] != v[i])) act = i;
             }
-        } else if (p.action_kind == BSX_ACT_F32 || p.action_kind == BSX_ACT_F32X4) {
+        } else if (kind_ == BSX_ACT_F32 || kind_ == BSX_ACT_F32X4) {
             a0 = double(rin.f0); a1 = double(rin.f1); a2 = double(rin.f2);
         } else {
             a0 = rin.c0; a1 = rin.c1; a2 = rin.c2;
@@ -514,8 +518,8 @@ void bsx_step_kernel(const StepArgs p) {
         }
         const float4 b3 = *reinterpret_cast<const float4*>(s_small + mine_c * bsx_actor::SMALL + 6 * bsx_actor::H + bsx_actor::H * bsx_actor::NA);
         const int64_t er_ = int64_t(blockIdx.x) * 32 + c;
-        const bool row_ok = has_row && er_ < p.E;
-        const size_t row = size_t(er_ < p.E ? er_ : p.E - 1) * A + mine_c;
+        const bool row_ok = has_row && er_ < E_;
+        const size_t row = size_t(er_ < E_ ? er_ : E_ - 1) * A + mine_c;
         const uint64_t aseq = p.aseq + (p.aseq_base ? *p.aseq_base : 0ull) + uint64_t(tk);
         bool game_over;
         if (WAVES > 1) game_over = s_gdone_all[c] != 0;
@@ -896,7 +900,7 @@ void bsx_step_kernel(const StepArgs p) {
         if (G == A && (reinterpret_cast<uintptr_t>(obs_t) & 15u) == 0) {
             // rows of this wave: global floats [base, base + rows*D); the wave's offset SPB*D*4 bytes is a multiple of 16
             const int64_t e_first = wblk * EPB;
-            const int64_t rows = min(int64_t(SPB), (p.E - e_first) * A);
+            const int64_t rows = min(int64_t(SPB), (E_ - e_first) * A);
             const int64_t nfl = rows * D;                                   // floats to write
             float* gbase = obs_t + size_t(e_first) * A * D;
             for (int i = tid * 4; i < nfl; i += SPB * 4) {
@@ -1127,19 +1131,19 @@ int launch_step(void* state, int64_t E, int n, const void* actions, int action_k
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (T == 0) {
         switch (n) {
-            case 1: hipLaunchKernelGGL((bsx_step_kernel<1, CONT, false>), grid, block, 0, s, a); break;
-            case 2: hipLaunchKernelGGL((bsx_step_kernel<2, CONT, false>), grid, block, 0, s, a); break;
-            case 3: hipLaunchKernelGGL((bsx_step_kernel<3, CONT, false>), grid, block, 0, s, a); break;
-            case 4: hipLaunchKernelGGL((bsx_step_kernel<4, CONT, false>), grid, block, 0, s, a); break;
-            default: hipLaunchKernelGGL((bsx_step_kernel<0, CONT, false>), grid, block, 0, s, a); break;
+            case 1: hipLaunchKernelGGL((bsx_step_kernel<1, CONT, false>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+            case 2: hipLaunchKernelGGL((bsx_step_kernel<2, CONT, false>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+            case 3: hipLaunchKernelGGL((bsx_step_kernel<3, CONT, false>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+            case 4: hipLaunchKernelGGL((bsx_step_kernel<4, CONT, false>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+            default: hipLaunchKernelGGL((bsx_step_kernel<0, CONT, false>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
         }
     } else {
         switch (n) {
-            case 1: hipLaunchKernelGGL((bsx_step_kernel<1, CONT, true>), grid, block, 0, s, a); break;
-            case 2: hipLaunchKernelGGL((bsx_step_kernel<2, CONT, true>), grid, block, 0, s, a); break;
-            case 3: hipLaunchKernelGGL((bsx_step_kernel<3, CONT, true>), grid, block, 0, s, a); break;
-            case 4: hipLaunchKernelGGL((bsx_step_kernel<4, CONT, true>), grid, block, 0, s, a); break;
-            default: hipLaunchKernelGGL((bsx_step_kernel<0, CONT, true>), grid, block, 0, s, a); break;
+            case 1: hipLaunchKernelGGL((bsx_step_kernel<1, CONT, true>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+            case 2: hipLaunchKernelGGL((bsx_step_kernel<2, CONT, true>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+            case 3: hipLaunchKernelGGL((bsx_step_kernel<3, CONT, true>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+            case 4: hipLaunchKernelGGL((bsx_step_kernel<4, CONT, true>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+            default: hipLaunchKernelGGL((bsx_step_kernel<0, CONT, true>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
         }
     }
     return int(hipGetLastError());
@@ -1255,10 +1259,10 @@ int bsx_rollout_discrete(void* state, int64_t E, int n, int T, const float* weig
     const dim3 grid(unsigned((E + 31) / 32));            // a workgroup = 32 games = G/2 waves
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (n) {
-        case 1: hipLaunchKernelGGL((bsx_step_kernel<1, false, true, true>), grid, dim3(SPB * 1), 0, s, a); break;
-        case 2: hipLaunchKernelGGL((bsx_step_kernel<2, false, true, true>), grid, dim3(SPB * 2), 0, s, a); break;
-        case 3: hipLaunchKernelGGL((bsx_step_kernel<3, false, true, true>), grid, dim3(SPB * 4), 0, s, a); break;
-        default: hipLaunchKernelGGL((bsx_step_kernel<4, false, true, true>), grid, dim3(SPB * 4), 0, s, a); break;
+        case 1: hipLaunchKernelGGL((bsx_step_kernel<1, false, true, true>), grid, dim3(SPB * 1), 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        case 2: hipLaunchKernelGGL((bsx_step_kernel<2, false, true, true>), grid, dim3(SPB * 2), 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        case 3: hipLaunchKernelGGL((bsx_step_kernel<3, false, true, true>), grid, dim3(SPB * 4), 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        default: hipLaunchKernelGGL((bsx_step_kernel<4, false, true, true>), grid, dim3(SPB * 4), 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
     }
     return int(hipGetLastError());
 }

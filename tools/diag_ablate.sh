@@ -10,7 +10,7 @@ cp $SRC/libbattlespace_hip.so /tmp/product.so
 hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -I include -c $SRC/bsx_actor.hip -o /tmp/actor.o
 for d in ${1:-"8 1 2"}; do
   LICM="-mllvm -disable-machine-licm"; case $d in *L) LICM="";; esac
-  hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form $LICM -DBSX_DIAG=${d%L} -I include -c $SRC/bsx_kernels.hip -o /tmp/k.o
+  hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -mllvm -amdgpu-kernarg-preload-count=11 $LICM -DBSX_DIAG=${d%L} -I include -c $SRC/bsx_kernels.hip -o /tmp/k.o
   hipcc --offload-arch=gfx950 -shared -fPIC /tmp/k.o /tmp/actor.o -o $SRC/libbattlespace_hip.so
   timeout -k 10 120 python bench.py ${BMODE:-} --steps 1000 --warmup 100 --no-cpu-baseline --no-other-workloads > gpurun_out/diag/diag${d}_C2.json
   timeout -k 10 120 python bench.py ${BMODE:-} --steps 300 --warmup 100 --no-cpu-baseline --no-other-workloads --envs-per-gpu 1048576 > gpurun_out/diag/diag${d}_1M.json

@@ -7,7 +7,7 @@ lib = os.path.join(src, "libbattlespace_hip.so")
 os.rename(lib, lib + ".product")
 try:
     objs = []
-    for f, extra in (("bsx_kernels.hip", ["-ffp-contract=off", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-mfma-vgpr-form", "-DBSX_STAMPS"]), ("bsx_actor.hip", ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form"])):
+    for f, extra in (("bsx_kernels.hip", ["-ffp-contract=off", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-mfma-vgpr-form", "-mllvm", "-amdgpu-kernarg-preload-count=11", "-DBSX_STAMPS"]), ("bsx_actor.hip", ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form"])):
         o = f"/tmp/stamps_{f}.o"
         subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", *extra, "-I", os.path.join(ROOT, "include"),
                         "-c", os.path.join(src, f), "-o", o], check=True)
