@@ -426,7 +426,32 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     double dir = 0.0;
     EnvU er = {};
     RawIn rin = {}, rin_next = {};
-    if (MULTI && !ACTOR) load_inputs(0, rin_next);
+    struct DecIn { int act; double a0, a1, a2, uu; };    // a call's inputs, decoded
+    auto decode = [&](const RawIn& r) {
+        DecIn d = {-1, 0.0, 0.0, 0.0, 0.0};
+        if (act_) {                                      // uniform branch
+            if (!CONT) {
+                if (kind_ == BSX_ACT_I32) d.act = r.ai;
+                else {   // np.argmax: first maximum; a NaN compares as the maximum
+                    const float v[4] = {r.lg.x, r.lg.y, r.lg.z, r.lg.w};
+                    d.act = 0;
+#pragma unroll
+                    for (int i = 1; i < 4; ++i)
+                        if (!(v[d.act] != v[d.act]) && (v[i] > v[d.act] || v[i] != v[i])) d.act = i;
+                }
+            } else if (kind_ == BSX_ACT_F32 || kind_ == BSX_ACT_F32X4) {
+                d.a0 = double(r.f0); d.a1 = double(r.f1); d.a2 = double(r.f2);
+            } else {
+                d.a0 = r.c0; d.a1 = r.c1; d.a2 = r.c2;
+            }
+        }
+        if (p.u) d.uu = r.uu;                            // uniform branch
+        return d;
+    };
+    // MULTI: the inputs of the NEXT tick are fetched while this one computes and decoded BEFORE this tick's stores go out:
+    // vmcnt is in-order and shared by loads and stores, so decoding at the top of the next tick would wait for all of them.
+    DecIn din_next = {-1, 0.0, 0.0, 0.0, 0.0};
+    if (MULTI && !ACTOR) { load_inputs(0, rin_next); din_next = decode(rin_next); }
     if constexpr (ACTOR) {
         constexpr int D = 3 * N + 2;
         for (int i = int(threadIdx.x); i < 2 * N * bsx_actor::SMALL / 4; i += SPB * WAVES) {
@@ -473,26 +498,9 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         unpack_plane(prw, x, y, live, hp, dir);
         er = unpack_env(erw);
     }
-    if (MULTI) rin = rin_next;
-    int act = -1;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, uu_in = 0.0;
-    if (act_) {                                          // uniform branch
-        if (!CONT) {
-            if (kind_ == BSX_ACT_I32) act = rin.ai;
-            else {   // np.argmax: first maximum; a NaN compares as the maximum
-                const float v[4] = {rin.lg.x, rin.lg.y, rin.lg.z, rin.lg.w};
-                act = 0;
-#pragma unroll
-                for (int i = 1; i < 4; ++i)
-                    if (!(v[act] != v[act]) && (v[i] > v[act] || v[i] != v[i])) act = i;
-            }
-        } else if (kind_ == BSX_ACT_F32 || kind_ == BSX_ACT_F32X4) {
-            a0 = double(rin.f0); a1 = double(rin.f1); a2 = double(rin.f2);
-        } else {
-            a0 = rin.c0; a1 = rin.c1; a2 = rin.c2;
-        }
-    }
-    if (u_t) uu_in = rin.uu;                             // uniform branch
+    const DecIn din = MULTI ? din_next : decode(rin);
+    int act = din.act;
+    double a0 = din.a0, a1 = din.a1, a2 = din.a2, uu_in = din.uu;
     if constexpr (ACTOR) {
         // ---- actions = argmax(actor(obs)) (maddpg/agent.py:25-33, battle_env.py:327-328), rows straight from LDS
         constexpr int D = 3 * N + 2, A_ = 2 * N, G_ = group_width(N);
@@ -862,6 +870,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     }
 
     STAMP(6);
+    if (MULTI && !ACTOR && tk + 1 < p.T) din_next = decode(rin_next);   // the prefetch has long arrived; no store of this tick is out yet
     // ---- write back (MULTI: plane and game records travel in registers; memory gets them once, after the last tick)
     const bool last_tick = !MULTI || tk == p.T - 1;
     if (valid) {
