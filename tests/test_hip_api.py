@@ -113,3 +113,24 @@ def test_empty_call_ties_every_running_game_of_the_batch():
     obs, rew, dones, _ = env.step({})
     assert bool(env.env_done.all()) and bool((env.winner == 3).all()) and float(rew["plane0"].abs().max()) == 0.0
     assert (env.counters()[:, :2] == 1).all()
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    """bench.py's contract with the driver: ONE JSON line on stdout with the agreed keys (a short run, no CPU baseline)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "300", "--warmup", "30", "--no-cpu-baseline",
+                          "--no-other-workloads"], capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["metric"] == "agent-steps/sec" and d["n_gpus"] == 1 and d["steps"] == 300 and d["warmup"] == 30
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert d["value"] > 1e9 and abs(d["value"] - 65536 * 2 * 300 / (d["ms_per_step"] * 1e-3 * 300)) / d["value"] < 1e-3
