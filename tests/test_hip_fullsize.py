@@ -553,3 +553,59 @@ def test_rollout_into_replay_buffer_on_device():
     a_s, s, a, r, a_s2, s2, d = buf.sample()
     assert s.shape == (256, n * env.obs_size) and a.shape == (n, 256, 4) and d.dtype == torch.bool
     assert float(a.abs().max()) <= 1.0
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_randomised_configurations_vs_c_oracle(case):
+    """A seeded sweep over the configuration space -- team size, batch size (ragged), action encoding, float rewards,
+    auto-reset on / off with masked host resets, env_offset, per-step vs multi-tick launches -- HIP against the C oracle:
+    dones equal, rewards within 1e-6, observations within 1e-5, complete integer state identical at the end."""
+    rs = np.random.RandomState(1000 + case)
+    n = int(rs.choice([1, 1, 2, 3, 4, 5, 7]))
+    E = int(rs.randint(1, 400))
+    cont = bool(rs.rand() < 0.3)
+    auto = bool(rs.rand() < 0.6)
+    many = (not cont or rs.rand() < 0.5) and bool(rs.rand() < 0.5)
+    rewards = dict(hit_base_reward=float(rs.choice([100, 50.5])), hit_plane_reward=float(rs.choice([10, 2.25])),
+                   miss_punishment=float(rs.choice([-1, -0.125])), die_punishment=-5.0, lose_punishment=float(rs.choice([-20, -7.5])))
+    off = int(rs.randint(0, 1 << 20))
+    A, T = 2 * n, 130
+    kw = dict(n_agents=n, n_envs=E, seed=case, auto_reset=auto, continuous_actions=cont, env_offset=off, **rewards)
+    env = _env(**kw)
+    c = cref.CRefBatch(E, **{k: v for k, v in kw.items() if k != "n_envs"})
+    env.reset(); c.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(case)
+    t = 0
+    while t < T:
+        k = int(rs.randint(1, 40)) if many else 1
+        k = min(k, T - t)
+        if cont:
+            acts = (torch.rand((k, E, A, 3), generator=g, device="cuda", dtype=torch.float64) * 2.4 - 1.2).to(torch.float32)
+        elif rs.rand() < 0.5:
+            acts = torch.randint(-1, 5, (k, E, A), generator=g, device="cuda", dtype=torch.int32)
+            acts = torch.where(torch.rand((k, E, A), generator=g, device="cuda") < 0.5, torch.ones_like(acts), acts)
+        else:
+            acts = torch.randn((k, E, A, 4), generator=g, device="cuda"); acts[..., 1] += 0.7
+        if many:
+            outs = env.step_many(acts.contiguous(), store=True)
+        for i in range(k):
+            o, r, d = (x[i] for x in outs) if many else env.step_batch(acts[i])
+            co, cr, cd = c.step(acts[i].cpu().numpy())
+            assert np.array_equal(d.cpu().numpy(), cd), (case, t + i)
+            np.testing.assert_allclose(r.cpu().numpy(), cr, rtol=1e-6, atol=1e-6)
+            np.testing.assert_allclose(o.cpu().numpy(), co, rtol=OBS_RTOL, atol=OBS_ATOL)
+        t += k
+        if not auto and rs.rand() < 0.3:                     # host-side masked reset of the finished games, same spawns on both sides
+            m = env.env_done.cpu().numpy().astype(bool)
+            if m.any():
+                spawn = np.zeros((E, 4 + 3 * A), np.int32)
+                spawn[:, 0:4] = [200, 300, 900, 400]
+                for a in range(A):
+                    spawn[:, 4 + 3 * a: 7 + 3 * a] = [100 + 30 * a if a < n else 1100 - 30 * a, 100 + 40 * a, 0 if a < n else 180]
+                env.reset(spawn=spawn, mask=m); c.reset(spawn=spawn, mask=m)
+    sh = {k2: v.cpu().numpy() for k2, v in env.export_state().items()}
+    sc = c.export_state()
+    for f in ("px", "py", "pdir", "php", "bhp", "tick", "env_done", "winner", "bl_live", "counters"):
+        assert np.array_equal(sh[f], sc[f]), (case, f)
+    mlive = sc["bl_live"].astype(bool)
+    assert np.array_equal(sh["bl_x"][mlive], sc["bl_x"][mlive]) and np.array_equal(sh["bl_dir"][mlive], sc["bl_dir"][mlive])
