@@ -639,11 +639,17 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         }
     }
 
-    // ---- stage the post-move block in LDS
-    s_x[tid] = x; s_y[tid] = y; s_hp[tid] = valid ? hp : 0;
-    s_bhit[tid] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    // ---- hand the post-move pose and hit points to the other planes of the game.  1v1: the only other plane is the lane
+    //      next door, three cross-lane moves (DPP) instead of LDS round trips; larger teams stage the block in LDS.
+    int nx_ = 0, ny_ = 0, nhp_ = 0;                      // 1v1: the enemy's x, y, hit points
+    if constexpr (N == 1) {
+        nx_ = __shfl_xor(x, 1); ny_ = __shfl_xor(y, 1); nhp_ = __shfl_xor(valid ? hp : 0, 1);
+    } else {
+        s_x[tid] = x; s_y[tid] = y; s_hp[tid] = valid ? hp : 0;
+        s_bhit[tid] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
 
     STAMP(2);
     // ---- Bullet.__init__ (sprites.py:293-318) for this call's shot: heading = pre-move heading + (u*8 - 4)
@@ -673,7 +679,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     int ex[NE], ey[NE];
     if (!(DIAG & 1u)) obs_pair(x, y, dir, obx, oby, ob_d, ob_a);
     if constexpr (N == 1) {
-        ex[0] = s_x[eb]; ey[0] = s_y[eb];
+        ex[0] = nx_; ey[0] = ny_;
         oe_d[0] = -1.0f; oe_a[0] = -1.0f;
         if (!(DIAG & 1u)) obs_pair(x, y, dir, ex[0], ey[0], oe_d[0], oe_a[0]);
     } else if constexpr (N >= 2) {
@@ -729,7 +735,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     int eam[NE];
     if (N > 0) {
 #pragma unroll
-        for (int j = 0; j < NE; ++j) eam[j] = (s_hp[eb + j] > 0) ? -1 : 0;
+        for (int j = 0; j < NE; ++j) eam[j] = ((N == 1 ? nhp_ : s_hp[eb + j]) > 0) ? -1 : 0;
     }
     // one bullet: pre-update position, step `dd`, updates so far `age0`, list index `j` it was read from (-1: this call's shot)
     auto update_item = [&](int j, int bx0, int by0, int age0, double2 dd, int lvm) {
@@ -804,7 +810,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         }
         // this call's shot is the newest bullet: appended last
         update_item(-1, x0, y0, 0, nd, (spawn ? -1 : 0) & physm);
-        if (nbase) __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)(&s_bhit[gl + team]), nbase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (N != 1 && nbase) __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)(&s_bhit[gl + team]), nbase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (phys) live = uint32_t(pos);
     }
     STAMP(5);
@@ -815,6 +821,14 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     for (int q = 0; q < OW; ++q) any_ovl |= ovl[q];
     if (__ballot(any_ovl != 0ull) != 0ull && !(DIAG & 4u)) {   // wave-uniform: most waves have no candidate at all
         uint32_t consumed = 0;                                 // by age
+        if constexpr (N == 1) {
+            // one shooter per target: my candidates, oldest first, hit until the enemy's hit points run out; the rest fly on
+            int left = nhp_;
+            for (int ag = K - 1; ag >= 1; --ag) {
+                const bool hit = ((ovl[0] >> (ag * FW)) & 1ull) != 0ull && left > 0;
+                if (hit) { left -= 1; nplane += 1; consumed |= 1u << ag; }
+            }
+        } else
         for (int ag = K - 1; ag >= 1; --ag) {                  // oldest first; an age-12 bullet is always a range miss
             uint64_t wsel = ovl[0];
             if (OW == 3) wsel = ((ag >> 2) == 0) ? ovl[0] : (((ag >> 2) == 1) ? ovl[OW > 1 ? 1 : 0] : ovl[OW > 2 ? 2 : 0]);
@@ -843,19 +857,26 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    int nplane_other = 0, nbase_other = 0;               // 1v1: what the enemy's bullets did to me / to my base
+    if constexpr (N == 1) { nplane_other = __shfl_xor(nplane, 1); nbase_other = __shfl_xor(nbase, 1); }
 
     // ---- rewards (battle_env.py:337-359), deaths, bases, win / tie (:363-372, :469-496)
     double rew = double(nmiss) * p.cfg.miss_punishment + double(nbase) * p.cfg.hit_base_reward +
                  double(nplane) * p.cfg.hit_plane_reward;
     bool alive = valid && hp > 0;
     if (mode == M_PHYS) {
-        const int hp_new = s_hp[tid];
+        const int hp_new = (N == 1) ? (valid ? hp : 0) - nplane_other : s_hp[tid];
         if (alive0 && hp_new <= 0) rew += p.cfg.die_punishment;                              // :359
         hp = valid ? hp_new : hp;
         alive = valid && hp > 0;
         er.tick = tick;
-        er.bhp_b -= s_bhit[gl + 0];                      // red shooters damage the blue base
-        er.bhp_r -= s_bhit[gl + 1];
+        if constexpr (N == 1) {
+            er.bhp_b -= team == 0 ? nbase : nbase_other;     // red shooters damage the blue base
+            er.bhp_r -= team == 0 ? nbase_other : nbase;
+        } else {
+            er.bhp_b -= s_bhit[gl + 0];                      // red shooters damage the blue base
+            er.bhp_r -= s_bhit[gl + 1];
+        }
         if (er.bhp_b <= 0) {                             // blue base dead: every red plane gets lose_punishment; red wins
             if (team == 0) rew += p.cfg.lose_punishment;
             er.winner = BSX_WINNER_RED; er.done = 1; cnt_delta.x += 1; cnt_delta.z += 1;
@@ -890,7 +911,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         if (N > 0) {
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
-                const bool on = alive && s_hp[eb + j] > 0;
+                const bool on = alive && ((N == 1) ? (mode == M_PHYS ? nhp_ - nplane : nhp_) : s_hp[eb + j]) > 0;
                 srow[2 + 3 * j] = on ? 1.0f : -1.0f;
                 srow[3 + 3 * j] = on ? oe_d[j] : -1.0f;
                 srow[4 + 3 * j] = on ? oe_a[j] : -1.0f;
