@@ -599,10 +599,30 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     if (!env_ok) mode = M_INERT;
 
     int4 cnt_delta = make_int4(0, 0, 0, 0);              // games, ties, red wins, blue wins
-    bool spawn = false;
     const int x0 = x, y0 = y;
     const double d0 = dir;
     const int64_t genv = p.env_offset + ec;
+    // does this call fire? (battle_env.py:404-406 / :423; the shot leaves from the PRE-move pose, so it is prepared first:
+    // its Philox draw and sincos run while the heading-table entry of the move below is still on its way from the L2)
+    if (CONT) a2 = fmin(fmax(a2, -1.0), 1.0);
+    bool spawn = (mode == M_PHYS) && alive0 && !(DIAG & 2u) && (CONT ? (a2 > 0.0) : (act == 1));
+    // ---- Bullet.__init__ (sprites.py:293-318) for this call's shot: heading = pre-move heading + (u*8 - 4)
+    const bool phys = (mode == M_PHYS) && valid && !(DIAG & 2u);
+    const int ks = tick % K;                             // birth-tick ring slot of this call's shot (heading, export only)
+    double2 nd = make_double2(0.0, 0.0);
+    if (spawn) {
+        double uu = uu_in;
+        if (!u_t) {
+            const uint4 r = draw4(seed_t, genv, STREAM_JITTER, uint32_t(games), (uint32_t(tick) << 8) | uint32_t(a));
+            uu = uniform53(r.x, r.y);
+        }
+        const double bdir = d0 + (uu * 8.0 - 4.0);
+        double sn, cs;
+        sincos(-(bdir * DEG2RAD), &sn, &cs);
+        nd = make_double2(BULLET_STEP * cs, BULLET_STEP * sn);
+        p.st.bdir[size_t(ks) * EAt + gt] = bdir;       // ring by birth tick: never moves, read only by bsx_export_state
+    }
+
 
 
     if (mode == M_RESET) {
@@ -624,9 +644,8 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
                 y = int(double(y) + dl.y);
                 clamp_plane(x, y);
             }
-            spawn = (act == 1);
         } else {
-            a0 = fmin(fmax(a0, -1.0), 1.0); a1 = fmin(fmax(a1, -1.0), 1.0); a2 = fmin(fmax(a2, -1.0), 1.0);
+            a0 = fmin(fmax(a0, -1.0), 1.0); a1 = fmin(fmax(a1, -1.0), 1.0);
             const double speed = ((a0 + 1.0) / 2.0) * 75.0 + 200.0;    // battle_env.py:419
             double sn, cs;
             sincos(-(dir * DEG2RAD), &sn, &cs);
@@ -635,7 +654,6 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
             y = int(double(y) + (st * sn));
             clamp_plane(x, y);
             dir = rotate_dir(dir, a1 * 35.0);                          // :421-422
-            spawn = a2 > 0.0;                                          // :423
         }
     }
 
@@ -652,25 +670,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     }
 
     STAMP(2);
-    // ---- Bullet.__init__ (sprites.py:293-318) for this call's shot: heading = pre-move heading + (u*8 - 4)
-    const bool phys = (mode == M_PHYS) && valid && !(DIAG & 2u);
-    const int ks = tick % K;                             // birth-tick ring slot of this call's shot (heading, export only)
-    double2 nd = make_double2(0.0, 0.0);
-    spawn = spawn && phys;
-    if (spawn) {
-        double uu = uu_in;
-        if (!u_t) {
-            const uint4 r = draw4(seed_t, genv, STREAM_JITTER, uint32_t(games), (uint32_t(tick) << 8) | uint32_t(a));
-            uu = uniform53(r.x, r.y);
-        }
-        const double bdir = d0 + (uu * 8.0 - 4.0);
-        double sn, cs;
-        sincos(-(bdir * DEG2RAD), &sn, &cs);
-        nd = make_double2(BULLET_STEP * cs, BULLET_STEP * sn);
-        p.st.bdir[size_t(ks) * EAt + gt] = bdir;       // ring by birth tick: never moves, read only by bsx_export_state
-    }
-
-    STAMP(3);
+    STAMP(3);                                            // (the shot is prepared before the move now: phase 2 -> 3 is empty)
     // ---- observation geometry (battle_env.py:202-244) from the staged block, BEFORE the bullets: poses are final after
     //      the move, only the alive flags can still change; this fp64 math runs while the bullet-step loads are in flight.
     const int obx = team == 0 ? er.bbx : er.brx, oby = team == 0 ? er.bby : er.bry;   // enemy base

@@ -53,7 +53,7 @@ try:
         d = np.diff(s, axis=1)
         tot[:7] += d.mean(0); reps += 1
         span.append(((s[:, 7].max() - s[:, 0].min()), (s[:, 7] - s[:, 0]).mean(), (s[:, 0].max() - s[:, 0].min())))
-    names = ["T0 loads -> plane rec; issue T1", "classify, action, stage", "spawn (philox, sincos)", "obs geometry", "12-slot bullet loop", "resolve + rewards/finish", "stores"]
+    names = ["T0 loads -> plane rec; issue T1", "classify, shot (philox, sincos), move, hand-off", "(moved into the phase above)", "obs geometry", "12-slot bullet loop", "resolve + rewards/finish", "stores"]
     tot /= reps
     print(f"E={E} n={n} waves={waves}; values are shader CYCLES x10 (s_memtime counts cycles)")
     print(f"  {'kernel entry -> first kernarg use (p.E)':40s} {pre / reps * 10:9.1f} ns")
