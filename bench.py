@@ -5,19 +5,33 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch: ONE step() of every game a rank owns (65 536 games of 1v1 per
-GPU = BASELINE.json configs[1]; N GPUs = N independent shards of 65 536, configs[3] at N=8; no collective on the
-step path).  Actions are i.i.d. uniform over {0,1,2,3} (torch Philox generator, seed 1234+rank), generated before
-the timed region and resident in HBM; bullet jitter and auto-reset spawns are drawn in-kernel (Philox4x32-10).
-Finished games are re-spawned by the next step() call (auto_reset), so resets are inside the measurement.
+Launched plainly with --gpus N > 1 this process touches no GPU: it starts N children (one per GPU, RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1), waits for them and exits with their code; rank 0's child prints the
+JSON line.  Under torch.distributed.run the environment is already there and each rank measures directly.
 
-The K timed steps are launched as replays of a HIP graph holding `--graph-len` consecutive step() launches (the
-launch-bound inner loop of a rollout; `--mode eager` times one Python call per step instead).  Timing: barrier +
-synchronize on both sides, max over ranks.  Rank 0 prints ONE JSON line.
+A "step" is one pass of the hot path over one batch: ONE step() of every game a rank owns (65 536 games of 1v1 per GPU =
+BASELINE.json configs[1]; N GPUs = N independent shards of 65 536, configs[3] at N=8; no collective on the step path).
+Actions are i.i.d. uniform over {0,1,2,3}, a counter hash of (seed 1234, tick, GLOBAL game index, agent) so that the job's
+action table does not depend on the sharding, generated before the timed region and resident in HBM; bullet jitter and auto-reset spawns are drawn in-kernel (Philox4x32-10).  Finished games are re-spawned
+by the next step() call (auto_reset), so resets are inside the measurement; the games' clocks are staggered first (game e
+starts e mod tie_tick ticks late) so that the time-limit ties -- 98 % of all game ends under random play -- are spread
+evenly over any window instead of arriving in lock-step every 121 calls.
 
-roofline: the step kernel is HBM-bound integer/fp64 work.  achieved = ALGORITHMIC bytes per launch (SURVEY.md
-section 8d: 260 B per agent-step at 1v1, 289.3 B at 4v4, x E*A agent-steps per launch) / the kernel's average launch
-duration, measured here with HIP events on the launch stream over the timed region.  peak = 8 TB/s.
+Timing (median of repeats).  After the stagger, the W warm-up steps and an untimed device ramp, the
+block of EXACTLY K steps is timed R times; each time
+  (A) wall clock of each rank's K steps between barrier + torch.cuda.synchronize pairs, MAX over ranks -> ms_per_step, value
+  (B) HIP events on the launch stream around the same K steps, recorded while an untimed K-step block queued just
+      before is still running, so the interval holds device time only (no host launch latency of the first graph)
+                                                                                                  -> roofline.avg_launch_us
+and the MEDIAN over the R repeats is reported (all samples are in the line).  The K steps are launched as replays of a
+HIP graph holding min(K, --graph-len) consecutive step() launches (the launch-bound inner loop of a rollout; `--mode
+eager` times one Python call per step instead).  Rank 0 prints ONE JSON line.
+
+roofline: the step kernel is HBM-bound integer/fp64 work.  achieved = ALGORITHMIC bytes per launch (SURVEY.md section 8d:
+260 B per agent-step at 1v1, 289.3 B at 4v4, x E*A agent-steps per launch) / the kernel's average launch duration (B).
+peak = 8 TB/s.  frac = achieved / peak is the contract figure; frac_on_traffic beside it is the same duration against the
+bytes that actually reached HBM (PMC FETCH_SIZE x 2 + WRITE_SIZE from a separate rocprofv3 pass of this workload, read
+from profiles/traffic.json -- `traffic_source` says which series; the counters cannot be read from inside this process).
 cpu_baseline: the CPU oracle (oracle/battlespace_ref.py, the scalar Python restatement of the reference's step()) on
 configs[0] -- 1 game of 1v1, the same uniform random actions, reset on done -- timed on one host core of this box.
 """
@@ -25,6 +39,9 @@ import argparse
 import json
 import os
 import platform
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -32,14 +49,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-B_ALG = {1: 260.0, 2: 279.25, 3: 285.67, 4: 289.3}   # algorithmic bytes per agent-step (SURVEY.md section 8d formula)
 HBM_PEAK_GBS = 8000.0                                 # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def b_alg(n):
-    """[13 + 146 + 13/A] + [13 + 50 + 5/A] + [4 + 4(3n+2) + 4 + 1] bytes per agent-step."""
+def b_alg(n, continuous=False):
+    """[13 + 146 + 13/A] + [13 + 50 + 5/A] + [4 + 4(3n+2) + 4 + 1] bytes per agent-step
+    (continuous actions: +8 B, three float32 instead of one int32)."""
     A = 2 * n
-    return (13 + 146 + 13 / A) + (13 + 50 + 5 / A) + (4 + 4 * (3 * n + 2) + 4 + 1)
+    return (13 + 146 + 13 / A) + (13 + 50 + 5 / A) + (4 + 4 * (3 * n + 2) + 4 + 1) + (8 if continuous else 0)
+
+
+def b_io(n, continuous=False):
+    return 4 + 4 * (3 * n + 2) + 4 + 1 + (8 if continuous else 0)
 
 
 def _cpu_model():
@@ -101,25 +122,108 @@ def cpu_baseline(seconds_target=12.0):
                       f"CPython {platform.python_version()}); oracle/battlespace_ref.py"}
 
 
-def main():
+def hashed_bits(T, lo, hi, A, k, seed, device):
+    """int64 [T, hi-lo, A, k] of 31 well-mixed bits each, a pure function of (seed, tick, GLOBAL game index, agent, component):
+    the job's action table does not depend on how its games are sharded over ranks (splitmix64 finaliser on a counter)."""
+    import torch
+    M = (1 << 64)
+
+    def c(v):                                               # two's-complement int64 constant
+        v %= M
+        return v - M if v >= (1 << 63) else v
+    t = torch.arange(T, device=device, dtype=torch.int64).view(T, 1, 1, 1)
+    e = torch.arange(lo, hi, device=device, dtype=torch.int64).view(1, hi - lo, 1, 1)
+    a = torch.arange(A, device=device, dtype=torch.int64).view(1, 1, A, 1)
+    j = torch.arange(k, device=device, dtype=torch.int64).view(1, 1, 1, k)
+    x = (e * A + a) * c(0x9E3779B97F4A7C15) + (t * 4 + j) * c(0xD1B54A32D192ED03) + c(seed * 0x2545F4914F6CDD1D + 0x632BE59BD9B4E019)
+    for sh, mul in ((30, 0xBF58476D1CE4E5B9), (27, 0x94D049BB133111EB)):
+        x = (x ^ ((x >> sh) & ((1 << (64 - sh)) - 1))) * c(mul)
+    x = x ^ ((x >> 31) & ((1 << 33) - 1))
+    return (x >> 20) & 0x7FFFFFFF
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--repeats", type=int, default=5, help="the K-step block is timed this many times; medians are reported")
+    ap.add_argument("--ramp-ms", type=float, default=150.0, help="untimed device ramp before the first timed block (clock ramp-up)")
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--n-agents", type=int, default=1, help="planes per team (1 = configs[1], 4 = configs[2])")
-    ap.add_argument("--action-mix", choices=("uniform", "forward", "shoot"), default="uniform",
+    ap.add_argument("--action-mix", choices=("uniform", "forward", "shoot", "dense"), default="uniform",
                     help="uniform = i.i.d. over {0,1,2,3} (the headline); forward = nobody ever shoots (traffic calibration: every "
-                         "byte moved is known); shoot = everybody shoots every tick (stress: ~11 live bullets per agent)")
+                         "byte moved is known); shoot = action 1 every tick (planes run into a wall: ~1.6 live bullets per agent); "
+                         "dense = recorded closed-loop keep-shooting play (~7 live bullets per agent, the bullet-heavy regime)")
     ap.add_argument("--continuous", action="store_true", help="continuous [speed, turn, shoot] actions (battle_env.py:418-424) instead of discrete")
     ap.add_argument("--mode", choices=("graph", "eager", "many"), default="graph")
     ap.add_argument("--graph-len", type=int, default=100)
+    ap.add_argument("--no-stagger", action="store_true", help="leave all games on the same clock (time-limit ties in lock-step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-workloads", action="store_true", help="skip the two extra (non-headline) measurements")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the extra (non-headline) measurements")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="process-group backend for the barrier / timing reduction (nccl = RCCL; gloo only to rehearse N>1 on a 1-GPU box)")
-    ap.add_argument("--rehearse-on-device0", action="store_true", help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
-    args = ap.parse_args()
+    ap.add_argument("--rehearse-on-device0", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (implies --backend gloo; at most 6 ranks may share the card)")
+    ap.add_argument("--digest-dir", default=None, help="every rank writes a digest of its shard's final state here (cross-process shard check)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` started plainly: N children, one per GPU.  The parent initialises no GPU (counting devices
+    does not), so nothing is exec'd or forked from a process that holds the card."""
+    import torch
+    N = args.gpus
+    have = torch.cuda.device_count()
+    if have < N and not args.rehearse_on_device0:
+        raise SystemExit(f"--gpus {N} but only {have} GPU(s) visible; to rehearse the {N}-rank path on one card: "
+                         f"python bench.py --gpus {N} --rehearse-on-device0")
+    if args.rehearse_on_device0 and N > 6:
+        raise SystemExit("at most 6 processes may share one card on this pool")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(N):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(N), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), BSX_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
+    rc = 0
+    try:
+        deadline = time.time() + 1500
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                r = p.poll()
+                if r is not None:
+                    pending.remove(p)
+                    if r != 0 and rc == 0:
+                        rc = r
+            if rc != 0 or time.time() > deadline:
+                break
+            time.sleep(0.05)
+        if pending:                                         # a rank failed (or the deadline passed): stop the others, by PID
+            rc = rc or 124
+            for p in pending:
+                p.terminate()
+            for p in pending:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    raise SystemExit(rc)
+
+
+def main():
+    args = parse_args()
+    if args.rehearse_on_device0:
+        args.backend = "gloo"
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args)
 
     import torch
     import torch.distributed as dist
@@ -127,7 +231,7 @@ def main():
 
     rank, world, local_rank = sharding.rank_world()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev_index = 0 if args.rehearse_on_device0 else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -142,25 +246,115 @@ def main():
             dist.init_process_group("gloo")
 
     def barrier():
+        torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def measure(n, E, K, W, mode, graph_len):
-        """K timed step() calls of E games x n-v-n on this rank; returns (env, seconds, kernel ms per launch, graph len)."""
+    def max_over_ranks(values):
+        if world == 1:
+            return list(values)
+        t = torch.tensor(values, device=red_dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.tolist()
+
+    def timed_blocks(run, K, R, restore=None):
+        """-> (wall seconds per repeat, kernel ms per launch per repeat); see the module docstring (A), (B).
+        restore: a recorded trajectory is rewound before every block (its device copy is what keeps the queue busy in (B))."""
+        walls, kms = [], []
+        for _ in range(R):
+            if restore:
+                restore()
+            barrier()
+            t0 = time.perf_counter()
+            run(K)
+            torch.cuda.synchronize(dev)
+            walls.append(time.perf_counter() - t0)          # this rank's K steps, synchronised; the MAX over ranks is taken below
+            barrier()
+            if restore:
+                restore()
+            else:
+                run(K)                                      # untimed: keeps the device busy while the events and the next block are queued
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            run(K)
+            ev1.record()
+            torch.cuda.synchronize(dev)
+            kms.append(ev0.elapsed_time(ev1) / K)
+        return max_over_ranks(walls), max_over_ranks(kms)
+
+    def ramp(run, ms, K):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        while (time.perf_counter() - t0) * 1e3 < ms:
+            run(K)
+            torch.cuda.synchronize(dev)
+
+    def stagger(env, step_fn):
+        """Spread the games' clocks: game e is re-spawned e mod tie_tick calls into the pre-roll, so afterwards the time-limit
+        ties (and with them the auto-resets) fall evenly on every call instead of all on call 121, 242, ..."""
+        P = env.tie_tick
+        idx = (torch.arange(env.n_envs, device=dev) + env.env_offset) % P      # global game index: the same games whatever the sharding
+        for k in range(P):
+            step_fn(k)
+            env.reset(mask=(idx == k))
+
+    def dense_policy(env):
+        """Closed-loop 'keep shooting' play for the bullet-heavy regime: fire unless the point 450 px ahead is off the field or
+        the enemy base sits on the line of fire (a base hit ends games and clears every bullet); then turn toward the middle."""
+        st = env.export_state(("px", "py", "pdir", "base_xy"))
+        px, py = st["px"].double(), st["py"].double()
+        d = torch.deg2rad(st["pdir"])
+        hx, hy = torch.cos(d), -torch.sin(d)
+        ax, ay = px + 450.0 * hx, py + 450.0 * hy
+        out = (ax < 0) | (ax > 1200) | (ay < 0) | (ay > 800)
+        b = st["base_xy"].double()
+        n = env.n_agents
+        ebx = torch.cat([b[:, 2:3].expand(-1, n), b[:, 0:1].expand(-1, n)], 1)
+        eby = torch.cat([b[:, 3:4].expand(-1, n), b[:, 1:2].expand(-1, n)], 1)
+        rx, ry = ebx - px, eby - py
+        along, perp = rx * hx + ry * hy, (rx * hy - ry * hx).abs()
+        near_base = (along > -40) & (along < 560) & (perp < 60)
+        turn = torch.where(hy * (600 - px) - hx * (400 - py) > 0, 2, 3)
+        return torch.where(out | near_base, turn, torch.ones_like(turn)).to(torch.int32)
+
+    def measure(n, E, K, W, mode, graph_len, mix="uniform", continuous=False, R=None, do_stagger=True):
+        """K timed step() calls of E games x n-v-n on this rank, R times -> dict(env, walls, kms, G, live)."""
         A = 2 * n
+        R = R or args.repeats
         env = sharding.make_shard(E * world, rank, world, n_agents=n, device=dev, seed=1234, auto_reset=True,
-                                  continuous_actions=args.continuous)
+                                  continuous_actions=continuous)
         env.reset()
         G = max(1, min(graph_len, K))                       # steps per graph replay; a remainder runs as plain calls
-        gen = torch.Generator(device=dev)
-        gen.manual_seed(1234 + rank)
-        if args.continuous:
-            actions = torch.rand((G, E, A, 3), generator=gen, device=dev, dtype=torch.float32) * 2 - 1
-        elif args.action_mix == "uniform":
-            actions = torch.randint(0, 4, (G, E, A), generator=gen, device=dev, dtype=torch.int32)
+        lo = env.env_offset
+        restore, live = None, None
+        if mix == "dense":
+            if continuous or mode != "graph":
+                raise SystemExit("--action-mix dense is a recorded discrete trajectory replayed as one HIP graph")
+            # pre-roll to the steady state of the closed-loop play, snapshot, record the next K calls' actions, rewind
+            stagger(env, lambda k: env.step_batch(dense_policy(env)))
+            for _ in range(60):
+                env.step_batch(dense_policy(env))
+            snap = env.state_dict()
+            G = K
+            actions = torch.empty((K, E, A), dtype=torch.int32, device=dev)
+            lv = []
+            for t in range(K):
+                actions[t] = dense_policy(env)
+                env.step_batch(actions[t])
+                if t % 10 == 0:
+                    lv.append(float(env.export_state(("bl_live",))["bl_live"].float().sum()) / (E * A))
+            live = round(sum(lv) / len(lv), 3)
+            restore = lambda: env.load_state_dict(snap)     # noqa: E731
+            restore()
+        elif continuous:
+            actions = (hashed_bits(G, lo, lo + E, A, 3, 1234, dev).to(torch.float32) * (2.0 / 2147483648.0) - 1.0).contiguous()
+        elif mix == "uniform":
+            actions = (hashed_bits(G, lo, lo + E, A, 1, 1234, dev)[..., 0] >> 29).to(torch.int32).contiguous()
         else:
-            actions = torch.full((G, E, A), 0 if args.action_mix == "forward" else 1, device=dev, dtype=torch.int32)
+            actions = torch.full((G, E, A), 0 if mix == "forward" else 1, device=dev, dtype=torch.int32)
+        if mix != "dense" and do_stagger and not args.no_stagger:
+            stagger(env, lambda k: env.step_batch(actions[k % G]))
         if mode == "graph":
             graph, _ = env.capture_steps(actions)
 
@@ -186,123 +380,203 @@ def main():
             def run(steps):
                 for t in range(steps):
                     env.step_batch(actions[t % G])
-        run(W)
-        barrier()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record()
-        run(K)
-        ev1.record()
-        barrier()
-        dt = time.perf_counter() - t0
-        kernel_ms = ev0.elapsed_time(ev1) / K              # average launch-to-launch duration on the launch stream
-        if world > 1:
-            t = torch.tensor([dt, kernel_ms], device=red_dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt, kernel_ms = float(t[0]), float(t[1])
-        return env, dt, kernel_ms, G
+        if not restore:
+            run(W)
+            ramp(run, args.ramp_ms, K)
+        else:
+            ramp(lambda k: (restore(), graph.replay()), args.ramp_ms, K)
+        walls, kms = timed_blocks(run, K, R, restore)
+        if live is None and E * A <= (1 << 22):
+            live = round(float(env.export_state(("bl_live",))["bl_live"].float().sum()) / (E * A), 3)
+        return dict(env=env, walls=walls, kms=kms, G=G, live=live)
+
+    def kernel_name(n, continuous, many):
+        return f"bsx_step_kernel<{n if n <= 4 else 0},{'true' if continuous else 'false'},{'true' if many else 'false'},false>"
+
+    def traffic_entry(key):
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
+        except Exception:
+            return None
+
+    def summary(m, n, E, K, continuous=False, many=False, key=None):
+        """One non-headline workload as a dict (medians over the repeats)."""
+        A = 2 * n
+        km, wall = statistics.median(m["kms"]), statistics.median(m["walls"])
+        ach = b_alg(n, continuous) * E * A / (km * 1e-3) / 1e9
+        out = {"agent_steps_per_s": round(E * A * K / wall, 1), "avg_launch_us": round(km * 1e3, 3), "roofline_frac": round(ach / HBM_PEAK_GBS, 4),
+               "kernel": kernel_name(n, continuous, many), "steps": K, "repeats": len(m["kms"]),
+               "live_bullets_per_agent": m["live"]}
+        te = traffic_entry(key) if key else None
+        if te:
+            tb = te["hbm_bytes_per_tick" if many else "hbm_bytes_per_launch"]
+            out.update(traffic=tb, frac_on_traffic=round(tb / (km * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), traffic_source=f"profiles/traffic.json[{key}] (series {te.get('series')})")
+        return out
 
     n, E = args.n_agents, args.envs_per_gpu
     A = 2 * n
     K, W = args.steps, args.warmup
-    env, dt, kernel_ms, G = measure(n, E, K, W, args.mode, args.graph_len)
-
+    head = measure(n, E, K, W, args.mode, args.graph_len, mix=args.action_mix, continuous=args.continuous)
+    env = head["env"]
     games = sharding.reduce_counters(sharding.local_counter_sums(env).to(red_dev))   # logging only, after the timed region
+    if args.digest_dir:
+        # cross-process shard check (tests/test_hip_sharding.py): what this rank's games look like after the run
+        import hashlib
+        st = env.export_state()
+        os.makedirs(args.digest_dir, exist_ok=True)
+        h = hashlib.sha256()
+        for k in sorted(st):
+            h.update(st[k].cpu().numpy().tobytes())
+        with open(os.path.join(args.digest_dir, f"rank{rank}.json"), "w") as f:
+            json.dump({"rank": rank, "world": world, "env_offset": env.env_offset, "n_envs": env.n_envs, "sha256": h.hexdigest()}, f)
+        torch.save({k: v.cpu() for k, v in st.items()}, os.path.join(args.digest_dir, f"rank{rank}.pt"))
+    head_env_tie_tick = env.tie_tick
+    del env
+    head["env"] = None
+    torch.cuda.empty_cache()
 
-    # not the headline: the same kernel on BASELINE.json configs[2] and in the streaming regime (working set > Infinity
-    # Cache), a few hundred steps each, so one run shows how the roofline fraction moves with the batch
-    others = {}
-    multi = None
-    if world == 1 and not args.no_other_workloads and args.mode != "many":
-        # the same K ticks as K/100 multi-tick launches (bsx_step_many_*: every tick's outputs stored, state carried in
-        # registers / L2 between ticks): what an open-loop caller (random or scripted play) gets without kernel boundaries
-        del env
+    # Not the headline: the same kernel on BASELINE.json configs[2], in the streaming regime (working set > Infinity Cache),
+    # with many live bullets, with continuous actions, as a multi-tick launch, and with the policy in the loop (configs[4]).
+    others, multi, loop_sampling, rollouts = {}, None, None, None
+    extra = world == 1 and not args.no_other_workloads and (n, E) == (1, 65536) and args.mode == "graph" \
+        and args.action_mix == "uniform" and not args.continuous
+    if extra:
+        Ko = min(K, 400)
+        m = measure(n, E, min(K, 1000), W, "many", 100)
+        multi = summary(m, n, E, min(K, 1000), many=True, key=f"E{E}_n{n}_many")
+        multi.update(ticks_per_launch=m["G"], us_per_tick=multi.pop("avg_launch_us"),
+                     note="not the headline: north_star asks for one kernel per step")
+        del m
         torch.cuda.empty_cache()
-        env, dtm, kmm, Gm = measure(n, E, K, W, "many", 100)
-        achm = b_alg(n) * E * A / (kmm * 1e-3) / 1e9
-        multi = {"agent_steps_per_s": round(E * A * K / dtm, 1), "us_per_tick": round(kmm * 1e3, 3), "ticks_per_launch": Gm,
-                 "roofline_frac": round(achm / HBM_PEAK_GBS, 4), "kernel": f"bsx_step_kernel<{n if n <= 4 else 0},{'true' if args.continuous else 'false'},true,false>",
-                 "note": "not the headline: north_star asks for one kernel per step"}
-        try:
-            multi["traffic_per_tick"] = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[f"E{E}_n{n}_many"]["hbm_bytes_per_tick"]
-        except Exception:
-            multi["traffic_per_tick"] = None
-    loop_sampling = None
-    if world == 1 and not args.no_other_workloads and not args.continuous:
         # SURVEY.md section 8d: the same loop with the actions SAMPLED inside it (one torch.randint + one step() call per
         # tick from Python, no graph): what a caller that draws random actions tick by tick sees
-        del env
-        torch.cuda.empty_cache()
-        env = sharding.make_shard(E, 0, 1, n_agents=n, device=dev, seed=1234, auto_reset=True)
-        env.reset()
+        envs = sharding.make_shard(E, 0, 1, n_agents=n, device=dev, seed=1234, auto_reset=True)
+        envs.reset()
         gen2 = torch.Generator(device=dev); gen2.manual_seed(1234)
         Ks = min(K, 500)
         for _ in range(50):
-            env.step_batch(torch.randint(0, 4, (E, A), generator=gen2, device=dev, dtype=torch.int32))
+            envs.step_batch(torch.randint(0, 4, (E, A), generator=gen2, device=dev, dtype=torch.int32))
         torch.cuda.synchronize(dev); t0 = time.perf_counter()
         for _ in range(Ks):
-            env.step_batch(torch.randint(0, 4, (E, A), generator=gen2, device=dev, dtype=torch.int32))
+            envs.step_batch(torch.randint(0, 4, (E, A), generator=gen2, device=dev, dtype=torch.int32))
         torch.cuda.synchronize(dev); dts = time.perf_counter() - t0
         loop_sampling = {"agent_steps_per_s": round(E * A * Ks / dts, 1), "us_per_step": round(dts / Ks * 1e6, 2), "steps": Ks,
                          "note": "eager Python loop: torch.randint + step_batch per tick"}
-    if world == 1 and not args.no_other_workloads and (n, E) == (1, 65536):
-        for tag, (n2, E2, K2) in {"configs[2] 65536 x 4v4": (4, 65536, 400), "1048576 x 1v1 (streaming)": (1, 1048576, 200),
-                                  "65536 x 1v1, all-shoot stress (action = 1 every tick, ~11 live bullets per agent)": (1, 65536, 400)}.items():
-            del env
-            torch.cuda.empty_cache()
-            saved_mix = args.action_mix
-            if "all-shoot" in tag:
-                args.action_mix = "shoot"
-            env, dt2, km2, _ = measure(n2, E2, K2, 50, args.mode, 100)
-            args.action_mix = saved_mix
-            ach = b_alg(n2) * E2 * 2 * n2 / (km2 * 1e-3) / 1e9
-            others[tag] = {"agent_steps_per_s": round(E2 * 2 * n2 * K2 / dt2, 1), "avg_launch_us": round(km2 * 1e3, 2),
-                           "roofline_frac": round(ach / HBM_PEAK_GBS, 4)}
-        del env
+        del envs
         torch.cuda.empty_cache()
+        for tag, (n2, E2, K2, mix2, cont2, key2) in {
+                "configs[2] 65536 x 4v4": (4, 65536, Ko, "uniform", False, "E65536_n4"),
+                "1048576 x 1v1 (streaming)": (1, 1048576, min(K, 200), "uniform", False, "E1048576_n1"),
+                "65536 x 1v1, bullet-heavy (recorded closed-loop keep-shooting play)": (1, 65536, min(K, 300), "dense", False, "E65536_n1_dense"),
+                "65536 x 1v1, action 1 every tick (planes end up on a wall)": (1, 65536, Ko, "shoot", False, None),
+                "65536 x 1v1, continuous actions": (1, 65536, Ko, "uniform", True, "E65536_n1_cont"),
+                "65536 x 4v4, continuous actions": (4, 65536, Ko, "uniform", True, "E65536_n4_cont")}.items():
+            m = measure(n2, E2, K2, 50, "graph", 100, mix=mix2, continuous=cont2, R=3)
+            others[tag] = summary(m, n2, E2, K2, continuous=cont2, key=key2)
+            del m
+            torch.cuda.empty_cache()
+        rollouts = rollout_lines(dev, E, min(K, 320))
     if rank == 0:
+        wall, km = statistics.median(head["walls"]), statistics.median(head["kms"])
         agent_steps = E * world * A * K
-        bytes_per_launch = b_alg(n) * E * A
-        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                key = f"E{E}_n{n}" + ("_many" if args.mode == "many" else "")
-                if key in tj:
-                    traffic = tj[key]["hbm_bytes_per_tick" if args.mode == "many" else "hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
+        bytes_per_launch = b_alg(n, args.continuous) * E * A
+        achieved = bytes_per_launch / (km * 1e-3) / 1e9
+        many = args.mode == "many"
+        key = f"E{E}_n{n}" + ("_cont" if args.continuous else "") + ("_dense" if args.action_mix == "dense" else "") + ("_many" if many else "")
+        te = traffic_entry(key) if args.action_mix in ("uniform", "dense") else None
+        traffic = te["hbm_bytes_per_tick" if many else "hbm_bytes_per_launch"] if te else None
+        mixname = {"uniform": "uniform random", "forward": "all-forward", "shoot": "all-shoot", "dense": "recorded keep-shooting"}[args.action_mix]
         out = {
-            "metric": "agent-steps/sec", "value": round(agent_steps / dt, 1), "unit": "agent-steps/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 6),
+            "metric": "agent-steps/sec", "value": round(agent_steps / wall, 1), "unit": "agent-steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(wall / K * 1e3, 6),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64/i16", "data": "synthetic",
-            "config": {"workload": f"{E} games x {n}v{n} per GPU, {'uniform random' if args.action_mix == 'uniform' else 'all-' + args.action_mix} {'continuous' if args.continuous else 'discrete'} actions, fused HIP step(), auto-reset "
-                                   f"(BASELINE.json configs[{1 if n == 1 else 2}]{' x ' + str(world) + ' shards' if world > 1 else ''})",
+            "config": {"workload": f"{E} games x {n}v{n} per GPU, {mixname} {'continuous' if args.continuous else 'discrete'} actions, fused HIP step(), auto-reset, "
+                                   f"staggered game clocks (BASELINE.json configs[{1 if n == 1 else 2}]{' x ' + str(world) + ' shards' if world > 1 else ''})",
                        "envs_per_gpu": E, "n_agents_per_team": n, "agents_per_env": A, "launch": args.mode,
-                       "graph_len": G if args.mode == "graph" else None, "parallelism": f"{world} independent env shards, no collective"},
+                       "graph_len": head["G"] if args.mode == "graph" else None, "parallelism": f"{world} independent env shards, no collective",
+                       "rehearsal_all_ranks_on_device0": bool(args.rehearse_on_device0) or None},
+            "timing": {"repeats": len(head["walls"]), "statistic": "median", "ramp_ms": args.ramp_ms,
+                       "ms_per_step_samples": [round(w / K * 1e3, 6) for w in head["walls"]],
+                       "avg_launch_us_samples": [round(k * 1e3, 3) for k in head["kms"]],
+                       "note": "ms_per_step: wall clock around K steps between barrier+synchronize pairs (at K = 20 the ~30 us of "
+                               "synchronisation are 15 % of the block); avg_launch_us: HIP events around the same K steps queued behind "
+                               "an untimed block, device time only"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": f"bsx_step_kernel<{n if n <= 4 else 0},{'true' if args.continuous else 'false'},{'true' if args.mode == 'many' else 'false'},false>", "avg_launch_us": round(kernel_ms * 1e3, 3),
-                         "algorithmic_bytes_per_launch": round(bytes_per_launch), "bytes_per_agent_step": round(b_alg(n), 2),
+                         "frac_on_traffic": round(traffic / (km * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
+                         "traffic_source": f"profiles/traffic.json[{key}] (series {te.get('series')}): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                           "workload, read side x2 (MI355X_MICROARCH.md); a constant from that profile, not measured by this run" if te else None,
+                         "kernel": kernel_name(n, args.continuous, many), "avg_launch_us": round(km * 1e3, 3),
+                         "algorithmic_bytes_per_launch": round(bytes_per_launch), "bytes_per_agent_step": round(b_alg(n, args.continuous), 2),
                          # SURVEY.md section 8d asks for these beside it: the API-only lower bound (action in; obs, reward, done out)
-                         # and the fraction on the bytes that actually reached HBM (PMC)
-                         "io_only_bytes_per_agent_step": 4 + 4 * (3 * n + 2) + 4 + 1,
-                         "io_only_frac": round((4 + 4 * (3 * n + 2) + 4 + 1) * E * A / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         "traffic_frac": round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
+                         "io_only_bytes_per_agent_step": b_io(n, args.continuous),
+                         "io_only_frac": round(b_io(n, args.continuous) * E * A / (km * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "live_bullets_per_agent": head["live"],
                          "regime": "latency-bound at this size: 2 wavefronts per SIMD, working set 48 MB inside the 256 MB Infinity Cache "
-                                   "(DESIGN.md section 6)" if (n, E) == (1, 65536) and args.mode != "many" else None},
+                                   "(DESIGN.md section 6)" if (n, E) == (1, 65536) and not many else None},
             "games_finished": int(games[0]), "ties": int(games[1]), "red_wins": int(games[2]), "blue_wins": int(games[3]),
+            "tie_tick": head_env_tie_tick,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         out["other_workloads"] = others
         out["multi_tick_launch"] = multi
         out["loop_incl_action_sampling"] = loop_sampling
+        out["policy_rollouts"] = rollouts
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def rollout_lines(dev, E, K):
+    """BASELINE.json configs[4]: 65 536 games x 1v1 with the policy in the loop, end-to-end agent-steps/s.  The caller's loop
+    `actions = actor(obs) + noise; obs, rew, done = env.step(actions)` (reference main.py:177-181, maddpg/agent.py:25-33) on
+    device: as a HIP graph of two kernels per tick (bsx_actor_forward -> bsx_step_*), and as ONE launch for all T ticks
+    (bsx_rollout_*); actors are random-init networks of the reference's shape, Gaussian exploration noise 0.1."""
+    import torch
+    import deep_rl_battlespace_amd as bsx
+    from deep_rl_battlespace_amd import instinct
+    from deep_rl_battlespace_amd.rollout import PolicyRollout, StackedActor
+    T = 32
+    out = {}
+    variants = [("graph of 2 kernels per tick, both teams on actors", dict(), False, False),
+                ("one launch for all ticks, both teams on actors", dict(one_launch=True), False, False),
+                ("one launch, 64x64 layer as split-bf16 matrix products", dict(one_launch=True, precision="bf16x3"), False, False),
+                ("one launch, red = actor vs blue = scripted instinct opponent (main.py:119-122)", dict(one_launch=True), True, False),
+                ("continuous actions: graph of 2 kernels per tick", dict(), False, True),
+                ("continuous actions: one launch for all ticks", dict(one_launch=True), False, True)]
+    for tag, kw, scripted, cont in variants:
+        try:
+            env = bsx.parallel_env(n_agents=1, n_envs=E, auto_reset=True, seed=1234, device=dev, continuous_actions=cont)
+            env.reset()
+            torch.manual_seed(0)
+            actor = StackedActor(2, 5, 3 if cont else 4, device=dev)
+            with torch.no_grad():
+                actor.w3.mul_(100.0)                        # random init leaves the head near 0: spread the scores so that play is varied
+            opp = instinct.Team(env.possible_blue, env.possible_red, env) if scripted else None
+            ro = PolicyRollout(env, actor, T, noise_std=0.1, opponent=opp, **kw)
+            ro.start(); ro.capture()
+            reps = max(1, K // T)
+            for _ in range(3 + 150 // T):                   # past the first time-limit ties
+                ro.run()
+            samples = []
+            for _ in range(3):
+                torch.cuda.synchronize(dev); t0 = time.perf_counter()
+                for _ in range(reps):
+                    ro.run()
+                torch.cuda.synchronize(dev)
+                samples.append((time.perf_counter() - t0) / (reps * T))
+            dt = statistics.median(samples)
+            c = env.counters().sum(0)
+            out[tag] = {"agent_steps_per_s": round(E * 2 / dt, 1), "us_per_tick": round(dt * 1e6, 3), "ticks_per_launch_or_graph": T,
+                        "ticks_timed": reps * T, "repeats": 3, "games_finished": int(c[0]), "ties": int(c[1]), "red_wins": int(c[2]), "blue_wins": int(c[3])}
+            del ro, env, actor
+        except Exception as exc:                            # a variant this build does not offer is reported, not hidden
+            out[tag] = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
+        torch.cuda.empty_cache()
+    return {"workload": f"BASELINE.json configs[4]: {E} games x 1v1 + on-device actor per plane (obs 5 -> 64 -> LayerNorm -> 64 -> LayerNorm -> 4, "
+                        "maddpg/networks.py:54-85), end to end", "variants": out}
 
 
 if __name__ == "__main__":

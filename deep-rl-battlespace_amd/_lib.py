@@ -3,9 +3,12 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbattlespace_hip.so")
+# The product library is the in-tree build.  BSX_LIB_PATH points the binding at ANOTHER build of the same sources (profiling
+# variants under csrc/variants/, built by tools/): diagnostic builds never overwrite the product file, and one whose
+# bsx_build_flags() is non-zero (results are not the reference's) is refused unless BSX_ALLOW_DIAG=1 is set as well.
+LIB_PATH = os.environ.get("BSX_LIB_PATH") or os.path.join(_HERE, "csrc", "libbattlespace_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 BULLET_SLOTS = 12
 MAX_N = 16
 MAX_T = 65535
@@ -29,7 +32,7 @@ class BsxRewards(ctypes.Structure):
 class BsxActorNoise(ctypes.Structure):
     _fields_ = [("gaussian_std", ctypes.c_float), ("ou_scale", ctypes.c_float), ("ou_theta", ctypes.c_float),
                 ("ou_sigma", ctypes.c_float), ("ou_mu", ctypes.c_float), ("ou_state", ctypes.c_void_p),
-                ("env_done", ctypes.c_void_p)]
+                ("env_done", ctypes.c_void_p), ("z_inject", ctypes.c_void_p)]
 
 
 EXPORT_FIELDS = ("px", "py", "pdir", "php", "palive", "base_xy", "bhp", "tick", "env_done", "winner",
@@ -43,6 +46,7 @@ class BsxExport(ctypes.Structure):
 # name -> (restype, argtypes): every symbol include/battlespace_hip.h declares
 SIGNATURES = {
     "bsx_abi_version": (c_int, []),
+    "bsx_build_flags": (c_int, []),
     "bsx_state_bytes": (c_int, [c_int64, c_int, ctypes.POINTER(c_size_t)]),
     "bsx_state_init": (c_int, [c_void_p, c_int64, c_int, c_void_p]),
     "bsx_reset": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_uint64, c_uint64, c_int64, c_void_p, c_void_p]),
@@ -51,12 +55,15 @@ SIGNATURES = {
     "bsx_step_continuous": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, ctypes.POINTER(BsxRewards), c_uint32, c_uint64, c_int64, c_void_p]),
     "bsx_step_many_discrete": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                       c_void_p, c_void_p, ctypes.POINTER(BsxRewards), c_uint32, c_int, c_uint64, c_int64, c_void_p]),
+                                       c_void_p, c_void_p, c_void_p, ctypes.POINTER(BsxRewards), c_uint32, c_int, c_uint64, c_int64, c_void_p]),
     "bsx_step_many_continuous": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                         c_void_p, c_void_p, ctypes.POINTER(BsxRewards), c_uint32, c_int, c_uint64, c_int64, c_void_p]),
+                                         c_void_p, c_void_p, c_void_p, ctypes.POINTER(BsxRewards), c_uint32, c_int, c_uint64, c_int64, c_void_p]),
     "bsx_rollout_discrete": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                     c_void_p, ctypes.POINTER(BsxRewards), c_uint32, ctypes.POINTER(BsxActorNoise), c_uint64,
+                                     c_void_p, c_void_p, ctypes.POINTER(BsxRewards), c_uint32, ctypes.POINTER(BsxActorNoise), c_uint64,
                                      c_uint64, c_void_p, c_uint64, c_int64, c_void_p]),
+    "bsx_rollout_continuous": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, ctypes.POINTER(BsxRewards), c_uint32, ctypes.POINTER(BsxActorNoise), c_uint64,
+                                       c_uint64, c_void_p, c_uint64, c_int64, c_void_p]),
     "bsx_observe": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "bsx_export_state": (c_int, [c_void_p, c_int64, c_int, ctypes.POINTER(BsxExport), c_void_p]),
     "bsx_tie_tick": (c_int, [c_int]),
@@ -64,7 +71,7 @@ SIGNATURES = {
     "bsx_instinct_continuous": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_uint64, c_uint64, c_void_p, c_void_p]),
     "bsx_actor_blob_floats": (c_int, [c_int, ctypes.POINTER(c_int)]),
     "bsx_actor_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, ctypes.POINTER(BsxActorNoise), c_uint64, c_uint64,
-                                  c_void_p, c_void_p]),
+                                  c_void_p, c_int64, c_void_p]),
 }
 
 _lib = None
@@ -88,6 +95,10 @@ def load():
     v = lib.bsx_abi_version()
     if v != ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {v}, binding expects {ABI_VERSION}; rebuild the extension")
+    flags = lib.bsx_build_flags()
+    if flags and os.environ.get("BSX_ALLOW_DIAG") != "1":
+        raise ImportError(f"{LIB_PATH} is a diagnostic build (bsx_build_flags() = {flags:#x}): its results are not the "
+                          f"reference's.  Rebuild the product library, or set BSX_ALLOW_DIAG=1 for a timing-only run.")
     _lib = lib
     return lib
 

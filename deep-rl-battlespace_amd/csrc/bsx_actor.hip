@@ -37,7 +37,7 @@ constexpr int ROWS_PER_WAVE = 64;
 
 struct ActorArgs {
     const float* weights; const float* obs; float* scores;
-    int64_t E; int A; int D; BsxActorNoise nz; uint64_t seed; uint64_t seq; const uint64_t* seq_base;
+    int64_t E; int A; int D; BsxActorNoise nz; uint64_t seed; uint64_t seq; const uint64_t* seq_base; int64_t env_offset;
 };
 
 // BF16X3 = false: exact f32, both 32-row tiles of the wave interleaved (four independent accumulators).
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(TPB) void bsx_actor_kernel(const ActorArgs p) {
     const size_t row = size_t(e < p.E ? e : p.E - 1) * p.A + a;
     const uint64_t seq = p.seq + (p.seq_base ? *p.seq_base : 0ull);   // seq_base: device word, so graph replays re-key
     const bool game_over = p.nz.ou_scale > 0.f && p.nz.env_done && p.nz.env_done[e < p.E ? e : p.E - 1];
-    r4 = finish_row(r4, b3, p.nz, p.seed, seq, row, game_over, e < p.E);
+    r4 = finish_row(r4, b3, p.nz, p.seed, seq, row, uint64_t(p.env_offset) * uint64_t(p.A) + row, game_over, e < p.E);
     if (e < p.E) reinterpret_cast<float4*>(p.scores)[row] = r4;
 }
 
@@ -174,15 +174,18 @@ int bsx_actor_blob_floats(int obs_len, int* floats_per_agent) {
 }
 
 int bsx_actor_forward(const float* weights, const float* obs, float* scores, int64_t E, int n, int precision,
-                      const BsxActorNoise* noise, uint64_t seed, uint64_t seq, const uint64_t* seq_base, void* stream) {
+                      const BsxActorNoise* noise, uint64_t seed, uint64_t seq, const uint64_t* seq_base, int64_t env_offset,
+                      void* stream) {
     if (!weights || !obs || !scores || E <= 0 || E > BSX_MAX_E || n < 1 || n > BSX_MAX_N) return BSX_E_ARG;
     if (precision != BSX_ACTOR_F32 && precision != BSX_ACTOR_BF16X3) return BSX_E_ARG;
     if (!aligned(weights, 16) || !aligned(scores, 16) || !aligned(obs, 4)) return BSX_E_ALIGN;
-    BsxActorNoise nz = {0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr};
+    BsxActorNoise nz = {0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr};
     if (noise) nz = *noise;
     if (nz.ou_scale > 0.f && (!nz.ou_state || !aligned(nz.ou_state, 16))) return nz.ou_state ? BSX_E_ALIGN : BSX_E_ARG;
+    if (nz.z_inject && !aligned(nz.z_inject, 16)) return BSX_E_ALIGN;
+    if (env_offset < 0) return BSX_E_ARG;
     const int A = 2 * n, D = 3 * n + 2;
-    ActorArgs a{weights, obs, scores, E, A, D, nz, seed, seq, seq_base};
+    ActorArgs a{weights, obs, scores, E, A, D, nz, seed, seq, seq_base, env_offset};
     const int rows_per_block = (TPB / 64) * ROWS_PER_WAVE;
     const dim3 grid(unsigned((E + rows_per_block - 1) / rows_per_block), unsigned(A)), block(TPB);
     if (precision == BSX_ACTOR_BF16X3) hipLaunchKernelGGL(bsx_actor_kernel<true>, grid, block, 0, static_cast<hipStream_t>(stream), a);

@@ -89,23 +89,31 @@ __device__ inline void ln_relu_tile(f32x16& a0, f32x16& a1, const float* __restr
     }
 }
 
+// Four standard normals from one Philox4x32-10 block (Box-Muller), keyed by (seed, seq ^ salt, global row).
+__device__ inline float4 normals4(uint64_t seed, uint64_t seq, uint64_t grow, uint32_t salt) {
+#pragma clang fp contract(fast)
+    const uint4 r = philox4x32_10(make_uint4(uint32_t(grow), uint32_t(grow >> 32), uint32_t(seq), uint32_t(seq >> 32) ^ salt),
+                                  make_uint2(uint32_t(seed), uint32_t(seed >> 32) ^ 0xA5A5A5A5u));
+    const float u0 = (float(r.x >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = float(r.y >> 8) * (1.0f / 16777216.0f);
+    const float u2 = (float(r.z >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = float(r.w >> 8) * (1.0f / 16777216.0f);
+    const float m0 = sqrtf(-2.0f * __logf(u0)), m1 = sqrtf(-2.0f * __logf(u2));
+    float s0, c0, s1, c1;
+    __sincosf(6.2831853071795864f * u1, &s0, &c0);
+    __sincosf(6.2831853071795864f * u3, &s1, &c1);
+    return make_float4(m0 * c0, m0 * s0, m1 * c1, m1 * s1);
+}
+
 // tanh of the head sums + bias, exploration noise, clamp (maddpg/networks.py:85, maddpg/agent.py:30-31) for ONE row.
-// Four normals via Philox + Box-Muller keyed by (seed, seq, row); optional Ornstein-Uhlenbeck state at ou_state[row]
-// (utils/noise.py:17-21), restarted from mu when `game_over` (main.py:155).  `store`: this lane owns a real row.
+// `row` indexes this launch's arrays (OU state, injected normals); `grow` = the job-wide row (env_offset + e)*A + a keys the
+// draws, so the noise a game sees does not depend on the sharding.  Optional Ornstein-Uhlenbeck state at ou_state[row]
+// (utils/noise.py:17-21), restarted from mu when `game_over` (main.py:155); with both processes on, the Gaussian term takes its
+// own draw (salt) -- the OU increment and the white term are independent.  `store`: this lane owns a real row.
 __device__ inline float4 finish_row(float4 r4, const float4 b3, const BsxActorNoise& nz, uint64_t seed, uint64_t seq,
-                                    size_t row, bool game_over, bool store) {
+                                    size_t row, uint64_t grow, bool game_over, bool store) {
 #pragma clang fp contract(fast)
     r4.x = tanhf(r4.x + b3.x); r4.y = tanhf(r4.y + b3.y); r4.z = tanhf(r4.z + b3.z); r4.w = tanhf(r4.w + b3.w);
     if (nz.gaussian_std > 0.f || nz.ou_scale > 0.f) {
-        const uint4 r = philox4x32_10(make_uint4(uint32_t(row), uint32_t(uint64_t(row) >> 32), uint32_t(seq), uint32_t(seq >> 32)),
-                                      make_uint2(uint32_t(seed), uint32_t(seed >> 32) ^ 0xA5A5A5A5u));
-        const float u0 = (float(r.x >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = float(r.y >> 8) * (1.0f / 16777216.0f);
-        const float u2 = (float(r.z >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = float(r.w >> 8) * (1.0f / 16777216.0f);
-        const float m0 = sqrtf(-2.0f * __logf(u0)), m1 = sqrtf(-2.0f * __logf(u2));
-        float s0, c0, s1, c1;
-        __sincosf(6.2831853071795864f * u1, &s0, &c0);
-        __sincosf(6.2831853071795864f * u3, &s1, &c1);
-        const float4 z = make_float4(m0 * c0, m0 * s0, m1 * c1, m1 * s1);
+        const float4 z = nz.z_inject ? reinterpret_cast<const float4*>(nz.z_inject)[row] : normals4(seed, seq, grow, 0u);
         if (nz.ou_scale > 0.f) {
             float4* xs = reinterpret_cast<float4*>(nz.ou_state) + row;
             float4 x = *xs;
@@ -119,8 +127,9 @@ __device__ inline float4 finish_row(float4 r4, const float4 b3, const BsxActorNo
             r4.z = fmaf(nz.ou_scale, x.z, r4.z); r4.w = fmaf(nz.ou_scale, x.w, r4.w);
         }
         if (nz.gaussian_std > 0.f) {
-            r4.x = fmaf(nz.gaussian_std, z.x, r4.x); r4.y = fmaf(nz.gaussian_std, z.y, r4.y);
-            r4.z = fmaf(nz.gaussian_std, z.z, r4.z); r4.w = fmaf(nz.gaussian_std, z.w, r4.w);
+            const float4 zg = (nz.ou_scale > 0.f && !nz.z_inject) ? normals4(seed, seq, grow, 0x80000000u) : z;
+            r4.x = fmaf(nz.gaussian_std, zg.x, r4.x); r4.y = fmaf(nz.gaussian_std, zg.y, r4.y);
+            r4.z = fmaf(nz.gaussian_std, zg.z, r4.z); r4.w = fmaf(nz.gaussian_std, zg.w, r4.w);
         }
         r4.x = fminf(fmaxf(r4.x, -1.f), 1.f); r4.y = fminf(fmaxf(r4.y, -1.f), 1.f);
         r4.z = fminf(fmaxf(r4.z, -1.f), 1.f); r4.w = fminf(fmaxf(r4.w, -1.f), 1.f);

@@ -62,6 +62,17 @@ __device__ unsigned long long* g_stamps = nullptr;
 #define STAMP(i) do { } while (0)
 #endif
 
+// Experiment switch (tools/build_variant.py -DBSX_X_NTSTORE): obs / rew / done leave with the non-temporal hint -- nothing on
+// the step path reads them back, so they need not stay (dirty) in the L2 until the end-of-kernel write-back.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+template <class T> __device__ inline void out_store(T* p, T v) {
+#ifdef BSX_X_NTSTORE
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 constexpr int FIELD_W = 1200, FIELD_H = 800;      // sprites.py:9-10
 constexpr int PLANE_HW = 25, PLANE_HH = 24;        // 50x48 sprite, half sizes (w>>1, h>>1)
 constexpr int PLANE_HP = 4;                        // battle_env.py:92
@@ -219,6 +230,7 @@ struct StepArgs {
     const void* actions; int action_kind;
     const double* u;
     float* obs; float* rew; uint8_t* done; uint8_t* env_done; uint8_t* winner;
+    uint8_t* env_done_t;                                 // MULTI: nullable [T][E], env_done after every tick
     BsxRewards cfg;
     uint32_t flags; uint64_t seed; int64_t env_offset; int tie_tick;
     // multi-tick launches (bsx_step_many_*): T ticks, per-tick strides of the action / output arrays (0 = same array every tick)
@@ -375,7 +387,8 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     __shared__ volatile int s_bhit_all[WAVES * SPB];     // base hits, index gl + shooter team
     __shared__ __attribute__((aligned(16))) float s_obs_all[WAVES * SPB * DROW];   // observation rows, [wave][lane][D]
     __shared__ __attribute__((aligned(16))) float s_small[ACTOR ? 2 * (N > 0 ? N : 1) * bsx_actor::SMALL : 4];   // per-neuron vectors + heads of the actors
-    __shared__ int s_act_all[(ACTOR && WAVES > 1) ? WAVES * SPB : 1];                // arg-max per row, ACTOR with several waves
+    __shared__ int s_act_all[(ACTOR && !CONT && WAVES > 1) ? WAVES * SPB : 1];       // arg-max per row, ACTOR with several waves
+    __shared__ float s_actf_all[(ACTOR && CONT && WAVES > 1) ? WAVES * SPB * 3 : 1];  // continuous: [speed, turn, shoot] per row
     __shared__ int s_gdone_all[(ACTOR && WAVES > 1) ? 32 : 1];                       // game-over flag per game of the workgroup
     // n >= 2: every plane-to-plane pair is computed ONCE, by one of its two planes, and handed to the other through these
     __shared__ float s_pd_all[(N >= 2) ? WAVES * SPB * N : 1];      // range (symmetric)
@@ -516,7 +529,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
 #pragma nounroll
         for (int ti = 0; ti < 2; ++ti) {                 // one tile at a time: its 64 weight registers are reused by the next
             const int ag = wave + ti * WAVES;            // wave-uniform
-            if (ag >= A_ || p.scripted_team == (ag >= N ? 1 : 0)) continue;   // no such plane / played by the scripted opponent
+            if (ag >= A_ || (!CONT && p.scripted_team == (ag >= N ? 1 : 0))) continue;   // no such plane / played by the scripted opponent
             const float* const Wn = p.aw + size_t(ag) * bsx_actor::blob_floats(D);
             const float* const smn = s_small + ag * bsx_actor::SMALL;
             auto xb = [&](int k) { return k < D ? s_obs_all[(c * G_ + ag) * D + k] : 0.f; };
@@ -532,24 +545,41 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         bool game_over;
         if (WAVES > 1) game_over = s_gdone_all[c] != 0;
         else game_over = __shfl(er.done, 2 * c) != 0;
-        if (p.scripted_team == (mine_c >= N ? 1 : 0)) {  // instinct/team.py:13-15 for this team's rows, as one-hot score rows
+        bool scripted_row = false;
+        if constexpr (!CONT) scripted_row = p.scripted_team == (mine_c >= N ? 1 : 0);
+        if (scripted_row) {                              // instinct/team.py:13-15 for this team's rows, as one-hot score rows
             double td_, ta_;
             r4 = one_hot_scores(instinct_choose([&](int k) { return s_obs_all[(c * G_ + mine_c) * D + k]; }, N, td_, ta_));
         } else {
-            r4 = bsx_actor::finish_row(r4, b3, p.nz, p.aseed, aseq, row, game_over, row_ok);
+            r4 = bsx_actor::finish_row(r4, b3, p.nz, p.aseed, aseq, row, uint64_t(p.env_offset) * uint64_t(A) + row, game_over, row_ok);
         }
         if (row_ok) reinterpret_cast<float4*>(p.scores + int64_t(tk) * p.scores_ts)[row] = r4;
-        const float v[4] = {r4.x, r4.y, r4.z, r4.w};
-        int am = 0;
+        if constexpr (!CONT) {
+            const float v[4] = {r4.x, r4.y, r4.z, r4.w};
+            int am = 0;
 #pragma unroll
-        for (int i = 1; i < 4; ++i)
-            if (!(v[am] != v[am]) && (v[i] > v[am] || v[i] != v[i])) am = i;
-        if (WAVES > 1) {                                 // plane (game, id) sits in lane game*G + id of the workgroup
-            if (has_row) s_act_all[c * G_ + mine] = am;
-            __syncthreads();
-            act = s_act_all[wave * SPB + tid];
+            for (int i = 1; i < 4; ++i)
+                if (!(v[am] != v[am]) && (v[i] > v[am] || v[i] != v[i])) am = i;
+            if (WAVES > 1) {                             // plane (game, id) sits in lane game*G + id of the workgroup
+                if (has_row) s_act_all[c * G_ + mine] = am;
+                __syncthreads();
+                act = s_act_all[wave * SPB + tid];
+            } else {
+                act = __shfl(am, ((lane & 1) << 5) | (lane >> 1));      // plane (game L>>1, agent L&1) <- lane 32*(L&1) + (L>>1)
+            }
         } else {
-            act = __shfl(am, ((lane & 1) << 5) | (lane >> 1));      // plane (game L>>1, agent L&1) <- lane 32*(L&1) + (L>>1)
+            // [speed, turn, shoot] of the row, as bsx_step_continuous reads a BSX_ACT_F32X4 row: float32 -> binary64
+            float f0, f1, f2;
+            if (WAVES > 1) {
+                if (has_row) { float* q = &s_actf_all[(c * G_ + mine) * 3]; q[0] = r4.x; q[1] = r4.y; q[2] = r4.z; }
+                __syncthreads();
+                const float* q = &s_actf_all[(wave * SPB + tid) * 3];
+                f0 = q[0]; f1 = q[1]; f2 = q[2];
+            } else {
+                const int src = ((lane & 1) << 5) | (lane >> 1);
+                f0 = __shfl(r4.x, src); f1 = __shfl(r4.y, src); f2 = __shfl(r4.z, src);
+            }
+            a0 = double(f0); a1 = double(f1); a2 = double(f2);
         }
     }
 
@@ -897,8 +927,8 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     if (valid) {
         if (MULTI ? last_tick : (mode == M_PHYS || mode == M_RESET))
             reinterpret_cast<uint4*>(p.st.plane)[gt] = pack_plane(x, y, live, hp, dir);
-        rew_t[gt] = float(rew);
-        done_t[gt] = er.done ? uint8_t(1) : uint8_t(alive ? 0 : 1);
+        out_store(&rew_t[gt], float(rew));
+        out_store(&done_t[gt], er.done ? uint8_t(1) : uint8_t(alive ? 0 : 1));
     }
     // observation row: a dead observer sees all -1, a dead enemy is [-1,-1,-1] (battle_env.py:215-218,235-242).
     // Rows are staged in LDS ([lane][D], D odd -> conflict-free) and leave as coalesced 16-byte stores: the wave's rows
@@ -935,7 +965,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
             float* gbase = obs_t + size_t(e_first) * A * D;
             for (int i = tid * 4; i < nfl; i += SPB * 4) {
                 if (i + 4 <= nfl) {
-                    *reinterpret_cast<float4*>(gbase + i) = *reinterpret_cast<const float4*>(&s_obs[i]);   // ds_read_b128
+                    out_store(reinterpret_cast<v4f_t*>(gbase + i), *reinterpret_cast<const v4f_t*>(&s_obs[i]));   // ds_read_b128
                 } else {
                     for (int t = i; t < nfl; ++t) gbase[t] = s_obs[t];
                 }
@@ -957,6 +987,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
                 if (p.env_done) p.env_done[e] = uint8_t(er.done);
                 if (p.winner) p.winner[e] = uint8_t(er.winner);
             }
+            if (MULTI && p.env_done_t) p.env_done_t[int64_t(tk) * E_ + e] = uint8_t(er.done);
         }
     }
     STAMP(7);
@@ -1136,7 +1167,7 @@ inline int grid_for(int64_t E, int n, int tpb = TPB) {
 template <bool CONT>
 int launch_step(void* state, int64_t E, int n, const void* actions, int action_kind, const double* u, float* obs,
                 float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner, const BsxRewards* cfg, uint32_t flags,
-                uint64_t seed, int64_t env_offset, void* stream, int T = 0, int store_all = 0) {
+                uint64_t seed, int64_t env_offset, void* stream, int T = 0, int store_all = 0, uint8_t* env_done_t = nullptr) {
     if (T < 0 || T > BSX_MAX_T) return BSX_E_ARG;
     if (!state || E <= 0 || E > BSX_MAX_E || n < 1 || n > BSX_MAX_N || !obs || !rew || !done || !cfg) return BSX_E_ARG;
     if (!actions && !(flags & BSX_F_EMPTY_CALL)) return BSX_E_ARG;
@@ -1148,10 +1179,10 @@ int launch_step(void* state, int64_t E, int n, const void* actions, int action_k
     StepArgs a;
     a.st = state_ptrs(state, E, n);
     a.E = E; a.n = n; a.actions = actions; a.action_kind = action_kind; a.u = u;
-    a.obs = obs; a.rew = rew; a.done = done; a.env_done = env_done; a.winner = winner;
+    a.obs = obs; a.rew = rew; a.done = done; a.env_done = env_done; a.winner = winner; a.env_done_t = env_done_t;
     a.cfg = *cfg; a.flags = flags; a.seed = seed; a.env_offset = env_offset; a.tie_tick = bsx_tie_tick(n);
     const int64_t EA = E * 2 * n;
-    a.aw = nullptr; a.aprec = 0; a.scripted_team = -1; a.obs0 = nullptr; a.scores = nullptr; a.scores_ts = 0; a.nz = BsxActorNoise{0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr};
+    a.aw = nullptr; a.aprec = 0; a.scripted_team = -1; a.obs0 = nullptr; a.scores = nullptr; a.scores_ts = 0; a.nz = BsxActorNoise{0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr};
     a.aseed = 0; a.aseq = 0; a.aseq_base = nullptr;
     a.T = T;
     a.act_tb = EA * (CONT ? (action_kind == BSX_ACT_F32 ? 12 : (action_kind == BSX_ACT_F64 ? 24 : 16)) : (action_kind == BSX_ACT_I32 ? 4 : 16));
@@ -1185,6 +1216,14 @@ int launch_step(void* state, int64_t E, int n, const void* actions, int action_k
 extern "C" {
 
 int bsx_abi_version(void) { return BSX_ABI_VERSION; }
+
+int bsx_build_flags(void) {
+#ifdef BSX_STAMPS
+    return int(DIAG & 0xFu) | 0x100;
+#else
+    return int(DIAG & 0xFu);
+#endif
+}
 
 int bsx_tie_tick(int n) {
     // battle_env.py:168,316-319: total_time += 0.1 (binary64) until >= 10 + 2n
@@ -1251,37 +1290,44 @@ int bsx_step_continuous(void* state, int64_t E, int n, const void* actions, int 
 }
 
 int bsx_step_many_discrete(void* state, int64_t E, int n, int T, const void* actions, int action_kind, const double* u,
-                           float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner, const BsxRewards* cfg,
+                           float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner, uint8_t* env_done_t, const BsxRewards* cfg,
                            uint32_t flags, int store_all, uint64_t seed, int64_t env_offset, void* stream) {
     if (T < 1 || !actions) return BSX_E_ARG;
     return launch_step<false>(state, E, n, actions, action_kind, u, obs, rew, done, env_done, winner, cfg, flags, seed,
-                              env_offset, stream, T, store_all);
+                              env_offset, stream, T, store_all, env_done_t);
 }
 
 int bsx_step_many_continuous(void* state, int64_t E, int n, int T, const void* actions, int action_kind, const double* u,
-                             float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner, const BsxRewards* cfg,
+                             float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner, uint8_t* env_done_t, const BsxRewards* cfg,
                              uint32_t flags, int store_all, uint64_t seed, int64_t env_offset, void* stream) {
     if (T < 1 || !actions) return BSX_E_ARG;
     return launch_step<true>(state, E, n, actions, action_kind, u, obs, rew, done, env_done, winner, cfg, flags, seed,
-                             env_offset, stream, T, store_all);
+                              env_offset, stream, T, store_all, env_done_t);
 }
 
-int bsx_rollout_discrete(void* state, int64_t E, int n, int T, const float* weights, int precision, int scripted_team, float* obs, float* scores, float* rew,
-                         uint8_t* done, uint8_t* env_done, uint8_t* winner, const BsxRewards* cfg, uint32_t flags,
-                         const BsxActorNoise* noise, uint64_t actor_seed, uint64_t seq, const uint64_t* seq_base, uint64_t seed,
-                         int64_t env_offset, void* stream) {
+}  // extern "C"
+
+namespace {
+// T x (actor -> step) in one launch; CONT = continuous actions (three actor outputs, BSX_ACT_F32X4 rows)
+template <bool CONT>
+int launch_rollout(void* state, int64_t E, int n, int T, const float* weights, int precision, int scripted_team, float* obs, float* scores, float* rew,
+                   uint8_t* done, uint8_t* env_done, uint8_t* winner, uint8_t* env_done_t, const BsxRewards* cfg, uint32_t flags,
+                   const BsxActorNoise* noise, uint64_t actor_seed, uint64_t seq, const uint64_t* seq_base, uint64_t seed,
+                   int64_t env_offset, void* stream) {
     if (!state || E <= 0 || E > BSX_MAX_E || n < 1 || n > 4 || T < 1 || T > BSX_MAX_T || !weights || !obs || !scores || !rew || !done || !cfg)
         return BSX_E_ARG;
     if ((flags & BSX_F_EMPTY_CALL) || (precision != BSX_ACTOR_F32 && precision != BSX_ACTOR_BF16X3) || scripted_team < -1 || scripted_team > 1) return BSX_E_ARG;
+    if (CONT && scripted_team != -1) return BSX_E_ARG;
     if (!aligned(state, 256) || !aligned(weights, 16) || !aligned(scores, 16) || !aligned(obs, 4) || !aligned(rew, 4)) return BSX_E_ALIGN;
-    BsxActorNoise nz = {0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr};
+    BsxActorNoise nz = {0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr};
     if (noise) nz = *noise;
     if (nz.ou_scale > 0.f && (!nz.ou_state || !aligned(nz.ou_state, 16))) return nz.ou_state ? BSX_E_ALIGN : BSX_E_ARG;
+    if (nz.z_inject) return BSX_E_ARG;                   // injected normals are per call: bsx_actor_forward only
     const int64_t EA = E * 2 * n, D = 3 * n + 2;
     StepArgs a;
     a.st = state_ptrs(state, E, n);
-    a.E = E; a.n = n; a.actions = nullptr; a.action_kind = BSX_ACT_LOGITS_F32; a.u = nullptr;
-    a.obs = obs + EA * D; a.rew = rew; a.done = done; a.env_done = env_done; a.winner = winner;
+    a.E = E; a.n = n; a.actions = nullptr; a.action_kind = CONT ? BSX_ACT_F32X4 : BSX_ACT_LOGITS_F32; a.u = nullptr;
+    a.obs = obs + EA * D; a.rew = rew; a.done = done; a.env_done = env_done; a.winner = winner; a.env_done_t = env_done_t;
     a.cfg = *cfg; a.flags = flags; a.seed = seed; a.env_offset = env_offset; a.tie_tick = bsx_tie_tick(n);
     a.T = T; a.act_tb = 0; a.u_ts = 0; a.obs_ts = EA * D; a.rew_ts = EA; a.done_ts = EA;
     a.aw = weights; a.aprec = precision; a.scripted_team = scripted_team; a.obs0 = obs; a.scores = scores; a.scores_ts = EA * 4; a.nz = nz; a.aseed = actor_seed; a.aseq = seq;
@@ -1289,12 +1335,31 @@ int bsx_rollout_discrete(void* state, int64_t E, int n, int T, const float* weig
     const dim3 grid(unsigned((E + 31) / 32));            // a workgroup = 32 games = G/2 waves
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (n) {
-        case 1: hipLaunchKernelGGL((bsx_step_kernel<1, false, true, true>), grid, dim3(SPB * 1), 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-        case 2: hipLaunchKernelGGL((bsx_step_kernel<2, false, true, true>), grid, dim3(SPB * 2), 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-        case 3: hipLaunchKernelGGL((bsx_step_kernel<3, false, true, true>), grid, dim3(SPB * 4), 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-        default: hipLaunchKernelGGL((bsx_step_kernel<4, false, true, true>), grid, dim3(SPB * 4), 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        case 1: hipLaunchKernelGGL((bsx_step_kernel<1, CONT, true, true>), grid, dim3(SPB * 1), 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        case 2: hipLaunchKernelGGL((bsx_step_kernel<2, CONT, true, true>), grid, dim3(SPB * 2), 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        case 3: hipLaunchKernelGGL((bsx_step_kernel<3, CONT, true, true>), grid, dim3(SPB * 4), 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        default: hipLaunchKernelGGL((bsx_step_kernel<4, CONT, true, true>), grid, dim3(SPB * 4), 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
     }
     return int(hipGetLastError());
+}
+}  // namespace
+
+extern "C" {
+
+int bsx_rollout_discrete(void* state, int64_t E, int n, int T, const float* weights, int precision, int scripted_team, float* obs, float* scores, float* rew,
+                         uint8_t* done, uint8_t* env_done, uint8_t* winner, uint8_t* env_done_t, const BsxRewards* cfg, uint32_t flags,
+                         const BsxActorNoise* noise, uint64_t actor_seed, uint64_t seq, const uint64_t* seq_base, uint64_t seed,
+                         int64_t env_offset, void* stream) {
+    return launch_rollout<false>(state, E, n, T, weights, precision, scripted_team, obs, scores, rew, done, env_done, winner, env_done_t, cfg, flags,
+                                 noise, actor_seed, seq, seq_base, seed, env_offset, stream);
+}
+
+int bsx_rollout_continuous(void* state, int64_t E, int n, int T, const float* weights, int precision, float* obs, float* scores, float* rew,
+                           uint8_t* done, uint8_t* env_done, uint8_t* winner, uint8_t* env_done_t, const BsxRewards* cfg, uint32_t flags,
+                           const BsxActorNoise* noise, uint64_t actor_seed, uint64_t seq, const uint64_t* seq_base, uint64_t seed,
+                           int64_t env_offset, void* stream) {
+    return launch_rollout<true>(state, E, n, T, weights, precision, -1, obs, scores, rew, done, env_done, winner, env_done_t, cfg, flags,
+                                noise, actor_seed, seq, seq_base, seed, env_offset, stream);
 }
 
 int bsx_observe(void* state, int64_t E, int n, float* obs, void* stream) {

@@ -325,13 +325,16 @@ class parallel_env:
             return self._obs.clone(), self._rew.clone(), self._done.view(torch.bool).clone()
         return self._obs, self._rew, self._done.view(torch.bool)
 
-    def _launch(self, act_ptr, kind, empty, u_ptr, obs_ptr, rew_ptr, done_ptr):
-        """Enqueue one fused step kernel on the current stream (no sync, no allocation: graph-capturable)."""
+    def _launch(self, act_ptr, kind, empty, u_ptr, obs_ptr, rew_ptr, done_ptr, env_done_ptr=None):
+        """Enqueue one fused step kernel on the current stream (no sync, no allocation: graph-capturable).
+        env_done_ptr: where this call's env_done [E] goes instead of the env-owned tensor (a rollout's per-tick record; the
+        caller copies the last one back into `self._env_done`)."""
         flags = (_lib.F_AUTO_RESET if self.auto_reset else 0) | (_lib.F_EMPTY_CALL if empty else 0)
         fn = self._lib.bsx_step_continuous if self.continuous_actions else self._lib.bsx_step_discrete
         with self._guard():
             _lib.check(fn(self._state.data_ptr(), self.n_envs, self.n_agents, act_ptr, kind, u_ptr,
-                          obs_ptr, rew_ptr, done_ptr, self._env_done.data_ptr(), self._winner.data_ptr(),
+                          obs_ptr, rew_ptr, done_ptr, env_done_ptr if env_done_ptr is not None else self._env_done.data_ptr(),
+                          self._winner.data_ptr(),
                           ctypes.byref(self._cfg), flags, self.seed, self.env_offset, self._stream()), "bsx_step")
 
     def _check_action_series(self, actions):
@@ -354,7 +357,7 @@ class parallel_env:
             raise ValueError(f"bad actions tensor for {T} calls: shape {tuple(actions.shape)}, dtype {actions.dtype}")
         return T, kind
 
-    def step_many(self, actions, store=False, out=None, u=None):
+    def step_many(self, actions, store=False, out=None, u=None, env_done_out=None):
         """T consecutive step() calls in ONE kernel launch (`for t: step(actions[t])` when all actions are known up
         front: random or scripted play, replays).  Results are those of T step_batch() calls, bit for bit; each
         wavefront walks its own games through the T ticks, so the state stays in the L2 between ticks instead of
@@ -364,7 +367,9 @@ class parallel_env:
         store:   False = obs/rew/done are the env-owned [E, A, ...] tensors and hold the last tick's results;
                  True  = new (or `out`) [T, E, A, ...] tensors hold every tick's results
         out:     optional (obs f32 [T,E,A,D], rew f32 [T,E,A], done uint8 [T,E,A]) to fill when store=True
-        u:       optional float64 [T, E, A] random() values for the shots (parity runs); needs rng='philox' otherwise"""
+        u:       optional float64 [T, E, A] random() values for the shots (parity runs); needs rng='philox' otherwise
+        env_done_out: optional uint8 [T, E] tensor that receives env_done after every tick (row t-1 set = call t found the game
+                 finished: the inert / re-spawn call of battle_env.py:303-306, not a transition)"""
         if self.rng != "philox" and u is None:
             raise ValueError("step_many needs rng='philox' (or injected u)")
         T, kind = self._check_action_series(actions)
@@ -390,11 +395,15 @@ class parallel_env:
             if self._u.shape != (T, E, A):
                 raise ValueError(f"u must have shape ({T}, {E}, {A})")
             u_ptr = self._u.data_ptr()
+        if env_done_out is not None and (env_done_out.shape != (T, E) or env_done_out.dtype != torch.uint8
+                                         or not env_done_out.is_contiguous() or env_done_out.device != self.device):
+            raise ValueError(f"env_done_out must be a contiguous uint8 [{T}, {E}] tensor on the env's device")
         flags = _lib.F_AUTO_RESET if self.auto_reset else 0
         fn = self._lib.bsx_step_many_continuous if self.continuous_actions else self._lib.bsx_step_many_discrete
         with self._guard():
             _lib.check(fn(self._state.data_ptr(), E, self.n_agents, T, actions.data_ptr(), kind, u_ptr, obs.data_ptr(),
                           rew.data_ptr(), done.data_ptr(), self._env_done.data_ptr(), self._winner.data_ptr(),
+                          env_done_out.data_ptr() if env_done_out is not None else None,
                           ctypes.byref(self._cfg), flags, 1 if store else 0, self.seed, self.env_offset, self._stream()),
                        "bsx_step_many")
         if self._mirror:
@@ -402,18 +411,25 @@ class parallel_env:
         return obs, rew, done.view(torch.bool)
 
     def _launch_rollout(self, T, weights_ptr, precision, scripted_team, obs_ptr, scores_ptr, rew_ptr, done_ptr, noise, actor_seed, seq,
-                        seq_base_ptr):
-        """Enqueue bsx_rollout_discrete: T ticks of (actor -> step) in one launch (used by rollout.PolicyRollout)."""
-        if self.continuous_actions or self.n_agents > 4:
-            raise ValueError("the one-launch rollout is built for discrete 1v1 ... 4v4")
+                        seq_base_ptr, env_done_t_ptr=None):
+        """Enqueue bsx_rollout_discrete / bsx_rollout_continuous: T ticks of (actor -> step) in one launch (rollout.PolicyRollout)."""
+        if self.n_agents > 4:
+            raise ValueError("the one-launch rollout is built for 1v1 ... 4v4")
         flags = _lib.F_AUTO_RESET if self.auto_reset else 0
+        common = (self._env_done.data_ptr(), self._winner.data_ptr(), env_done_t_ptr, ctypes.byref(self._cfg), flags,
+                  ctypes.byref(noise) if noise is not None else None, int(actor_seed), int(seq), seq_base_ptr, self.seed,
+                  self.env_offset, self._stream())
         with self._guard():
-            _lib.check(self._lib.bsx_rollout_discrete(
-                self._state.data_ptr(), self.n_envs, self.n_agents, int(T), weights_ptr, int(precision), int(scripted_team), obs_ptr, scores_ptr,
-                rew_ptr, done_ptr,
-                self._env_done.data_ptr(), self._winner.data_ptr(), ctypes.byref(self._cfg), flags,
-                ctypes.byref(noise) if noise is not None else None, int(actor_seed), int(seq), seq_base_ptr, self.seed,
-                self.env_offset, self._stream()), "bsx_rollout_discrete")
+            if self.continuous_actions:
+                if int(scripted_team) != -1:
+                    raise ValueError("no scripted opponent in the continuous one-launch rollout")
+                _lib.check(self._lib.bsx_rollout_continuous(self._state.data_ptr(), self.n_envs, self.n_agents, int(T), weights_ptr,
+                                                            int(precision), obs_ptr, scores_ptr, rew_ptr, done_ptr, *common),
+                           "bsx_rollout_continuous")
+            else:
+                _lib.check(self._lib.bsx_rollout_discrete(self._state.data_ptr(), self.n_envs, self.n_agents, int(T), weights_ptr,
+                                                          int(precision), int(scripted_team), obs_ptr, scores_ptr, rew_ptr, done_ptr,
+                                                          *common), "bsx_rollout_discrete")
 
     def capture_steps(self, actions, store=False):
         """Capture T consecutive step() launches into ONE HIP graph (the launch-bound inner loop of a rollout).
@@ -593,13 +609,36 @@ class parallel_env:
         return out
 
     def state_dict(self):
-        """Snapshot of the raw device state (the reference never checkpoints env state; here it is one tensor)."""
+        """Snapshot of the raw device state (the reference never checkpoints env state; here it is one tensor) plus what
+        identifies the job it belongs to."""
         return {"state": self._state.clone(), "env_done": self._env_done.clone(), "winner": self._winner.clone(),
-                "done": self._done.clone(), "reset_nonce": self._reset_nonce}
+                "done": self._done.clone(), "reset_nonce": self._reset_nonce,
+                "meta": {"abi": _lib.ABI_VERSION, "n_envs": self.n_envs, "n_agents": self.n_agents, "seed": self.seed,
+                         "env_offset": self.env_offset, "continuous_actions": self.continuous_actions}}
 
     def load_state_dict(self, sd):
+        """Restore a snapshot taken by `state_dict()` of an env of the same shape.  Host mirrors (drop-in / rng='python' mode:
+        alive flags, ticks, `dones`, `winner`) are rebuilt from the restored device state."""
+        meta = sd.get("meta")
+        if meta is not None:
+            mine = {"abi": _lib.ABI_VERSION, "n_envs": self.n_envs, "n_agents": self.n_agents,
+                    "continuous_actions": self.continuous_actions}
+            bad = {k: (meta.get(k), v) for k, v in mine.items() if meta.get(k) != v}
+            if bad:
+                raise ValueError(f"state_dict does not fit this env (saved, expected): {bad}")
+        if sd["state"].shape != self._state.shape:
+            raise ValueError(f"state block of {sd['state'].numel()} bytes does not fit this env ({self._state.numel()} bytes)")
         self._state.copy_(sd["state"]); self._env_done.copy_(sd["env_done"]); self._winner.copy_(sd["winner"])
         self._done.copy_(sd["done"]); self._reset_nonce = int(sd["reset_nonce"])
+        if self._mirror:
+            self._sync_mirror()
+        if self._compat:
+            # `dones` as step() would have left it: all True once the game is over (win()/tie() rebind the dict, :478,:494),
+            # else True for the planes that have died; `winner` from the restored code
+            d = self._done[0].cpu().numpy().astype(bool)
+            over = bool(self._h_done[0])
+            self.dones = {a: bool(over or d[i]) for i, a in enumerate(self.possible_agents)}
+            self._winner_name = _lib.WINNER_NAMES[int(self._winner[0])]
 
     # ------------------------------------------------------------------ rendering: out of scope (SURVEY.md section 2, rows 3-4)
     def render(self, mode="human"):

@@ -70,18 +70,30 @@ class ReplayBuffer:
                   obs_, torch.stack([col(dones, a) for a in self.agent_list], 1).bool())
 
     def store_rollout(self, rollout, columns):
-        """Append all T*E transitions of a PolicyRollout for the agents in `columns` (env column indices of this
-        team, e.g. range(n) for red), tick-major -- no host copy."""
+        """Append the transitions of a PolicyRollout for the agents in `columns` (env column indices of this team, e.g.
+        range(n) for red), tick-major, without a host copy of the data.  Only rows of RUNNING games are transitions
+        (`rollout.valid`): a tick on a finished game is the reference's inert call (battle_env.py:303-306) or, with
+        auto_reset, the re-spawn -- its row would pair the old game's last observation with the new game's first under
+        done=False, and the reference's loop (`while not env.env_done`, main.py:177-181) never stores such a row.
+        Returns the number of rows stored (one host sync: the count decides where the ring wraps)."""
         c = torch.as_tensor(list(columns), device=rollout.obs.device)
         T = rollout.T
-        flat = lambda x: x.index_select(2, c).reshape(-1, len(c), *x.shape[3:])   # noqa: E731
+        keep = rollout.valid.reshape(-1).nonzero().squeeze(1)                      # [R] indices into the T*E rows, tick-major
+        flat = lambda x: x.index_select(2, c).reshape(-1, len(c), *x.shape[3:]).index_select(0, keep)   # noqa: E731
         self._put(flat(rollout.obs[:T]), flat(rollout.scores)[..., :self.n_actions], flat(rollout.rew), flat(rollout.obs[1:T + 1]), flat(rollout.done))
+        return int(keep.numel())
 
-    def sample(self):
+    def sample(self, idx=None):
         """buffer.py:49-67 -> (actor_states [nA, B, obs], states [B, nA*obs], actions [nA, B, n_actions], rewards [B, nA],
-        actor_new_states [nA, B, obs], states_ [B, nA*obs], dones [B, nA]), all on the device."""
+        actor_new_states [nA, B, obs], states_ [B, nA*obs], dones [B, nA]), all on the device.
+        idx: optional row indices to return instead of drawing them (parity runs with the reference's np.random.choice draw)."""
         max_mem = min(self.mem_cntr, self.mem_size)
-        idx = torch.randint(0, max_mem, (self.batch_size,), device=self.actor_states.device, generator=self.generator)
+        if idx is None:
+            idx = torch.randint(0, max_mem, (self.batch_size,), device=self.actor_states.device, generator=self.generator)
+        else:
+            idx = torch.as_tensor(idx, device=self.actor_states.device).long()
+            if idx.shape != (self.batch_size,) or int(idx.max()) >= max_mem or int(idx.min()) < 0:
+                raise ValueError("idx must be batch_size indices into the filled rows")
         o, o_, a = self.actor_states[idx], self.actor_new_states[idx], self.action_mem[idx]
         B = self.batch_size
         return (o.transpose(0, 1), o.reshape(B, -1), a.transpose(0, 1), self.rew_mem[idx],

@@ -130,8 +130,10 @@ class FusedActor:
 
     PRECISIONS = {"f32": _lib.ACTOR_F32, "bf16x3": _lib.ACTOR_BF16X3}
 
-    def __init__(self, actor, n_agents_per_team, seed=0, precision="f32"):
-        self.actor, self.n = actor, int(n_agents_per_team)
+    def __init__(self, actor, n_agents_per_team, seed=0, precision="f32", env_offset=0):
+        """env_offset: global index of the shard's first game (sharding.make_shard): exploration noise is keyed by the GLOBAL row,
+        so a job's noise is the same however its games are split over ranks."""
+        self.actor, self.n, self.env_offset = actor, int(n_agents_per_team), int(env_offset)
         if precision not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
         self.precision = self.PRECISIONS[precision]
@@ -147,11 +149,16 @@ class FusedActor:
     def refresh(self):
         self.actor.pack(out=self.weights)
 
-    def noise_struct(self, E, noise_std=0.0, ou=None):
-        """BsxActorNoise for E games (None = no noise); validates the OU state tensor."""
+    def noise_struct(self, E, noise_std=0.0, ou=None, z=None):
+        """BsxActorNoise for E games (None = no noise); validates the OU state tensor.  z: optional float32 [E, A, 4] standard
+        normals to use instead of the in-kernel draws (parity runs against the reference's np.random.randn values)."""
         if not (noise_std > 0.0 or ou is not None):
             return None
-        nz = _lib.BsxActorNoise(float(noise_std), 0.0, 0.15, 0.2, 0.0, None, None)
+        nz = _lib.BsxActorNoise(float(noise_std), 0.0, 0.15, 0.2, 0.0, None, None, None)
+        if z is not None:
+            if z.dtype != torch.float32 or tuple(z.shape) != (E, 2 * self.n, 4) or not z.is_contiguous():
+                raise ValueError("z must be a contiguous float32 [E, A, 4] tensor")
+            nz.z_inject = z.data_ptr()
         if ou is not None:
             st = ou["state"]
             if st.dtype != torch.float32 or tuple(st.shape) != (E, 2 * self.n, 4) or not st.is_contiguous():
@@ -162,7 +169,7 @@ class FusedActor:
             nz.env_done = ou["env_done"].data_ptr() if ou.get("env_done") is not None else None
         return nz
 
-    def forward_into(self, obs, scores, noise_std=0.0, seq=None, seq_base=None, ou=None):
+    def forward_into(self, obs, scores, noise_std=0.0, seq=None, seq_base=None, ou=None, z=None):
         """obs f32 [E, A, D] (contiguous) -> scores f32 [E, A, 4] (contiguous, 16-byte aligned), on the current stream.
         noise_std: Gaussian exploration noise.  ou: optional dict(scale, state[, theta, sigma, mu, env_done]) for the
         reference's Ornstein-Uhlenbeck noise (utils/noise.py): `state` is a float32 [E, A, 4] tensor updated in place,
@@ -172,10 +179,10 @@ class FusedActor:
         if seq is None:
             self.seq += 1
             seq = self.seq
-        nz = self.noise_struct(E, noise_std, ou)
+        nz = self.noise_struct(E, noise_std, ou, z)
         _lib.check(self._lib.bsx_actor_forward(self.weights.data_ptr(), obs.data_ptr(), scores.data_ptr(), E, self.n, self.precision,
                                                _lib.ctypes.byref(nz) if nz is not None else None, self.seed, int(seq),
-                                               seq_base.data_ptr() if seq_base is not None else None,
+                                               seq_base.data_ptr() if seq_base is not None else None, self.env_offset,
                                                torch.cuda.current_stream(obs.device).cuda_stream), "bsx_actor_forward")
         return scores
 
@@ -191,6 +198,9 @@ class PolicyRollout:
         ro.start(); ro.capture()
         ro.run()                       # one replay = T ticks of every game
         ro.obs[t], ro.scores[t], ro.rew[t], ro.done[t], ro.obs[t+1]   # transition t, buffers in HBM
+        ro.valid[t]                    # bool [E]: tick t found the game running.  A tick on a FINISHED game is the reference's
+                                       # inert call (battle_env.py:303-306) or, with auto_reset, the re-spawn: its row pairs the old
+                                       # game's last observation with the new game's first and is not a transition
 
     The env must be batched, discrete, rng='philox'; auto_reset is recommended (finished games re-spawn in place).
     Exploration noise on the score vectors is Gaussian (noise_std) and/or the reference's Ornstein-Uhlenbeck process
@@ -211,7 +221,7 @@ class PolicyRollout:
         if self.continuous and opponent is not None:
             raise ValueError("the scripted opponent writes float64 [E, A, 3] actions: not combinable with the actor's rows")
         self.env, self.actor, self.T, self.noise_std = env, actor, int(T), float(noise_std)
-        self.fused = FusedActor(actor, env.n_agents, seed=seed, precision=precision) if fused else None
+        self.fused = FusedActor(actor, env.n_agents, seed=seed, precision=precision, env_offset=env.env_offset) if fused else None
         self.opponent = opponent
         # ou_scale > 0: the reference's Ornstein-Uhlenbeck exploration noise (utils/noise.py; main.py:151-155 scales it per
         # game and restarts it at every game start) -- fused path only; the process state is one more [E, A, 4] tensor
@@ -219,14 +229,14 @@ class PolicyRollout:
         if ou_scale > 0.0:
             if not fused:
                 raise ValueError("ou_scale needs the fused actor")
-            self.ou = dict(scale=float(ou_scale), env_done=env._env_done,
+            self.ou = dict(scale=float(ou_scale),
                            state=torch.zeros((env.n_envs, env._A, 4), dtype=torch.float32, device=env.device))
-        # one_launch: all T ticks (actor -> step) in ONE kernel (bsx_rollout_discrete) instead of 2T launches in a graph:
-        # observation rows stay in LDS between the step and the actor, game state in registers / L2.  Discrete, up to 4v4; a scripted
-        # opponent (instinct.Team of one side) is played in-kernel and its actor is skipped; same transitions, bit for bit.
+        # one_launch: all T ticks (actor -> step) in ONE kernel (bsx_rollout_discrete / _continuous) instead of 2T launches in a
+        # graph: observation rows stay in LDS between the step and the actor, game state in registers / L2.  Up to 4v4; discrete: a
+        # scripted opponent (instinct.Team of one side) is played in-kernel and its actor is skipped; same transitions, bit for bit.
         self.one_launch = bool(one_launch)
-        if self.one_launch and (not fused or env.n_agents > 4 or env.continuous_actions):
-            raise ValueError("one_launch needs the fused actor and a discrete env of 1v1 ... 4v4")
+        if self.one_launch and (not fused or env.n_agents > 4):
+            raise ValueError("one_launch needs the fused actor and an env of 1v1 ... 4v4")
         if self.one_launch and opponent is not None and getattr(opponent, "team", None) not in (0, 1):
             raise ValueError("one_launch plays a scripted opponent in-kernel: it must be an instinct.Team of one side")
         self._seq_base = torch.zeros(1, dtype=torch.int64, device=env.device)
@@ -238,17 +248,27 @@ class PolicyRollout:
         self.rew = torch.empty((T, E, A), dtype=torch.float32, device=dev)
         self._done = torch.empty((T, E, A), dtype=torch.uint8, device=dev)
         self.done = self._done.view(torch.bool)
+        # env_done[t] = the games' env_done BEFORE tick t (row 0: when the rollout starts; row t+1 is written by tick t)
+        self.env_done = torch.ones((T + 1, E), dtype=torch.uint8, device=dev)
         self.graph = None
+
+    @property
+    def valid(self):
+        """bool [T, E]: tick t started on a running game, i.e. row t of that game is a transition of the reference's loop
+        (`while not env.env_done: step`, main.py:177-181)."""
+        return self.env_done[:self.T] == 0
 
     def _tick(self, t):
         if self.fused is not None:
             # graph arguments are frozen: the noise key is (seed, seq_base + t, row) with seq_base a device word that the
             # graph advances by T once per replay (_body)
-            self.fused.forward_into(self.obs[t], self.scores[t], self.noise_std, seq=t, seq_base=self._seq_base, ou=self.ou)
+            ou = dict(self.ou, env_done=self.env_done[t]) if self.ou is not None else None
+            self.fused.forward_into(self.obs[t], self.scores[t], self.noise_std, seq=t, seq_base=self._seq_base, ou=ou)
             if self.opponent is not None:
                 self.opponent.write_actions(out=self.scores[t], obs=self.obs[t])
             self.env._launch(self.scores[t].data_ptr(), self._kind, False, None,
-                             self.obs[t + 1].data_ptr(), self.rew[t].data_ptr(), self._done[t].data_ptr())
+                             self.obs[t + 1].data_ptr(), self.rew[t].data_ptr(), self._done[t].data_ptr(),
+                             env_done_ptr=self.env_done[t + 1].data_ptr())
             return
         with torch.no_grad():
             s = self.actor(self.obs[t])
@@ -258,11 +278,13 @@ class PolicyRollout:
         if self.opponent is not None:
             self.opponent.write_actions(out=self.scores[t], obs=self.obs[t])
         self.env._launch(self.scores[t].data_ptr(), self._kind, False, None,
-                         self.obs[t + 1].data_ptr(), self.rew[t].data_ptr(), self._done[t].data_ptr())
+                         self.obs[t + 1].data_ptr(), self.rew[t].data_ptr(), self._done[t].data_ptr(),
+                         env_done_ptr=self.env_done[t + 1].data_ptr())
 
     def start(self):
         """Begin from the env's current observations (call after env.reset())."""
         self.obs[self.T].copy_(self.env._obs)          # every run starts by moving obs[T] to obs[0]
+        self.env_done[self.T].copy_(self.env._env_done)
 
     def capture(self):
         """Record the T ticks into a HIP graph (one warm-up pass runs first, on a side stream, as torch requires)."""
@@ -280,14 +302,17 @@ class PolicyRollout:
 
     def _body(self):
         self.obs[0].copy_(self.obs[self.T])            # continue where the previous rollout ended
+        self.env_done[0].copy_(self.env_done[self.T])
         if self.one_launch:
             nz = self.fused.noise_struct(self.env.n_envs, self.noise_std, self.ou)
             self.env._launch_rollout(self.T, self.fused.weights.data_ptr(), self.fused.precision,
                                      -1 if self.opponent is None else self.opponent.team, self.obs.data_ptr(), self.scores.data_ptr(),
-                                     self.rew.data_ptr(), self._done.data_ptr(), nz, self.fused.seed, 0, self._seq_base.data_ptr())
+                                     self.rew.data_ptr(), self._done.data_ptr(), nz, self.fused.seed, 0, self._seq_base.data_ptr(),
+                                     env_done_t_ptr=self.env_done[1].data_ptr())
         else:
             for t in range(self.T):
                 self._tick(t)
+            self.env._env_done.copy_(self.env_done[self.T])        # the per-tick launches wrote their flags into the record
         self._seq_base.add_(self.T)                    # fresh exploration-noise keys for the next run
 
     def run(self):

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define BSX_ABI_VERSION 8
+#define BSX_ABI_VERSION 9
 #define BSX_BULLET_SLOTS 12 /* a bullet is removed at the latest on its 12th update (sprites.py:334-337: 12*45 >= 500) */
 #define BSX_MAX_N 16
 #define BSX_MAX_E (INT64_C(1) << 30)   /* games per call: keeps every grid below 2^31 workgroups; 2^30 games of 1v1 is ~0.8 TB of state */
@@ -60,6 +60,11 @@ typedef struct BsxRewards {
 #define BSX_ACT_F32X4 2      /* float32 [E*A*4], 16-byte aligned: speed, turn, shoot + one ignored float -- the 4-wide rows bsx_actor_forward writes */
 
 int bsx_abi_version(void);
+
+/* 0 for the product build.  Non-zero = a diagnostic build whose RESULTS ARE NOT THE REFERENCE'S (timing ablations compiled
+ * with -DBSX_DIAG=<bits>: bits 0-3; in-kernel phase stamps -DBSX_STAMPS: bit 8).  A binding must refuse such a library
+ * unless the caller asked for it explicitly (deep-rl-battlespace_amd/_lib.py: BSX_ALLOW_DIAG=1). */
+int bsx_build_flags(void);
 
 /* Size in bytes of the opaque per-job state block for E envs of n-per-team (256-byte aligned base required).
  * Holds what parallel_env holds between calls (battle_env.py:165-184,254-276): planes, bases, bullets, time, flags,
@@ -102,15 +107,17 @@ int bsx_step_continuous(void* state, int64_t E, int n, const void* actions, int 
  * of bsx_step_discrete / bsx_step_continuous, bit for bit; arrays gain a leading T axis: actions [T][E*A] (or [T][E*A*4],
  * [T][E*A*3]), u [T][E*A] (nullable).  store_all != 0: obs [T][E*A*D], rew [T][E*A], done [T][E*A] hold every call's
  * results; store_all == 0: obs / rew / done are [E*A...] and hold the LAST call's (each call still writes them).
- * env_done / winner (nullable, [E]) are the state after the last call.  1 <= T <= BSX_MAX_T.
- * A wavefront walks its games through the T calls, so between calls the state stays in the L2. */
+ * env_done / winner (nullable, [E]) are the state after the last call; env_done_t (nullable, uint8 [T][E]) receives env_done
+ * after EVERY call, so a consumer can tell which of the T rows of a game belong to a running game (a call on a finished game is
+ * the reference's inert call, battle_env.py:303-306, or -- with BSX_F_AUTO_RESET -- the re-spawn: neither is a transition).
+ * 1 <= T <= BSX_MAX_T.  A wavefront walks its games through the T calls, so between calls the state stays in the L2. */
 #define BSX_MAX_T 65535
 int bsx_step_many_discrete(void* state, int64_t E, int n, int T, const void* actions, int action_kind, const double* u,
-                           float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner,
+                           float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner, uint8_t* env_done_t,
                            const BsxRewards* cfg, uint32_t flags, int store_all, uint64_t seed, int64_t env_offset,
                            void* stream);
 int bsx_step_many_continuous(void* state, int64_t E, int n, int T, const void* actions, int action_kind, const double* u,
-                             float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner,
+                             float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner, uint8_t* env_done_t,
                              const BsxRewards* cfg, uint32_t flags, int store_all, uint64_t seed, int64_t env_offset,
                              void* stream);
 
@@ -147,14 +154,19 @@ int bsx_export_state(const void* state, int64_t E, int n, const BsxExport* out, 
  *            bsx_step_discrete with BSX_ACT_LOGITS_F32.
  *   noise    nullable.  Exploration noise added to the tanh outputs, then clamp(-1, 1) (maddpg/agent.py:30-31): Gaussian
  *            and/or the reference's Ornstein-Uhlenbeck process (utils/noise.py:4-21).  Normal draws are Philox-keyed by
- *            (seed, seq + *seq_base, row): pass a new seq per call, or -- inside a captured HIP graph, whose arguments are
- *            frozen -- a device word seq_base (nullable) that the graph itself advances once per replay. */
+ *            (seed, seq + *seq_base, GLOBAL row (env_offset + e)*A + a), so a job's noise does not depend on how its games are
+ *            sharded; the Gaussian term takes a second, independent draw when both processes are on.  Pass a new seq per call,
+ *            or -- inside a captured HIP graph, whose arguments are frozen -- a device word seq_base (nullable) that the graph
+ *            itself advances once per replay.  z_inject replaces the draws by the caller's normals (parity runs against
+ *            utils/noise.py with the reference's own np.random.randn values). */
 typedef struct BsxActorNoise {
     float gaussian_std;       /* > 0: scores += N(0, gaussian_std) */
     float ou_scale;           /* > 0: x += ou_theta*(ou_mu - x) + ou_sigma*N(0,1);  scores += ou_scale * x   (utils/noise.py:17-21) */
     float ou_theta, ou_sigma, ou_mu;   /* reference defaults 0.15, 0.2, 0 */
     float* ou_state;          /* float32[E*A*4] process state x, required when ou_scale > 0 */
     const uint8_t* env_done;  /* nullable uint8[E]: rows of finished games restart from ou_mu (main.py:155 reset_noise per game) */
+    const float* z_inject;    /* nullable float32[E*A*4], 16-byte aligned: standard normals to use instead of the Philox draws
+                                 (bsx_actor_forward only; one set per call, used by the OU and the Gaussian term alike) */
 } BsxActorNoise;
 /* precision of the 64 x 64 layer: exact float32 (an fmaf chain, bit for bit), or both operands split in two bf16 terms and
  * three bf16 matrix products accumulated in float32 (about 1e-5 on a score; 16x the matrix rate).  All else is float32. */
@@ -162,7 +174,8 @@ typedef struct BsxActorNoise {
 #define BSX_ACTOR_BF16X3 1
 int bsx_actor_blob_floats(int obs_len, int* floats_per_agent);
 int bsx_actor_forward(const float* weights, const float* obs, float* scores, int64_t E, int n, int precision,
-                      const BsxActorNoise* noise, uint64_t seed, uint64_t seq, const uint64_t* seq_base, void* stream);
+                      const BsxActorNoise* noise, uint64_t seed, uint64_t seq, const uint64_t* seq_base, int64_t env_offset,
+                      void* stream);
 
 /* The caller's rollout loop -- `for t in range(T): actions = actor(obs) (+ noise, clamp); obs, rew, done = step(actions)`
  * (main.py:177-181 with maddpg/agent.py:25-33) -- in ONE launch: T x (bsx_actor_forward -> bsx_step_discrete with
@@ -170,7 +183,8 @@ int bsx_actor_forward(const float* weights, const float* obs, float* scores, int
  * them, the actor's MFMA reads them), their state in registers / L2, and walks them through all T ticks.
  *   obs     float32 [T+1][E*A*D]: obs[0] = the observations to start from (in), obs[t+1] = after tick t (out)
  *   scores  float32 [T][E*A*4] (out, 16-byte aligned): what the actors produced = the actions taken
- *   rew     float32 [T][E*A], done uint8 [T][E*A] (out); env_done / winner (nullable, [E]): state after the last tick
+ *   rew     float32 [T][E*A], done uint8 [T][E*A] (out); env_done / winner (nullable, [E]): state after the last tick;
+ *           env_done_t (nullable, uint8 [T][E]): env_done after every tick (which rows are transitions: see bsx_step_many_*)
  *   scripted_team  -1: both teams act by their actors; 0 / 1: the red / blue planes are played by the scripted opponent
  *            (bsx_instinct_discrete, instinct/agent.py:10-62) -- the reference's training setup, main.py:119-122 -- their actor
  *            is not evaluated, their score rows are the one-hot rows bsx_instinct_discrete writes, no noise
@@ -180,9 +194,17 @@ int bsx_actor_forward(const float* weights, const float* obs, float* scores, int
  * exactly two tiles; 2v2: two waves; 3v3 / 4v4: four) that exchange observation rows and arg-maxes through LDS.  Larger teams
  * return BSX_E_ARG -- use the per-tick form. */
 int bsx_rollout_discrete(void* state, int64_t E, int n, int T, const float* weights, int precision, int scripted_team, float* obs, float* scores, float* rew,
-                         uint8_t* done, uint8_t* env_done, uint8_t* winner, const BsxRewards* cfg, uint32_t flags,
+                         uint8_t* done, uint8_t* env_done, uint8_t* winner, uint8_t* env_done_t, const BsxRewards* cfg, uint32_t flags,
                          const BsxActorNoise* noise, uint64_t actor_seed, uint64_t seq, const uint64_t* seq_base,
                          uint64_t seed, int64_t env_offset, void* stream);
+/* The same loop for a continuous-action env (battle_env.py:295-297,418-424; the reference's own driver test_env.py:22-43 is
+ * continuous): T x (bsx_actor_forward -> bsx_step_continuous with BSX_ACT_F32X4), bit for bit.  The actors have three outputs
+ * [speed, turn, shoot] padded to the 4-wide rows (`scores` [T][E*A*4]: what was fed to the step; the fourth value is ignored).
+ * No scripted opponent here: the reference's continuous instinct agent draws float64 actions with its own noise. */
+int bsx_rollout_continuous(void* state, int64_t E, int n, int T, const float* weights, int precision, float* obs, float* scores, float* rew,
+                           uint8_t* done, uint8_t* env_done, uint8_t* winner, uint8_t* env_done_t, const BsxRewards* cfg, uint32_t flags,
+                           const BsxActorNoise* noise, uint64_t actor_seed, uint64_t seq, const uint64_t* seq_base,
+                           uint64_t seed, int64_t env_offset, void* stream);
 
 /* ---- the reference's scripted opponent on device (instinct/agent.py:10-62, instinct/team.py:3-15): a pure function of
  * the observation rows.  Writes ONLY the rows of `team` (0 red, 1 blue, 2 both) so a learned policy can fill the others

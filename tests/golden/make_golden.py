@@ -45,6 +45,8 @@ from collections import deque
 
 import numpy as np
 
+sys.dont_write_bytecode = True          # nothing is ever written under /root/reference (read-only study material)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference"
 K = 12  # bullet slots per shooter (a bullet lives at most 12 updates: 12*45 >= 500)
@@ -615,9 +617,92 @@ def actor_fixture():
     print("g9_actor_forward:", sorted(out)[:6], "...")
 
 
+def learner_side_fixture():
+    """G10 / G11: the two numpy-only pieces next to the step path that the rollout feeds (SURVEY.md section 8f-3 and the OU
+    exploration noise of the caller's loop), run UNMODIFIED from /root/reference:
+      g10  maddpg/buffer.py ReplayBuffer -- store_transition layouts after a partial fill and after the ring wrapped, and what
+           sample() returns for the indices np.random.choice drew (recorded by wrapping that numpy function);
+      g11  utils/noise.py OUNoise -- a trajectory of noise() values and process states for recorded np.random.randn draws,
+           with a reset() (main.py:155 restarts the process per game) and a re-scale (main.py:154) on the way."""
+    sys.path[:0] = [REF]
+    import maddpg.buffer as rbuf
+    import utils.noise as rnoise
+    rng = np.random.default_rng(10)
+    out = {}
+    agents, obs_size, n_act, M, B = ["plane0", "plane1"], 8, 4, 6, 5              # the red team of a 2v2 game (main.py:113-118)
+    buf = rbuf.ReplayBuffer(M, B, agents, obs_size, obs_size * len(agents), n_act)
+    S = 10                                                                          # > M: rows 0..3 are overwritten
+    tr = dict(states=rng.uniform(-1, 1, (S, 2, obs_size)).astype(np.float32), actions=rng.uniform(-1, 1, (S, 2, n_act)).astype(np.float32),
+              rewards=rng.integers(-20, 100, (S, 2)).astype(np.float64), states_=rng.uniform(-1, 1, (S, 2, obs_size)).astype(np.float32),
+              dones=rng.random((S, 2)) < 0.3)
+    picks = []
+    real_choice = np.random.choice
+
+    def choice_tap(a, size=None, *args, **kw):
+        r = real_choice(a, size, *args, **kw)
+        picks.append(np.asarray(r).copy())
+        return r
+
+    def snap(tag):
+        for k in ("state_mem", "new_state_mem", "rew_mem", "done_mem"):
+            out[f"{tag}/{k}"] = getattr(buf, k).copy()
+        for k in ("actor_states", "actor_new_states", "action_mem"):
+            out[f"{tag}/{k}"] = np.stack(getattr(buf, k)).copy()                   # [agent, M, ...]
+        out[f"{tag}/mem_cntr"] = np.int64(buf.mem_cntr)
+        out[f"{tag}/is_ready"] = np.bool_(buf.is_ready())
+        if buf.is_ready():
+            np.random.seed(100 + buf.mem_cntr)
+            np.random.choice = choice_tap
+            try:
+                res = buf.sample()
+            finally:
+                np.random.choice = real_choice
+            out[f"{tag}/idx"] = picks[-1].astype(np.int64)
+            for name, v in zip(("actor_states", "states", "actions", "rewards", "actor_new_states", "states_", "dones"), res):
+                out[f"{tag}/sample/{name}"] = np.asarray(v).copy()
+    for k in range(S):
+        d = lambda key: {a: tr[key][k, i] for i, a in enumerate(agents)}            # noqa: E731
+        buf.store_transition(d("states"), d("actions"), d("rewards"), d("states_"), d("dones"))
+        if k + 1 in (3, 5, S):
+            snap(f"after{k + 1}")
+    for k, v in tr.items():
+        out[f"in/{k}"] = v
+    out["cfg"] = np.asarray([M, B, obs_size, n_act, len(agents)], np.int64)
+    np.savez_compressed(os.path.join(HERE, "g10_replay_buffer.npz"), **out)
+    print("g10_replay_buffer:", len(out), "arrays; sampled idx", [p.tolist() for p in picks])
+
+    zs = []
+    real_randn = np.random.randn
+
+    def randn_tap(*shape):
+        z = real_randn(*shape)
+        zs.append(np.asarray(z, np.float64).copy())
+        return z
+    np.random.seed(11)
+    np.random.randn = randn_tap
+    try:
+        ou = rnoise.OUNoise(4)                                                      # maddpg/agent.py:15
+        vals, states, events = [], [], []
+        for t in range(40):
+            if t == 13:
+                ou.reset(); events.append((t, 1, 0.0))                             # reset_noise per game (main.py:155)
+            if t == 20:
+                ou.scale = 0.37; events.append((t, 2, 0.37))                       # scale_noise (main.py:154)
+            vals.append(np.asarray(ou.noise(), np.float64).copy())
+            states.append(np.asarray(ou.state, np.float64).copy())
+    finally:
+        np.random.randn = real_randn
+    np.savez_compressed(os.path.join(HERE, "g11_ou_noise.npz"), z=np.stack(zs), noise=np.stack(vals), state=np.stack(states),
+                        events=np.asarray(events, np.float64), params=np.asarray([0.1, 0.0, 0.15, 0.2]))   # scale0, mu, theta, sigma
+    print("g11_ou_noise:", np.stack(vals).shape, "last", vals[-1])
+
+
 if __name__ == "__main__":
     if "--actor-only" in sys.argv:
         actor_fixture()
+        sys.exit(0)
+    if "--learner-side-only" in sys.argv:
+        learner_side_fixture()
         sys.exit(0)
     cwd = os.getcwd()
     try:
@@ -626,3 +711,4 @@ if __name__ == "__main__":
         os.chdir(cwd)
     if "--instinct-only" not in sys.argv:
         actor_fixture()
+        learner_side_fixture()

@@ -112,14 +112,16 @@ def test_largest_batch_offsets_past_4GB_play_the_same_games():
     for t in range(T):
         tail = torch.randint(0, 4, (q, 2), generator=g, device="cuda", dtype=torch.int32)
         tail = torch.where(torch.rand((q, 2), generator=g, device="cuda") < 0.6, torch.ones_like(tail), tail)
-        act.fill_(1); act[E - q:] = tail                       # everyone else just shoots
+        act.fill_(2 if t % 4 == 0 else 1); act[E - q:] = tail   # everyone else: three shots, one turn (planes circle instead of parking on a wall)
         o1, r1, d1 = big.step_batch(act)
         o2, r2, d2 = small.step_batch(tail)
         assert torch.equal(o1[E - q:], o2) and torch.equal(r1[E - q:], r2) and torch.equal(d1[E - q:], d2), f"step {t}"
     s1 = big.export_state(); s2 = small.export_state()
     for f in ("px", "py", "pdir", "php", "bhp", "tick", "bl_live", "bl_x", "bl_y", "bl_dir", "counters"):
         assert torch.equal(s1[f][E - q:], s2[f]), f
-    assert int(s1["bl_live"].sum()) > E // 8                      # bullets in flight all over the batch, not only in the tail
+    # bullets in flight all over the batch, not only in the tail: this schedule holds 3.8 live bullets per plane after 70 calls
+    # (measured with the C oracle on 8 192 games, same seed); ask for 2.5
+    assert int(s1["bl_live"].sum()) > 2.5 * 2 * E
 
 
 def test_state_invariants_at_full_size():
@@ -396,11 +398,16 @@ def test_fused_actor_ou_noise_follows_the_reference_process():
     want = torch.where(done.bool()[:, None, None], torch.full_like(prev, 0.25), prev)
     want = want + 0.5 * (0.25 - want) + 0.1 * z
     torch.testing.assert_close(st, want, rtol=1e-5, atol=1e-6)
-    # Gaussian and OU may be combined; a missing state tensor is refused
-    g = torch.empty_like(base); fused.forward_into(obs, g, 0.25, seq=3)
+    # Gaussian and OU may be combined: the OU increment keeps its draw, the white term takes a second, independent one
     both = torch.empty_like(base); st2 = torch.zeros_like(st)
     fused.forward_into(obs, both, 0.25, seq=3, ou=dict(scale=scale, state=st2))
-    torch.testing.assert_close(both, (base + scale * x1 + 0.25 * z).clamp(-1, 1), rtol=0, atol=2e-6)
+    assert torch.equal(st2, x1)
+    zg = (both - (base + scale * x1)) / 0.25
+    inside = (both.abs() < 0.999)
+    assert abs(float(zg[inside].mean())) < 0.02 and abs(float(zg[inside].std()) - 1.0) < 0.05
+    corr = float(torch.corrcoef(torch.stack([zg[inside], z[inside]]))[0, 1])
+    assert abs(corr) < 0.01, corr                                # not the OU process's normals again
+    # a missing state tensor is refused
     with pytest.raises(ValueError):
         fused.forward_into(obs, out, 0.0, seq=3, ou=dict(scale=scale, state=st[:10]))
 
@@ -495,8 +502,10 @@ def test_continuous_policy_rollout(fused):
         torch.testing.assert_close(got[..., :3], want, rtol=0, atol=2e-5)
         assert float(got[..., 3].abs().max()) == 0.0
     buf = ReplayBuffer(100000, 64, env.possible_red, env.obs_size, env.obs_size * n, 3, device="cuda")
-    buf.store_rollout(ro, range(n))
-    assert buf.mem_cntr == T * E and torch.equal(buf.action_mem[5], ro.scores[0, 5, :n, :3])
+    stored = buf.store_rollout(ro, range(n))
+    keep = ro.valid.reshape(-1).nonzero().squeeze(1)
+    assert stored == buf.mem_cntr == int(ro.valid.sum()) and 0 < stored <= T * E
+    k5 = int(keep[5]); assert torch.equal(buf.action_mem[5], ro.scores[k5 // E, k5 % E, :n, :3])
     with pytest.raises(ValueError):
         PolicyRollout(env, StackedActor(A, D, 4, device="cuda"), T)                 # discrete head on a continuous env
 
@@ -527,32 +536,54 @@ def test_one_launch_rollout_tiny_and_ragged_batches(E, n):
 
 
 def test_rollout_into_replay_buffer_on_device():
-    """f-1 -> f-3: a rollout's transitions go into the device replay ring without touching the host; a sampled batch is
-    self-consistent (next-state of a stored row is the state the env produced one tick later)."""
+    """f-1 -> f-3: a rollout's transitions go into the device replay ring without a host copy of the data, and ONLY transitions
+    do: a tick that found its game finished -- the auto-reset call, whose row would pair the old game's last observation with
+    the new game's first under done=False -- is not stored (the reference's loop never produces one: `while not env.env_done`,
+    main.py:177-181).  Checked row by row against the rollout's own record of env_done before every tick."""
     from deep_rl_battlespace_amd.replay import ReplayBuffer
     from deep_rl_battlespace_amd.rollout import PolicyRollout, StackedActor
+    from deep_rl_battlespace_amd import instinct
     E, n, T = 512, 2, 16
-    env = _env(n_agents=n, n_envs=E, seed=5, auto_reset=True); env.reset()
-    actor = StackedActor(2 * n, 3 * n + 2, 4, device="cuda")
-    with torch.no_grad():
-        actor.w3.mul_(100.0)
-    ro = PolicyRollout(env, actor, T, noise_std=0.2); ro.start(); ro.capture()
-    buf = ReplayBuffer(20000, 256, env.possible_red, env.obs_size, env.obs_size * n, 4, device="cuda")
-    for rep in range(3):
-        ro.run()
-        buf.store_rollout(ro, range(n))
-    torch.cuda.synchronize()
-    assert buf.mem_cntr == 3 * T * E and buf.is_ready()
-    # rows of the LAST rollout sit at the ring positions mem_cntr - T*E ... (tick-major): check a few against the buffers
-    base = (buf.mem_cntr - T * E) % buf.mem_size
-    for t, e in ((0, 0), (3, 17), (T - 1, E - 1)):
-        row = (base + t * E + e) % buf.mem_size
-        assert torch.equal(buf.actor_states[row], ro.obs[t, e, :n]) and torch.equal(buf.actor_new_states[row], ro.obs[t + 1, e, :n])
-        assert torch.equal(buf.action_mem[row], ro.scores[t, e, :n]) and torch.equal(buf.rew_mem[row], ro.rew[t, e, :n])
-        assert torch.equal(buf.done_mem[row], ro.done[t, e, :n])
-    a_s, s, a, r, a_s2, s2, d = buf.sample()
-    assert s.shape == (256, n * env.obs_size) and a.shape == (n, 256, 4) and d.dtype == torch.bool
-    assert float(a.abs().max()) <= 1.0
+    for one_launch in (False, True):
+        env = _env(n_agents=n, n_envs=E, seed=5, auto_reset=True); env.reset()
+        actor = StackedActor(2 * n, 3 * n + 2, 4, device="cuda")
+        with torch.no_grad():
+            actor.w3.mul_(100.0)
+        # the scripted opponent makes games decisive early, so game ends (and re-spawns) fall inside these few ticks
+        ro = PolicyRollout(env, actor, T, noise_std=0.2, one_launch=one_launch, opponent=instinct.Team(env.possible_blue, env.possible_red, env))
+        ro.start(); ro.capture()
+        buf = ReplayBuffer(40000, 256, env.possible_red, env.obs_size, env.obs_size * n, 4, device="cuda")
+        total, dropped, ends = 0, 0, 0
+        for rep in range(12):
+            ro.run()
+            edone = ro.env_done.clone()
+            # the record is env_done BEFORE each tick: row t+1 follows from tick t's dones, and a finished game is re-spawned by
+            # the very next tick (auto_reset), so two consecutive set rows never occur
+            assert bool(ro.done[edone[1:] != 0].all())           # a finished game reports every plane done
+            assert not bool(((edone[:-1] != 0) & (edone[1:] != 0)).any())
+            reset_rows = edone[:T] != 0
+            assert float(ro.rew[reset_rows].abs().max() if reset_rows.any() else 0.0) == 0.0 and not bool(ro.done[reset_rows].any())
+            before = buf.mem_cntr
+            stored = buf.store_rollout(ro, range(n))
+            keep = (~reset_rows).reshape(-1).nonzero().squeeze(1)
+            assert stored == keep.numel() == buf.mem_cntr - before
+            # every stored row, in order, is the kept row of the rollout
+            rows = (before + torch.arange(stored, device="cuda")) % buf.mem_size
+            t_i, e_i = keep // E, keep % E
+            assert torch.equal(buf.actor_states[rows], ro.obs[t_i, e_i, :n]) and torch.equal(buf.actor_new_states[rows], ro.obs[t_i + 1, e_i, :n])
+            assert torch.equal(buf.action_mem[rows], ro.scores[t_i, e_i, :n]) and torch.equal(buf.rew_mem[rows], ro.rew[t_i, e_i, :n])
+            assert torch.equal(buf.done_mem[rows], ro.done[t_i, e_i, :n])
+            total += stored; dropped += int(reset_rows.sum()); ends += int((edone[1:] != 0).sum())
+        torch.cuda.synchronize()
+        assert dropped > 0 and total + dropped == 12 * T * E and buf.is_ready()
+        waiting = int((env.env_done != 0).sum())
+        assert dropped == ends - waiting                          # one re-spawn call per game end (those still waiting excepted)
+        games = int(env.counters()[:, 0].sum())
+        assert ends <= games <= 2 * ends                          # both bases in one call count as two games (battle_env.py:363-372)
+        a_s, s2_, a, r, a_s2, s2, d = buf.sample()
+        assert s2_.shape == (256, n * env.obs_size) and a.shape == (n, 256, 4) and d.dtype == torch.bool
+        assert float(a.abs().max()) <= 1.0
+        assert torch.equal(env.env_done, ro.env_done[T] != 0)   # the env's own flag is the last row of the record
 
 
 @pytest.mark.parametrize("case", range(12))

@@ -1,0 +1,278 @@
+"""The rollout path (BASELINE.json configs[4]) against the oracle and against fixtures recorded from the
+unmodified reference: the closed loop  reference ActorNetwork weights -> on-device actor -> arg-max -> step  beside the C
+oracle stepping on the same score vectors; the Ornstein-Uhlenbeck exploration noise against utils/noise.py's own
+trajectory (g11); the device replay ring against maddpg/buffer.py's memory layout (g10); the continuous-action one-launch
+rollout against its two-kernel form; exploration noise under sharding; one game's exported state as an image."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref
+from trace_util import OBS_ATOL, OBS_RTOL
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _env(**kw):
+    import deep_rl_battlespace_amd as bsx
+    return bsx.parallel_env(**kw)
+
+
+def _reference_actor(tag, n_slots, device="cuda"):
+    """StackedActor whose every slot holds the reference ActorNetwork's weights recorded in g9 (maddpg/networks.py:54-85)."""
+    from deep_rl_battlespace_amd.rollout import StackedActor
+    g9 = np.load(os.path.join(GOLD, "g9_actor_forward.npz"))
+    sd = {k.split("/", 1)[1]: torch.from_numpy(g9[k]) for k in g9.files if k.startswith(tag + "/") and k.split("/")[1] not in ("x", "y")}
+    actor = StackedActor(n_slots, sd["fc1.weight"].shape[1], 4, device=device)
+    for i in range(n_slots):
+        actor.load_reference_actor(i, {k: v.to(device) for k, v in sd.items()})
+    with torch.no_grad():                                        # the stacked module IS the reference forward on the fixture's rows
+        x, y = torch.from_numpy(g9[tag + "/x"]).to(device), torch.from_numpy(g9[tag + "/y"]).to(device)
+        got = actor(x[:, None, :].expand(-1, n_slots, -1).contiguous())
+    torch.testing.assert_close(got[:, 0], y, rtol=0, atol=2e-6)
+    return actor
+
+
+@pytest.mark.parametrize("one_launch", [True, False])
+def test_closed_loop_reference_actor_rollout_vs_c_oracle(one_launch):
+    """configs[4] at full size, loop closed against the oracle.  Device: 65 536 games of 1v1, both planes run the reference
+    ActorNetwork (g9 weights) through the MFMA actor, exploration noise, clamp, in-kernel arg-max, fused step, for 256 ticks
+    (two full games and the auto-resets between them) -- as ONE launch per 32 ticks (bsx_rollout_discrete) and as the
+    two-kernel graph.  Beside it the C oracle plays the SAME games from the same score vectors' arg-max
+    (maddpg/agent.py:25-33 -> battle_env.py:327-328): rewards, dones, game flags and the full state must be identical,
+    observations within 1e-5; and on the observations the games actually visited the device actor equals the torch fp32
+    restatement of the reference forward."""
+    from deep_rl_battlespace_amd.rollout import FusedActor, PolicyRollout
+    E, n, T, RUNS = 65536, 1, 32, 8
+    actor = _reference_actor("1v1", 2)
+    env = _env(n_agents=n, n_envs=E, seed=77, auto_reset=True)
+    c = cref.CRefBatch(E, n_agents=n, seed=77, auto_reset=True)
+    o_h = env.reset(); o_c = c.reset()
+    np.testing.assert_allclose(torch.stack([o_h[a] for a in env.possible_agents], 1).cpu().numpy(), o_c, rtol=OBS_RTOL, atol=OBS_ATOL)
+    ro = PolicyRollout(env, actor, T, noise_std=0.6, seed=5, one_launch=one_launch)
+    ro.start(); ro.capture()
+    n_exact = n_vals = 0
+    acts_seen = torch.zeros(4, dtype=torch.long)
+    for run in range(RUNS):
+        ro.run()
+        torch.cuda.synchronize()
+        obs, sc, rew, done, edone = (x.cpu().numpy() for x in (ro.obs, ro.scores, ro.rew, ro._done, ro.env_done))
+        if run == 0:
+            np.testing.assert_allclose(obs[0], o_c, rtol=OBS_RTOL, atol=OBS_ATOL)
+        for t in range(T):
+            assert np.array_equal(edone[t], c.env_done), (run, t)         # env_done BEFORE the tick
+            co, cr, cd = c.step(sc[t])                                     # float32 [E, A, 4] score vectors: arg-maxed (battle_env.py:327-328)
+            assert np.array_equal(done[t].astype(bool), cd), (run, t)
+            assert np.array_equal(rew[t].astype(np.float64), cr), (run, t)
+            np.testing.assert_allclose(obs[t + 1], co, rtol=OBS_RTOL, atol=OBS_ATOL, err_msg=f"run {run} tick {t}")
+            n_exact += int((obs[t + 1] == co).sum()); n_vals += co.size
+        assert np.array_equal(edone[T], c.env_done) and np.array_equal(env.winner.cpu().numpy(), c.winner)
+        sh = {k: v.cpu().numpy() for k, v in env.export_state().items()}
+        scx = c.export_state()
+        for f in ("px", "py", "pdir", "php", "palive", "base_xy", "bhp", "tick", "env_done", "winner", "bl_live", "counters"):
+            assert np.array_equal(sh[f], scx[f]), (run, f)
+        m = scx["bl_live"].astype(bool)
+        for f in ("bl_x", "bl_y", "bl_dir"):
+            assert np.array_equal(sh[f][m], scx[f][m]), (run, f)
+        acts_seen += torch.bincount(ro.scores.argmax(-1).flatten().cpu(), minlength=4)
+    assert n_exact >= n_vals * (1 - 1e-3)
+    cn = scx["counters"].sum(0)
+    assert cn[0] >= 2 * E and cn[0] == cn[1] + cn[2] + cn[3]               # two full games per env and more
+    assert int((acts_seen > 0.05 * acts_seen.sum()).sum()) == 4             # all four actions in real use
+    # the actor itself, on observations these games visited: MFMA kernel == torch fp32 restatement of the reference forward
+    with torch.no_grad():
+        want = actor(ro.obs[T // 2])
+    got = FusedActor(actor, n)(ro.obs[T // 2])
+    torch.testing.assert_close(got, want, rtol=0, atol=2e-5)
+    clear = (want.topk(2, -1).values[..., 0] - want.topk(2, -1).values[..., 1]) > 1e-4
+    assert torch.equal(got.argmax(-1)[clear], want.argmax(-1)[clear])
+
+
+def test_ou_noise_reproduces_the_reference_trajectory():
+    """g11: utils/noise.py OUNoise(4) run unmodified -- 40 noise() calls with the np.random.randn values it drew, a reset()
+    (main.py:155) and a re-scale (main.py:154) on the way.  The in-kernel process (bsx_actor_forward) is fed the same normals
+    (BsxActorNoise.z_inject) with an all-zero actor, so its scores ARE scale * state: state and noise must follow the
+    reference's binary64 trajectory to float32 accuracy, for every row."""
+    from deep_rl_battlespace_amd.rollout import FusedActor, StackedActor
+    g = np.load(os.path.join(GOLD, "g11_ou_noise.npz"))
+    scale, mu, theta, sigma = (float(v) for v in g["params"])
+    events = {int(e[0]): (int(e[1]), float(e[2])) for e in g["events"]}
+    n, E = 2, 37
+    A, D = 2 * n, 3 * n + 2
+    actor = StackedActor(A, D, 4, device="cuda")
+    with torch.no_grad():
+        for p in (actor.w1, actor.b1, actor.w2, actor.b2, actor.w3, actor.b3):
+            p.zero_()                                            # tanh(0) = 0: the score rows are the noise alone
+    fused = FusedActor(actor, n, seed=1)
+    obs = torch.rand((E, A, D), device="cuda")
+    st = torch.full((E, A, 4), mu, device="cuda")
+    out = torch.empty((E, A, 4), device="cuda")
+    done = torch.zeros(E, dtype=torch.uint8, device="cuda")
+    for t in range(g["z"].shape[0]):
+        done.zero_()
+        if t in events:
+            kind, val = events[t]
+            if kind == 1:
+                done.fill_(1)                                    # reset_noise(): rows of finished games restart from mu
+            else:
+                scale = val
+        z = torch.from_numpy(g["z"][t]).float().cuda().expand(E, A, 4).contiguous()
+        fused.forward_into(obs, out, 0.0, seq=t, ou=dict(scale=scale, state=st, env_done=done, theta=theta, sigma=sigma, mu=mu), z=z)
+        want_state = torch.from_numpy(g["state"][t]).float().cuda().expand(E, A, 4)
+        want_noise = torch.from_numpy(g["noise"][t]).float().cuda().expand(E, A, 4)
+        torch.testing.assert_close(st, want_state, rtol=2e-6, atol=2e-7, msg=f"state, call {t}")
+        torch.testing.assert_close(out, want_noise.clamp(-1, 1), rtol=2e-6, atol=2e-7, msg=f"noise, call {t}")
+    # Gaussian term with injected normals: scores = std * z exactly as maddpg/agent.py:30-31 adds and clamps
+    z = torch.randn((E, A, 4), device="cuda")
+    fused.forward_into(obs, out, 0.7, seq=0, z=z)
+    torch.testing.assert_close(out, (0.7 * z).clamp(-1, 1), rtol=1e-6, atol=1e-7)
+
+
+def test_replay_ring_reproduces_the_reference_buffer():
+    """g10 (maddpg/buffer.py run unmodified; see trace_util.check_replay_against_reference) with the ring in HBM."""
+    from trace_util import check_replay_against_reference
+    check_replay_against_reference("cuda")
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4])
+@pytest.mark.parametrize("noise", ["none", "gaussian", "ou-bf16x3"])
+def test_one_launch_continuous_rollout_equals_two_kernel_rollout(noise, n):
+    """bsx_rollout_continuous (T ticks of actor -> continuous step in ONE launch) against bsx_actor_forward +
+    bsx_step_continuous per tick (BSX_ACT_F32X4 rows): the same transitions bit for bit across runs and auto-resets, and both
+    equal a plain env stepped with the float32 [E, A, 3] actions the actors produced (battle_env.py:295-297,418-424)."""
+    from deep_rl_battlespace_amd.rollout import PolicyRollout, StackedActor
+    E, T = (4100 if n == 1 else 1030), 40
+    torch.manual_seed(13)
+    actor = StackedActor(2 * n, 3 * n + 2, 3, device="cuda")
+    with torch.no_grad():
+        actor.w3.mul_(60.0); actor.g1.uniform_(0.5, 1.5); actor.h1.uniform_(-0.3, 0.3)
+    kw = dict(noise_std=0.3) if noise == "gaussian" else (dict(ou_scale=0.4, precision="bf16x3") if noise.startswith("ou") else {})
+    ros = []
+    for one in (False, True):
+        env = _env(n_agents=n, n_envs=E, seed=31, auto_reset=True, continuous_actions=True); env.reset()
+        ro = PolicyRollout(env, actor, T, seed=7, one_launch=one, **kw); ro.start()
+        if one:
+            ro.capture()
+        ros.append(ro)
+    twin = _env(n_agents=n, n_envs=E, seed=31, auto_reset=True, continuous_actions=True); twin.reset()
+    a, b = ros
+    for rep in range(5):
+        a.run(); b.run()
+        torch.cuda.synchronize()
+        assert torch.equal(a.obs, b.obs), rep
+        assert torch.equal(a.scores, b.scores), rep
+        assert torch.equal(a.rew, b.rew) and torch.equal(a.done, b.done) and torch.equal(a.env_done, b.env_done), rep
+        if noise.startswith("ou"):
+            assert torch.equal(a.ou["state"], b.ou["state"]), rep
+        for t in range(T):
+            o, r, d = twin.step_batch(b.scores[t][..., :3].contiguous())
+            assert torch.equal(o, b.obs[t + 1]) and torch.equal(r, b.rew[t]) and torch.equal(d, b.done[t]), (rep, t)
+    sa, sb = a.env.export_state(), b.env.export_state()
+    for k in ("px", "py", "pdir", "php", "bhp", "tick", "env_done", "winner", "bl_live", "bl_x", "bl_y", "counters"):
+        assert torch.equal(sa[k], sb[k]), k
+    assert int(a.env.counters()[:, 0].sum()) >= E                # the runs crossed game ends
+    assert float(b.scores[..., 2].max()) > 0 and float(b.scores[..., 2].min()) < 0      # some planes fire, some do not
+    with pytest.raises(ValueError):                              # no scripted opponent in continuous mode (it writes float64 rows)
+        from deep_rl_battlespace_amd import instinct
+        PolicyRollout(a.env, actor, T, one_launch=True, opponent=instinct.Team(a.env.possible_blue, a.env.possible_red, a.env))
+
+
+@pytest.mark.parametrize("one_launch", [False, True])
+def test_exploration_noise_does_not_depend_on_the_sharding(one_launch):
+    """A job split over ranks (sharding.make_shard: env_offset) explores exactly as the unsplit job: the actor's Philox draws are
+    keyed by the GLOBAL row, like the env's own jitter and spawn draws -- Gaussian noise and the OU process alike."""
+    from deep_rl_battlespace_amd.rollout import PolicyRollout, StackedActor
+    E, n, T, parts = 2048, 2, 24, 4
+    torch.manual_seed(2)
+    actor = StackedActor(2 * n, 3 * n + 2, 4, device="cuda")
+    with torch.no_grad():
+        actor.w3.mul_(60.0)
+
+    def play(E_, off):
+        env = _env(n_agents=n, n_envs=E_, seed=11, auto_reset=True, env_offset=off); env.reset()
+        ro = PolicyRollout(env, actor, T, noise_std=0.3, ou_scale=0.2, seed=9, one_launch=one_launch); ro.start()
+        for _ in range(8):
+            ro.run()
+        torch.cuda.synchronize()
+        return ro
+    whole = play(E, 0)
+    q = E // parts
+    pieces = [play(q, i * q) for i in range(parts)]
+    for name in ("obs", "scores", "rew", "done", "env_done"):
+        assert torch.equal(getattr(whole, name), torch.cat([getattr(p, name) for p in pieces], dim=1)), name
+    assert torch.equal(whole.ou["state"], torch.cat([p.ou["state"] for p in pieces]))
+    assert int(whole.env.counters()[:, 0].sum()) > 0
+
+
+def test_exported_game_state_renders_what_the_oracle_holds(tmp_path):
+    """f-4 (battle_env.py:498-560 draws planes, bases and bullets of ONE game): the state block of a running batch is exported,
+    one game of it equals the oracle's game field by field, and its host-side image shows every live sprite where the state
+    says it is (team colour at the centre of each live plane and base, bullet pixels at live bullets)."""
+    from deep_rl_battlespace_amd import render
+    E, n = 300, 2
+    env = _env(n_agents=n, n_envs=E, seed=4, auto_reset=True); env.reset()
+    c = cref.CRefBatch(E, n_agents=n, seed=4, auto_reset=True); c.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    for t in range(45):
+        a = torch.where(torch.rand((E, 2 * n), generator=g, device="cuda") < 0.5, 1, torch.randint(0, 4, (E, 2 * n), generator=g, device="cuda")).to(torch.int32)
+        env.step_batch(a); c.step(a.cpu().numpy())
+    st = {k: v.cpu().numpy() for k, v in env.export_state().items()}
+    sc = c.export_state()
+    live = sc["bl_live"].astype(bool)
+    e = int(np.argmax(live.reshape(E, -1).sum(1)))               # the game with most bullets in flight
+    one = {k: v[e] for k, v in st.items()}
+    for f in ("px", "py", "pdir", "php", "base_xy", "bhp", "bl_live"):
+        assert np.array_equal(one[f], sc[f][e]), f
+    img = render.frame(env, e)                                   # device -> host copy of game e, rasterised
+    want = render.frame_from_state({k: sc[k][e] for k in ("px", "py", "pdir", "php", "base_xy", "bhp", "bl_live", "bl_x", "bl_y")}, n)
+    assert img.shape == (800, 1200, 3) and np.array_equal(img, want)          # the same picture as the oracle's game
+    inked = lambda y, x: tuple(img[min(max(int(y), 0), 799), min(max(int(x), 0), 1199)]) != render.WHITE    # noqa: E731
+    for i in range(2 * n):
+        assert inked(one["py"][i] - 23, one["px"][i] - 24)      # a corner of the 50 x 48 hit box: filled when alive, outlined when dead
+        for k in range(12):
+            if one["bl_live"][i, k]:
+                assert inked(one["bl_y"][i, k], one["bl_x"][i, k])
+    bx = one["base_xy"]
+    assert inked(bx[1] - 30, bx[0] - 30) and inked(bx[3] - 30, bx[2] - 30)
+    render.save_ppm(tmp_path / "game.ppm", img)
+    assert int(live[e].sum()) >= 3 and (tmp_path / "game.ppm").stat().st_size > 800 * 1200 * 3
+
+
+def test_checkpoint_restores_host_mirrors_and_checks_its_shape():
+    """state_dict / load_state_dict in drop-in mode: after a restore the reference-typed surface (`agents`, `dones`, `env_done`,
+    `winner`) is what it was at the snapshot -- the next step() draws its random() values for the right planes -- and a
+    snapshot of another job shape is refused."""
+    import random
+    random.seed(5)
+    env = _env(n_agents=2)
+    env.reset()
+    ids = env.possible_agents
+    # play until a plane has died but the game is still on, snapshot there
+    snap = None
+    for t in range(400):
+        if env.env_done:
+            env.reset()
+        obs, rew, dones, _ = env.step({a: 1 if t % 3 else 2 for a in env.agents})
+        if not env.env_done and len(env.agents) < len(ids) and snap is None:
+            snap = (env.state_dict(), list(env.agents), dict(env.dones), env.winner, random.getstate())
+            break
+    assert snap is not None, "no plane died in 400 calls of shoot-heavy play"
+    sd, agents, dones, winner, rstate = snap
+    trace = []
+    for t in range(30):
+        if env.env_done:
+            break
+        o, r, d, _ = env.step({a: 1 for a in env.agents})
+        trace.append(({k: v.copy() for k, v in o.items()}, dict(r), dict(d)))
+    env.load_state_dict(sd)
+    random.setstate(rstate)
+    assert env.agents == agents and env.dones == dones and env.winner == winner and env.env_done is False
+    for t, (o0, r0, d0) in enumerate(trace):
+        o, r, d, _ = env.step({a: 1 for a in env.agents})
+        assert r == r0 and dict(d) == d0 and all(np.array_equal(o[k], o0[k]) for k in o), t
+    other = _env(n_agents=1)
+    with pytest.raises(ValueError):
+        other.load_state_dict(sd)

@@ -1,0 +1,49 @@
+"""configs[3] on one card: the multi-rank path of bench.py exercised across PROCESSES.  `python bench.py --gpus 2
+--rehearse-on-device0` starts two ranks itself (one process each, gloo for the barrier / timing reduction, both on cuda:0 --
+the only part of the 8-GPU layout a one-GPU box can run); every rank owns a contiguous range of a 131 072-game job and
+writes its final game state.  The concatenation must equal, field by field, what ONE process playing all 131 072 games
+ends with: independent games, RNG and action table keyed by the global game index, no collective on the step path."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_rank_job_equals_the_single_process_job(tmp_path):
+    common = ["--steps", "150", "--warmup", "10", "--repeats", "2", "--ramp-ms", "0", "--no-cpu-baseline", "--no-other-workloads"]
+    d2, d1 = str(tmp_path / "two"), str(tmp_path / "one")
+    two = _bench(["--gpus", "2", "--rehearse-on-device0", "--envs-per-gpu", "65536", "--digest-dir", d2, *common])
+    one = _bench(["--gpus", "1", "--envs-per-gpu", "131072", "--digest-dir", d1, *common])
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1 and two["scaling"] == "weak"
+    assert two["config"]["rehearsal_all_ranks_on_device0"] is True
+    # whole-job throughput of the two-rank line = the games of BOTH ranks over the slower rank's time
+    assert abs(two["value"] - 2 * 65536 * 2 * 150 / (two["ms_per_step"] * 1e-3 * 150)) / two["value"] < 1e-3
+    metas = [json.load(open(os.path.join(d2, f"rank{r}.json"))) for r in range(2)]
+    assert [m["env_offset"] for m in metas] == [0, 65536] and all(m["n_envs"] == 65536 and m["world"] == 2 for m in metas)
+    parts = [torch.load(os.path.join(d2, f"rank{r}.pt")) for r in range(2)]
+    whole = torch.load(os.path.join(d1, "rank0.pt"))
+    for k in sorted(whole):
+        cat = torch.cat([p[k] for p in parts])
+        if k in ("bl_x", "bl_y", "bl_dir"):                      # slots without a live bullet hold leftovers
+            m = whole["bl_live"].bool()
+            assert torch.equal(cat[m], whole[k][m]), k
+        else:
+            assert torch.equal(cat, whole[k]), k
+    # both lines count the same finished games: the logging all-reduce summed the two shards' counters
+    assert two["games_finished"] == one["games_finished"] > 0 and two["ties"] == one["ties"]
+    assert int(whole["counters"][:, 0].sum()) == one["games_finished"]

@@ -50,13 +50,18 @@ def test_bad_arguments_are_rejected_before_any_launch():
     assert lib.bsx_state_init(ctypes.c_void_p(4096 + 8), 4, 1, None) == -2      # misaligned state base
     # the multi-tick and rollout entry points: T out of range, team sizes the one-launch rollout is not built for, unknown precision
     ok = ctypes.c_void_p(4096)
-    assert lib.bsx_step_many_discrete(ok, 4, 1, 0, ok, 0, None, ok, ok, ok, None, None, ctypes.byref(cfg), 0, 1, 0, 0, None) == -1
-    assert lib.bsx_step_many_discrete(ok, 4, 1, 70000, ok, 0, None, ok, ok, ok, None, None, ctypes.byref(cfg), 0, 1, 0, 0, None) == -1
-    assert lib.bsx_step_many_continuous(ok, 4, 1, 5, None, 0, None, ok, ok, ok, None, None, ctypes.byref(cfg), 0, 1, 0, 0, None) == -1
-    assert lib.bsx_rollout_discrete(ok, 4, 5, 8, ok, 0, -1, ok, ok, ok, ok, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1
-    assert lib.bsx_rollout_discrete(ok, 4, 1, 8, ok, 7, -1, ok, ok, ok, ok, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1
-    assert lib.bsx_rollout_discrete(ok, 4, 1, 8, ok, 0, 2, ok, ok, ok, ok, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1
-    assert lib.bsx_actor_forward(ok, ok, ok, 4, 1, 7, None, 0, 0, None, None) == -1
+    assert lib.bsx_step_many_discrete(ok, 4, 1, 0, ok, 0, None, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, 1, 0, 0, None) == -1
+    assert lib.bsx_step_many_discrete(ok, 4, 1, 70000, ok, 0, None, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, 1, 0, 0, None) == -1
+    assert lib.bsx_step_many_continuous(ok, 4, 1, 5, None, 0, None, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, 1, 0, 0, None) == -1
+    assert lib.bsx_rollout_discrete(ok, 4, 5, 8, ok, 0, -1, ok, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1
+    assert lib.bsx_rollout_discrete(ok, 4, 1, 8, ok, 7, -1, ok, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1
+    assert lib.bsx_rollout_discrete(ok, 4, 1, 8, ok, 0, 2, ok, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1
+    assert lib.bsx_rollout_continuous(ok, 4, 5, 8, ok, 0, ok, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1
+    nz = L.BsxActorNoise(0.1, 0.0, 0.15, 0.2, 0.0, None, None, ctypes.c_void_p(4096))     # injected normals are per call: not for a T-tick launch
+    assert lib.bsx_rollout_continuous(ok, 4, 1, 8, ok, 0, ok, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, ctypes.byref(nz), 0, 0, None, 0, 0, None) == -1
+    assert lib.bsx_actor_forward(ok, ok, ok, 4, 1, 7, None, 0, 0, None, 0, None) == -1
+    assert lib.bsx_actor_forward(ok, ok, ok, 4, 1, 0, None, 0, 0, None, -5, None) == -1   # negative env_offset
+    assert lib.bsx_build_flags() == 0                                                      # the in-tree library is the product build
 
 
 def test_env_refuses_to_run_without_gpu_or_library():
@@ -161,3 +166,48 @@ def test_render_frame_from_exported_state(tmp_path):
     assert tuple(img[400, 1100]) == render.BLUE and tuple(img[400, 100]) == render.RED       # bases
     render.save_ppm(tmp_path / "f.ppm", img)
     assert (tmp_path / "f.ppm").stat().st_size == 800 * 1200 * 3 + len(b"P6\n1200 800\n255\n")
+
+
+def test_binding_refuses_a_diagnostic_build(tmp_path):
+    """Timing-ablation / stamped builds give WRONG results; they are built as separate variant files (tools/build_variant.py),
+    report themselves through bsx_build_flags(), and the binding loads one only when BSX_ALLOW_DIAG=1 says so -- the product
+    library in the tree is never replaced by one."""
+    prod = os.path.join(ROOT, "deep-rl-battlespace_amd", "csrc", "libbattlespace_hip.so")
+    before = os.path.getmtime(prod)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "build_variant.py"), "citest_diag2", "-DBSX_DIAG=2"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    variant = out.stdout.strip().splitlines()[-1]
+    try:
+        assert os.path.getmtime(prod) == before and os.path.dirname(variant).endswith("variants")
+        code = "import sys; sys.path.insert(0, %r); from deep_rl_battlespace_amd import _lib; print(_lib.load().bsx_build_flags())" % ROOT
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BSX_LIB_PATH=variant), capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "diagnostic build" in r.stderr
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BSX_LIB_PATH=variant, BSX_ALLOW_DIAG="1"), capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and r.stdout.strip() == "2", r.stderr[-500:]
+    finally:
+        os.remove(variant)
+
+
+def test_bench_action_table_is_shard_invariant_and_uniform():
+    """bench.py keys its synthetic actions by the GLOBAL game index, so `--gpus N` shards play the games of the unsplit job."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    whole = bench.hashed_bits(40, 0, 3000, 2, 1, 1234, "cpu")[..., 0] >> 29
+    part = bench.hashed_bits(40, 1000, 2000, 2, 1, 1234, "cpu")[..., 0] >> 29
+    assert torch.equal(whole[:, 1000:2000], part)
+    cnt = torch.bincount(whole.flatten(), minlength=4).float()
+    assert cnt.numel() == 4 and float((cnt / cnt.sum() - 0.25).abs().max()) < 0.01
+    f = bench.hashed_bits(8, 0, 500, 2, 3, 1234, "cpu").float() * (2.0 / 2147483648.0) - 1.0
+    assert float(f.min()) >= -1.0 and float(f.max()) < 1.0 and abs(float(f.mean())) < 0.02
+
+
+def test_bench_multi_gpu_launch_without_gpus_fails_loudly():
+    """`python bench.py --gpus 2` launched plainly starts its own ranks; on a box with fewer cards it must say so, not hang."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two cards visible: the launch would really start two ranks")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE")})
+    assert r.returncode != 0 and "--rehearse-on-device0" in (r.stderr + r.stdout)

@@ -166,3 +166,29 @@ def test_packed_actor_blob_drives_the_mfma_fragment_arithmetic(n):
                     o = sum(acc[mt, nt, v, c + 32 * h2] * w3[h2, mt, v] for h2 in range(2) for mt in range(2) for v in range(16))
                     out[32 * nt + c] = np.tanh(o + b3)
             np.testing.assert_allclose(out, want[:, a, :], atol=tol)
+
+
+def test_replay_ring_reproduces_the_reference_buffer_on_cpu():
+    """g10: the memory layout and sample() tuple of maddpg/buffer.py (run unmodified by tests/golden/make_golden.py), with the
+    ring on the CPU device -- the same check runs with the ring in HBM under -m gpu."""
+    from trace_util import check_replay_against_reference
+    check_replay_against_reference("cpu")
+
+
+def test_ou_fixture_is_the_reference_recursion():
+    """g11 sanity (no GPU): the recorded trajectory obeys x += theta*(mu - x) + sigma*z, noise = scale*x (utils/noise.py:17-21)
+    with the recorded normals, the reset and the re-scale -- what the -m gpu test asks of the in-kernel process."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g11_ou_noise.npz"))
+    scale, mu, theta, sigma = (float(v) for v in g["params"])
+    ev = {int(e[0]): (int(e[1]), float(e[2])) for e in g["events"]}
+    x = np.full(4, mu)
+    for t in range(g["z"].shape[0]):
+        if t in ev:
+            if ev[t][0] == 1:
+                x = np.full(4, mu)
+            else:
+                scale = ev[t][1]
+        x = x + theta * (mu - x) + sigma * g["z"][t]
+        np.testing.assert_allclose(g["state"][t], x, rtol=0, atol=1e-15)
+        np.testing.assert_allclose(g["noise"][t], x * scale, rtol=0, atol=1e-15)

@@ -148,3 +148,37 @@ def replay_batched(make_env, t, ep_ids, exact_obs=False):
         assert np.array_equal(np.asarray(env.env_done())[on].astype(bool), t["env_done"][rows])
         assert np.array_equal(np.asarray(env.winner())[on], t["winner"][rows])
     return n_exact, n_vals
+
+
+def check_replay_against_reference(device):
+    """g10: maddpg/buffer.py ReplayBuffer run unmodified on 10 transitions of a 2-plane team (ring of 6: four rows overwritten),
+    snapshots after 3 / 5 / 10 stores, and what sample() returned for the indices np.random.choice drew.  The device ring,
+    fed the same dicts through the same `store_transition`, holds the same memory and returns the same batch for those
+    indices (float32 here, binary64 there; the values are float32-representable)."""
+    import numpy as np
+    from deep_rl_battlespace_amd.replay import ReplayBuffer
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g10_replay_buffer.npz"))
+    M, B, obs_size, n_act, nA = (int(v) for v in g["cfg"])
+    agents = [f"plane{i}" for i in range(nA)]
+    buf = ReplayBuffer(M, B, agents, obs_size, obs_size * nA, n_act, device=device)
+    S = g["in/states"].shape[0]
+    for k in range(S):
+        d = lambda key: {a: g["in/" + key][k, i] for i, a in enumerate(agents)}     # noqa: E731  (one game: plain per-agent values)
+        buf.store_transition(d("states"), d("actions"), d("rewards"), d("states_"), d("dones"))
+        tag = f"after{k + 1}"
+        if tag + "/mem_cntr" not in g.files:
+            continue
+        assert buf.mem_cntr == int(g[tag + "/mem_cntr"]) and buf.is_ready() == bool(g[tag + "/is_ready"])
+        np.testing.assert_array_equal(buf.state_mem.cpu().numpy(), g[tag + "/state_mem"].astype(np.float32))
+        np.testing.assert_array_equal(buf.new_state_mem.cpu().numpy(), g[tag + "/new_state_mem"].astype(np.float32))
+        np.testing.assert_array_equal(buf.rew_mem.cpu().numpy(), g[tag + "/rew_mem"].astype(np.float32))
+        np.testing.assert_array_equal(buf.done_mem.cpu().numpy(), g[tag + "/done_mem"])
+        for name, mine in (("actor_states", buf.actor_states), ("actor_new_states", buf.actor_new_states), ("action_mem", buf.action_mem)):
+            np.testing.assert_array_equal(mine.transpose(0, 1).cpu().numpy(), g[f"{tag}/{name}"].astype(np.float32))   # reference: [agent][M, ...]
+        if tag + "/idx" in g.files:
+            res = buf.sample(idx=g[tag + "/idx"])
+            for name, v in zip(("actor_states", "states", "actions", "rewards", "actor_new_states", "states_", "dones"), res):
+                ref = g[f"{tag}/sample/{name}"]
+                assert tuple(v.shape) == ref.shape, name
+                np.testing.assert_array_equal(v.cpu().numpy(), ref.astype(np.float32) if ref.dtype != bool else ref, err_msg=name)
+    assert buf.mem_cntr == S

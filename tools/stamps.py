@@ -2,17 +2,13 @@
 import ctypes, os, subprocess, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-src = os.path.join(ROOT, "deep-rl-battlespace_amd/csrc")
-lib = os.path.join(src, "libbattlespace_hip.so")
-os.rename(lib, lib + ".product")
-try:
-    objs = []
-    for f, extra in (("bsx_kernels.hip", ["-ffp-contract=off", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-mfma-vgpr-form", "-mllvm", "-amdgpu-kernarg-preload-count=11", "-DBSX_STAMPS"]), ("bsx_actor.hip", ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form"])):
-        o = f"/tmp/stamps_{f}.o"
-        subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", *extra, "-I", os.path.join(ROOT, "include"),
-                        "-c", os.path.join(src, f), "-o", o], check=True)
-        objs.append(o)
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib], check=True)
+# the stamped build is a VARIANT next to the product library (tools/build_variant.py), selected through BSX_LIB_PATH for this
+# process only -- the product file is never renamed or overwritten, so a kill or timeout here cannot leave a wrong library behind
+V = os.path.join(ROOT, "deep-rl-battlespace_amd/csrc/variants/lib_stamps.so")
+if not os.path.exists(V):
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools/build_variant.py"), "stamps", "-DBSX_STAMPS"], check=True)
+os.environ["BSX_LIB_PATH"], os.environ["BSX_ALLOW_DIAG"] = V, "1"
+if True:
     import deep_rl_battlespace_amd as bsx
     from deep_rl_battlespace_amd import _lib
     E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
@@ -63,5 +59,3 @@ try:
         print(f"  {'end-of-tick fence (stores acknowledged)':40s} {fence / reps * 10:9.1f} ns   [mode {mode}: last tick of 16; the first phase includes the actor in rollout mode]")
     sp = np.asarray(span).mean(0)
     print(f"  wave lifetime mean {sp[1]*10:.0f} ns; first-start to last-end {sp[0]*10:.0f} ns; start skew {sp[2]*10:.0f} ns")
-finally:
-    os.replace(lib + ".product", lib)
