@@ -37,7 +37,12 @@ namespace {
 
 constexpr int K = BSX_BULLET_SLOTS;
 constexpr int TPB = 256;   // reset / export kernels
-constexpr int SPB = 64;    // step kernel: ONE wavefront per workgroup -- a game never spans a wave, so no block barrier is needed
+constexpr int SPB = 64;    // step kernel: a game never spans a wavefront, so the waves of a workgroup share nothing and no block barrier is needed
+// wavefronts per workgroup of the per-step / multi-tick kernels (the fused rollout has its own: 32 games per workgroup)
+#ifndef BSX_X_WPB
+#define BSX_X_WPB 1
+#endif
+constexpr int WPB = BSX_X_WPB;
 
 // Timing-only ablation mask for profiling builds (hipcc -DBSX_DIAG=<bits>; results are WRONG with any bit set):
 // 1 = skip observation math, 2 = skip the bullet loop, 4 = skip the ordered resolve.  The product build has 0.
@@ -62,16 +67,25 @@ __device__ unsigned long long* g_stamps = nullptr;
 #define STAMP(i) do { } while (0)
 #endif
 
-// Experiment switch (tools/build_variant.py -DBSX_X_NTSTORE): obs / rew / done leave with the non-temporal hint -- nothing on
-// the step path reads them back, so they need not stay (dirty) in the L2 until the end-of-kernel write-back.
+// obs / rew / done leave with the non-temporal hint: nothing on the step path reads them back, so they need not sit dirty in
+// the L2 until the end-of-kernel write-back (C2: 8.21 -> 8.02 us per step; -DBSX_X_PLAINSTORE builds ordinary stores for A/B).
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 template <class T> __device__ inline void out_store(T* p, T v) {
-#ifdef BSX_X_NTSTORE
-    __builtin_nontemporal_store(v, p);
-#else
+#ifdef BSX_X_PLAINSTORE
     *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
 #endif
 }
+
+// Bullets are updated in WORK SLOTS packed across the wavefront (see "wave-packed bullet pass" in the step kernel) for the
+// compile-time team sizes 1..4; -DBSX_X_NOPACK builds the per-lane item walk instead (kept for the runtime-n kernel and for A/B).
+#ifdef BSX_X_NOPACK
+constexpr bool PACK_BULLETS = false;
+#else
+constexpr bool PACK_BULLETS = true;
+#endif
+#define BSX_LDS(T, arr) ((__attribute__((address_space(3))) T*)(uintptr_t)(arr))
 
 constexpr int FIELD_W = 1200, FIELD_H = 800;      // sprites.py:9-10
 constexpr int PLANE_HW = 25, PLANE_HH = 24;        // 50x48 sprite, half sizes (w>>1, h>>1)
@@ -198,9 +212,30 @@ __device__ inline double pair_rads(int x0, int y0, int x1, int y1) {   // rel_an
 }
 // The two divisions by constants (battle_env.py:230-231) are multiplications by the float64 reciprocal here: the
 // float64 result can differ in its last bit, which survives the single rounding to float32 with probability ~2^-29.
+// sqrt of a squared pixel distance q = dx*dx + dy*dy (an integer below 2^22): the correctly rounded binary64 root, as math.sqrt
+// gives it (battle_env.py:57).  Same iteration as the library sqrt -- reciprocal-root estimate, two coupled Newton steps on
+// (g ~ sqrt x, h ~ 1 / (2 sqrt x)), two residual corrections with exact fma residuals -- without its range scaling and class tests,
+// which an integer in [0, 2^22) never needs; q = 0 is returned as is.  -DBSX_X_LIBSQRT builds the library call for A/B.
+__device__ inline double sqrt_pixels(int q) {
+#ifdef BSX_X_LIBSQRT
+    return sqrt(double(q));
+#else
+    const double x = double(q);
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return q == 0 ? 0.0 : g;
+#endif
+}
 __device__ inline float obs_dist(int x0, int y0, int x1, int y1) {
     const int dx = x0 - x1, dy = y0 - y1;
-    return float(sqrt(double(dx * dx + dy * dy)) * (2.0 / FIELD_DIAG) - 1.0);
+    return float(sqrt_pixels(dx * dx + dy * dy) * (2.0 / FIELD_DIAG) - 1.0);
 }
 __device__ inline float obs_angle(int x0, int y0, double a0, int x1, int y1) {
     return float(rel_angle(x0, y0, a0, x1, y1) * (1.0 / 360.0));
@@ -351,14 +386,14 @@ __device__ inline void obs_pair(int x, int y, double dir, int tx, int ty, float&
 // workgroup, that plane), and the arg-max travels back to the plane's own lane through LDS (one cross-lane move for 1v1).
 // Everything else stays private to a wave exactly as in the other variants: a wave still only touches its own games.
 template <int N, bool CONT, bool MULTI, bool ACTOR = false>
-__global__ __launch_bounds__(SPB * (ACTOR ? group_width(N > 0 ? N : 1) / 2 : 1)) __attribute__((amdgpu_waves_per_eu((ACTOR && N > 1) ? 2 : 1)))
+__global__ __launch_bounds__(SPB * (ACTOR ? group_width(N > 0 ? N : 1) / 2 : WPB)) __attribute__((amdgpu_waves_per_eu((ACTOR && N > 1) ? 2 : 1)))
 void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* const cnt_, const PlaneRec* const plane_, const void* const act_,
                      const int kind_, const StepArgs p) {
     // The six leading arguments repeat p.E, p.st.env, p.st.cnt, p.st.plane, p.actions, p.action_kind: eleven dwords that the
     // dispatcher preloads into SGPRs (-amdgpu-kernarg-preload-count), so that a wave's first loads need nothing from the
     // kernarg segment and do not queue behind its cold scalar-cache fetch.
     STAMP(8);                                            // diagnostic builds: kernel entry, before any kernarg load
-    constexpr int WAVES = ACTOR ? group_width(N > 0 ? N : 1) / 2 : 1;
+    constexpr int WAVES = ACTOR ? group_width(N > 0 ? N : 1) / 2 : WPB;
     const int n = (N > 0) ? N : p.n;
     const int A = 2 * n;
     const int G = group_width(n);
@@ -393,6 +428,25 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // n >= 2: every plane-to-plane pair is computed ONCE, by one of its two planes, and handed to the other through these
     __shared__ float s_pd_all[(N >= 2) ? WAVES * SPB * N : 1];      // range (symmetric)
     __shared__ double s_pr_all[(N >= 2) ? WAVES * SPB * N : 1];     // the owner's bearing in radians, [0, 2 pi)
+    // wave-packed bullet pass (N = 1 .. 4): the bullets of ALL lanes of the wave are laid out back to back as work slots
+    constexpr bool PACK = PACK_BULLETS && N >= 1 && N <= 4;
+    constexpr int OWN_CAP = SPB * (K + 1);                 // every lane with a full list plus this call's shot
+    __shared__ uint16_t s_own_all[PACK ? WAVES * OWN_CAP : 1];   // slot -> owner lane | item index << 8 | "this call's shot" << 15
+    __shared__ uint32_t s_agg_all[PACK ? WAVES * SPB : 1];       // per owner: survivor bit per entry | misses << 16 | base hits << 24
+    __shared__ uint32_t s_eb_all[PACK ? WAVES * SPB : 1];        // per owner: enemy base x | y << 16
+    __shared__ uint32_t s_pq_all[PACK ? WAVES * SPB : 1];        // per plane: post-move x | y << 11 | alive << 21
+    __shared__ uint32_t s_nw_all[PACK ? WAVES * SPB : 1];        // per owner: this call's shot as a list word (age 0)
+    __shared__ __attribute__((aligned(16))) double s_nd_all[PACK ? WAVES * SPB * 2 : 2];   // ... and its per-update step
+    __shared__ unsigned long long s_ov_all[PACK ? WAVES * SPB : 1], s_pm_all[PACK ? WAVES * SPB : 1];   // per owner: overlap fields / positions by age
+    auto* const s_own = BSX_LDS(uint16_t, s_own_all) + (PACK ? wave * OWN_CAP : 0);
+    auto* const s_agg = BSX_LDS(uint32_t, s_agg_all) + (PACK ? wave * SPB : 0);
+    auto* const s_eb = BSX_LDS(uint32_t, s_eb_all) + (PACK ? wave * SPB : 0);
+    auto* const s_pq = BSX_LDS(uint32_t, s_pq_all) + (PACK ? wave * SPB : 0);
+    auto* const s_nw = BSX_LDS(uint32_t, s_nw_all) + (PACK ? wave * SPB : 0);
+    auto* const s_nd = BSX_LDS(double, s_nd_all) + (PACK ? wave * SPB * 2 : 0);
+    auto* const s_ov = BSX_LDS(unsigned long long, s_ov_all) + (PACK ? wave * SPB : 0);
+    auto* const s_pm = BSX_LDS(unsigned long long, s_pm_all) + (PACK ? wave * SPB : 0);
+    if constexpr (PACK) { s_ov[tid] = 0ull; s_pm[tid] = 0ull; }   // cleared again by whoever finds them set
     float* const s_pd = s_pd_all + ((N >= 2) ? wave * SPB * N : 0);
     double* const s_pr = s_pr_all + ((N >= 2) ? wave * SPB * N : 0);
     // (explicit LDS address space: a volatile access through a generic pointer compiles to flat_load / flat_store)
@@ -593,22 +647,21 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // The heading table (361 x 16 B, read by every wave of every launch) stays hot in each CU's L1: the entry for the
     // post-rotation heading is gathered FIRST in this batch, so the plane can move while the bullet loads are in flight.
     double dir_rot = dir;
-    if (!CONT) {
-        if (act == 2) dir_rot = rotate_dir(dir, 15.0);
-        else if (act == 3) dir_rot = rotate_dir(dir, -15.0);
-    }
+    if (!CONT) dir_rot = rotate_dir(dir, act == 2 ? 15.0 : (act == 3 ? -15.0 : 0.0));   // one straight-line rotate (+0 leaves any heading in [0, 360] as it is)
     double2 dl = make_double2(0.0, 0.0);
     if (!CONT) dl = p.st.lut[min(max(int(dir_rot), 0), 360)];   // 21.5*cos(-radians(d)), 21.5*sin(-radians(d)) from host libm
     constexpr int NI = 4;
     const int cnt0 = (DIAG & 2u) ? 0 : int(live0 & 15u);
     uint32_t iw[NI]; double2 idd[NI];
+    if constexpr (!PACK) {
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const bool has = j < cnt0;
-        iw[j] = *(has ? &p.st.bxy[size_t(j) * EAt + gt] : reinterpret_cast<const uint32_t*>(p.st.lut));
-        idd[j] = *(has ? &p.st.bd[size_t(j) * EAt + gt] : p.st.lut);
+        for (int j = 0; j < NI; ++j) {
+            const bool has = j < cnt0;
+            iw[j] = *(has ? &p.st.bxy[size_t(j) * EAt + gt] : reinterpret_cast<const uint32_t*>(p.st.lut));
+            idd[j] = *(has ? &p.st.bd[size_t(j) * EAt + gt] : p.st.lut);
+        }
+        if (MULTI && !ACTOR && tk + 1 < p.T) load_inputs(tk + 1, rin_next);   // behind this tick's own loads: nothing waits for it before the tick ends
     }
-    if (MULTI && !ACTOR && tk + 1 < p.T) load_inputs(tk + 1, rin_next);   // behind this tick's own loads: nothing waits for it before the tick ends
     const bool alive0 = valid && hp > 0;
     STAMP(1);
 
@@ -639,6 +692,51 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // ---- Bullet.__init__ (sprites.py:293-318) for this call's shot: heading = pre-move heading + (u*8 - 4)
     const bool phys = (mode == M_PHYS) && valid && !(DIAG & 2u);
     const int ks = tick % K;                             // birth-tick ring slot of this call's shot (heading, export only)
+    // ---- wave-packed bullet pass, part 1: lay the wave's bullets out as work slots and fetch the first 64 of them.
+    // Under uniform play an agent holds 0.6 bullets and fires every fourth call, so a per-lane walk over list entries
+    // (4 static items + the shot + a loop for the 58 % of waves in which some lane holds more) runs 7 mostly-empty rounds; packed,
+    // the wave's ~50 bullets fill ONE round of 64 slots.  Slots are numbered ENTRY-major: first every lane's entry 0 (in lane
+    // order), then every entry 1, ...; a lane's own shot is its last entry.  Lists are stored entry-major too ([entry j][agent]),
+    // so the lanes of a round read and write along rows, as coalesced as a per-lane walk -- also when lists are long.
+    // Slot w is served by lane w % 64 in round w / 64; the slot of (lane l, entry k) = #entries below k in the wave + #lanes
+    // below l that have an entry k: one ballot per k.
+    int slots = 0;                                       // wave total
+    struct Slot { int o, k; bool isnew, on; uint32_t wd; double2 dd; size_t go; };   // owner lane, list index, "this call's shot", in use; entry; owner's row
+    Slot cur = {0, 0, false, false, 0u, make_double2(0.0, 0.0), 0};
+    size_t gbt = size_t(wblk * EPB) * size_t(A);         // row of lane 0's agent; owner lane o sits (o / G) * A + (o % G) rows on
+    if (MULTI) asm volatile("" : "+v"(gbt));
+    auto fetch_slot = [&](int rd) {                      // slot rd * 64 + lane: who owns it, and its list entry (loads in flight on return)
+        Slot f;
+        const int w = rd * SPB + lane;
+        f.on = w < slots;
+        const uint32_t v = f.on ? uint32_t(s_own[w]) : 0u;
+        f.o = int(v & 63u); f.k = int((v >> 8) & 15u); f.isnew = (v >> 15) != 0u;
+        f.go = gbt + size_t(f.o / G) * size_t(A) + size_t(f.o & (G - 1));
+        const bool ld = f.on && !f.isnew;
+        const size_t off = size_t(f.k) * EAt + f.go;     // one 64-bit multiply for both arrays
+        f.wd = *(ld ? p.st.bxy + off : reinterpret_cast<const uint32_t*>(p.st.lut));
+        f.dd = *(ld ? p.st.bd + off : p.st.lut);
+        return f;
+    };
+    if constexpr (PACK) {
+        const int ci = phys ? cnt0 + (spawn ? 1 : 0) : 0;
+        for (int k = 0;; ++k) {
+            const unsigned long long hk = __ballot(k < ci);          // lanes that have an entry k
+            if (hk == 0ull) break;
+            if (k < ci) {
+                const int w = slots + int(__builtin_amdgcn_mbcnt_hi(uint32_t(hk >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(hk), 0u)));
+                s_own[w] = uint16_t(uint32_t(lane) | (uint32_t(k) << 8) | ((k == cnt0) ? 0x8000u : 0u));
+            }
+            slots += __popcll(hk);
+        }
+        s_agg[tid] = 0u;
+        s_eb[tid] = pack_xy(team == 0 ? er.bbx : er.brx, team == 0 ? er.bby : er.bry);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        cur = fetch_slot(0);
+        if (MULTI && !ACTOR && tk + 1 < p.T) load_inputs(tk + 1, rin_next);   // behind this tick's own loads
+    }
     double2 nd = make_double2(0.0, 0.0);
     if (spawn) {
         double uu = uu_in;
@@ -652,8 +750,10 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         nd = make_double2(BULLET_STEP * cs, BULLET_STEP * sn);
         p.st.bdir[size_t(ks) * EAt + gt] = bdir;       // ring by birth tick: never moves, read only by bsx_export_state
     }
-
-
+    if constexpr (PACK) {                                // this call's shot as the work slot will read it: list word (age 0) + step
+        s_nw[tid] = pack_bullet(x, y, 0);
+        s_nd[2 * tid] = nd.x; s_nd[2 * tid + 1] = nd.y;
+    }
 
     if (mode == M_RESET) {
         // re-spawn in place of the inert call; episode id = games played so far
@@ -690,6 +790,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // ---- hand the post-move pose and hit points to the other planes of the game.  1v1: the only other plane is the lane
     //      next door, three cross-lane moves (DPP) instead of LDS round trips; larger teams stage the block in LDS.
     int nx_ = 0, ny_ = 0, nhp_ = 0;                      // 1v1: the enemy's x, y, hit points
+    if constexpr (PACK) s_pq[tid] = uint32_t(x) | (uint32_t(y) << 11) | ((valid && hp > 0) ? (1u << 21) : 0u);
     if constexpr (N == 1) {
         nx_ = __shfl_xor(x, 1); ny_ = __shfl_xor(y, 1); nhp_ = __shfl_xor(valid ? hp : 0, 1);
     } else {
@@ -811,6 +912,107 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
             pos += 1;
         }
     };
+    if constexpr (PACK) {
+        // ---- wave-packed bullet pass, part 2: Bullet.update per work slot.  A slot reads what its bullet's OWNER would have had
+        // in registers -- the enemy base, the enemy planes' post-move poses and alive flags, this call's shot -- from the wave's
+        // LDS block, moves the bullet, and hands the outcome back: one LDS add per slot (survivor bit, miss and base-hit counts),
+        // the survivor straight to its compacted list position, the rare plane-overlap candidates as the by-age bit fields the
+        // ordered resolve below walks.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): the first round's loads arrived behind the observation geometry
+                                                         // (and no later wait is held up by the stores issued since: vmcnt is in-order)
+        bool any_hit = false;
+        // a round's survivor stores are issued at the START of the next round (after the loop for the last one), i.e. BEFORE the
+        // loads of the round after: loads and stores share the in-order vmcnt, so a wait for loads issued ahead of stores would
+        // also sit out the stores' acknowledgement; issued behind them, both are long done when the entries are needed
+        bool st_on = false, st_dd = false; size_t st_go = 0; int st_ps = 0; uint32_t st_w = 0u; double2 st_d = make_double2(0.0, 0.0);
+        auto flush_stores = [&]() {
+            if (st_on) {
+                const size_t off = size_t(st_ps) * EAt + st_go;
+                p.st.bxy[off] = st_w;
+                if (st_dd) p.st.bd[off] = st_d;                                  // the entry moved down (or is new): its step moves with it
+            }
+        };
+        // what a slot needs from its owner's side of the game, read from the wave's LDS block: enemy base, enemy planes (post-move
+        // pose + alive flag), this call's shot
+        struct Ctx { uint32_t ebw, pq[NE], nw; double ndx, ndy; };
+        auto fetch_ctx = [&](int o) {
+            Ctx c;
+            c.ebw = s_eb[o];
+            const int ebl = (o & ~(G - 1)) + (((o & (G - 1)) < N) ? N : 0);     // first lane of the owner's enemy team
+#pragma unroll
+            for (int q = 0; q < NE; ++q) c.pq[q] = s_pq[ebl + q];
+            c.nw = s_nw[o]; c.ndx = s_nd[2 * o]; c.ndy = s_nd[2 * o + 1];
+            return c;
+        };
+        Ctx cx = fetch_ctx(cur.o);
+        for (int rd = 0; rd * SPB < slots; ++rd) {
+            const int o = cur.o, k = cur.k; const bool isnew = cur.isnew, on = cur.on;
+            uint32_t wd = cur.wd; double2 dd = cur.dd;
+            const size_t go = cur.go;
+            const Ctx c = cx;
+            if (rd > 0) flush_stores();
+            // more than 64 bullets in the wave: the next round's entries and context are fetched while this one is worked on
+            if ((rd + 1) * SPB < slots) { cur = fetch_slot(rd + 1); cx = fetch_ctx(cur.o); }
+            const int obx_o = sx16(c.ebw), oby_o = sy16(c.ebw);
+            int qx[NE], qy[NE], qa[NE];
+#pragma unroll
+            for (int q = 0; q < NE; ++q) {
+                qx[q] = int(c.pq[q] & 0x7FFu); qy[q] = int((c.pq[q] >> 11) & 0x3FFu); qa[q] = -int((c.pq[q] >> 21) & 1u);
+            }
+            if (isnew) { wd = c.nw; dd = make_double2(c.ndx, c.ndy); }
+            const int age0 = bullet_age(wd);
+            const int lvm = (on && age0 != int(TOMBSTONE_AGE)) ? -1 : 0;         // a tombstone (plane hit last call) is dropped
+            const int bx = int(double(bullet_x(wd)) + dd.x);                    // truncation toward zero
+            const int by = int(double(bullet_y(wd)) + dd.y);
+            const int age = age0 + 1;
+            const int missm = ((bx | (FIELD_W - bx) | by | (FIELD_H - by) | (11 - age)) >> 31);
+            const int dxb = bx - obx_o, dyb = by - oby_o;
+            const int basem = ~(((dxb + 33) | (33 - dxb) | (dyb + 32) | (31 - dyb)) >> 31) & ~missm;
+            uint32_t m = 0;
+#pragma unroll
+            for (int q = 0; q < NE; ++q) {
+                const int dxp = bx - qx[q], dyp = by - qy[q];
+                const int pm = ~(((dxp + 27) | (27 - dxp) | (dyp + 25) | (24 - dyp)) >> 31) & qa[q];
+                m |= uint32_t(pm) & (1u << q);
+            }
+            const int gonem = (missm | basem) & lvm;
+            const int keepm = lvm & ~gonem;
+            m &= uint32_t(keepm);
+            // One LDS add per slot hands the outcome to the owner: survivor bit k | misses << 16 | base hits << 24 (each entry adds
+            // its bit once, so the add is an OR there).  Entries below k of the same owner sit in earlier slots -- an earlier round
+            // or lower lanes of this one -- and their adds are done when the word is read back: list position of a survivor =
+            // number of survivor bits below k.
+            const uint32_t add = (uint32_t(keepm & 1) << k) | (uint32_t(missm & lvm & 1) << 16) | (uint32_t(basem & lvm & 1) << 24);
+            if (add) __hip_atomic_fetch_add(&s_agg[o], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int ps = __popc(s_agg[o] & ((1u << k) - 1u));
+            st_on = keepm != 0; st_dd = isnew || ps != k; st_go = go; st_ps = ps; st_w = pack_bullet(bx, by, age); st_d = dd;
+            if (__any(m != 0u)) {                        // wave-uniform and rare: a bullet overlaps a live enemy plane
+                any_hit = true;
+                if (m != 0u) {
+                    __hip_atomic_fetch_or(&s_ov[o], (unsigned long long)(m) << (age * FW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_or(&s_pm[o], (unsigned long long)(ps) << (4 * age), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        if (slots > 0) flush_stores();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t agg = s_agg[tid];
+        nmiss = int((agg >> 16) & 0xFFu); nbase = int((agg >> 24) & 0xFFu); pos = __popc(agg & 0xFFFFu);
+        if (any_hit) {
+            ovl[0] = s_ov[tid]; posmap = s_pm[tid];
+            s_ov[tid] = 0ull; s_pm[tid] = 0ull;
+        }
+        if (N != 1 && nbase) __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)(&s_bhit[gl + team]), nbase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (phys) live = uint32_t(pos);
+    } else
     {
         const int physm = phys ? -1 : 0;
         // All item loads have long arrived (the observation geometry ran in between); say so once.  Loads and stores share
@@ -822,7 +1024,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
             const int age0 = bullet_age(iw[j]);                                     // a tombstone (plane hit last call) is dropped
             update_item(j, bullet_x(iw[j]), bullet_y(iw[j]), age0, idd[j], ((j < cnt0 && age0 != int(TOMBSTONE_AGE)) ? -1 : 0) & physm);
         }
-        // lists longer than NI: rare under sparse play, two more rounds when every agent fires every tick
+        // lists longer than NI: two more rounds when every agent fires every tick
         for (int base = NI; __any(cnt0 > base); base += NI) {
             uint32_t rw[NI]; double2 rd[NI];
 #pragma unroll
@@ -879,6 +1081,8 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
             }
         }
         // a bullet that hit a plane is gone: its list entry becomes a tombstone, dropped by the next call's compaction
+        // (packed pass: the survivor word was stored by ANOTHER lane of this wave; let it land before it is overwritten)
+        if (PACK && __any(consumed != 0u)) __builtin_amdgcn_s_waitcnt(0x0F70);
         while (consumed) {
             const int ag = __builtin_ctz(consumed);
             consumed &= consumed - 1u;
@@ -1188,7 +1392,7 @@ int launch_step(void* state, int64_t E, int n, const void* actions, int action_k
     a.act_tb = EA * (CONT ? (action_kind == BSX_ACT_F32 ? 12 : (action_kind == BSX_ACT_F64 ? 24 : 16)) : (action_kind == BSX_ACT_I32 ? 4 : 16));
     a.u_ts = EA;
     a.obs_ts = store_all ? EA * (3 * n + 2) : 0; a.rew_ts = store_all ? EA : 0; a.done_ts = store_all ? EA : 0;
-    const dim3 grid(grid_for(E, n, SPB)), block(SPB);
+    const dim3 grid(grid_for(E, n, SPB * WPB)), block(SPB * WPB);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (T == 0) {
         switch (n) {

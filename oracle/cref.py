@@ -73,6 +73,8 @@ class CRefBatch:
         sp = None if spawn is None else np.ascontiguousarray(spawn, np.int32)
         mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         self.lib.bsr_reset(self.h, _p(mk), _p(sp), self.seed, self.nonce, self.env_offset, _p(self.obs))
+        sel = slice(None) if mk is None else mk.astype(bool)     # the flags step() reports, as they stand after the reset
+        self.env_done[sel] = 0; self.winner[sel] = 0; self.done[sel] = 0
         return self.obs
 
     def step(self, actions, u=None, empty=False):
