@@ -21,11 +21,13 @@ Timing (median of repeats).  After the stagger, the W warm
 block of EXACTLY K steps is timed R times; each time
   (A) wall clock of each rank's K steps between barrier + torch.cuda.synchronize pairs, MAX over ranks -> ms_per_step, value
   (B) HIP events on the launch stream around the same K steps, recorded while an untimed K-step block queued just
-      before is still running, so the interval holds device time only (no host launch latency of the first graph)
-                                                                                                  -> roofline.avg_launch_us
-and the MEDIAN over the R repeats is reported (all samples are in the line).  The K steps are launched as replays of a
-HIP graph holding min(K, --graph-len) consecutive step() launches (the launch-bound inner loop of a rollout; `--mode
-eager` times one Python call per step instead).  Rank 0 prints ONE JSON line.
+      before is still running, so the interval holds device time only (no host launch latency of the first graph);
+      when K < --graph-len the bracket holds the whole action table (graph-len launches) as ONE graph, so that the
+      ~11 us a graph replay costs on top of its kernels is not booked on the kernel     -> roofline.avg_launch_us
+and the MEDIAN over the R repeats is reported (all samples are in the line).  The K steps are launched as replays of
+HIP graphs holding G = min(K, --graph-len) consecutive step() launches (the launch-bound inner loop of a rollout; `--mode
+eager` times one Python call per step instead); the action table always spans --graph-len ticks and a short block walks
+through it slice by slice, so the workload does not depend on K.  Rank 0 prints ONE JSON line.
 
 roofline: the step kernel is HBM-bound integer/fp64 work.  achieved = ALGORITHMIC bytes per launch (SURVEY.md section 8d:
 260 B per agent-step at 1v1, 289.3 B at 4v4, x E*A agent-steps per launch) / the kernel's average launch duration (B).
@@ -258,10 +260,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return t.tolist()
 
-    def timed_blocks(run, K, R, restore=None):
+    def timed_blocks(run, K, R, restore=None, run_b=None, Kb=None):
         """-> (wall seconds per repeat, kernel ms per launch per repeat); see the module docstring (A), (B).
-        restore: a recorded trajectory is rewound before every block (its device copy is what keeps the queue busy in (B))."""
+        restore: a recorded trajectory is rewound before every block (its device copy is what keeps the queue busy in (B)).
+        run_b / Kb: (B) brackets Kb >= 100 launches -- the K-step block repeated inside ONE graph -- when K itself is shorter than
+        that, so that the per-replay cost of a short graph (~11 us) is not booked on the kernel."""
         walls, kms = [], []
+        if run_b is None:
+            run_b, Kb = run, K
         for _ in range(R):
             if restore:
                 restore()
@@ -274,13 +280,13 @@ def main():
             if restore:
                 restore()
             else:
-                run(K)                                      # untimed: keeps the device busy while the events and the next block are queued
+                run_b(Kb)                                   # untimed: keeps the device busy while the events and the next block are queued
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-            run(K)
+            run_b(Kb)
             ev1.record()
             torch.cuda.synchronize(dev)
-            kms.append(ev0.elapsed_time(ev1) / K)
+            kms.append(ev0.elapsed_time(ev1) / Kb)
         return max_over_ranks(walls), max_over_ranks(kms)
 
     def ramp(run, ms, K):
@@ -347,22 +353,38 @@ def main():
             live = round(sum(lv) / len(lv), 3)
             restore = lambda: env.load_state_dict(snap)     # noqa: E731
             restore()
+        # The action table always spans TT >= graph_len ticks (a multiple of G), whatever K is: a short block (the driver's
+        # --steps 20) walks through it slice by slice, so the games see the same 100-tick action cycle as in a long run
+        NG = max(1, graph_len // G) if mix != "dense" else 1
+        TT = NG * G
+        if mix == "dense":
+            pass
         elif continuous:
-            actions = (hashed_bits(G, lo, lo + E, A, 3, 1234, dev).to(torch.float32) * (2.0 / 2147483648.0) - 1.0).contiguous()
+            actions = (hashed_bits(TT, lo, lo + E, A, 3, 1234, dev).to(torch.float32) * (2.0 / 2147483648.0) - 1.0).contiguous()
         elif mix == "uniform":
-            actions = (hashed_bits(G, lo, lo + E, A, 1, 1234, dev)[..., 0] >> 29).to(torch.int32).contiguous()
+            actions = (hashed_bits(TT, lo, lo + E, A, 1, 1234, dev)[..., 0] >> 29).to(torch.int32).contiguous()
         else:
-            actions = torch.full((G, E, A), 0 if mix == "forward" else 1, device=dev, dtype=torch.int32)
+            actions = torch.full((TT, E, A), 0 if mix == "forward" else 1, device=dev, dtype=torch.int32)
         if mix != "dense" and do_stagger and not args.no_stagger:
-            stagger(env, lambda k: env.step_batch(actions[k % G]))
+            stagger(env, lambda k: env.step_batch(actions[k % TT]))
+        run_b, Kb = None, None
+        pos = [0]                                           # which G-tick slice of the table comes next
         if mode == "graph":
-            graph, _ = env.capture_steps(actions)
+            graphs = [env.capture_steps(actions[i * G:(i + 1) * G])[0] for i in range(NG)]
+            graph = graphs[0]
 
             def run(steps):
                 for _ in range(steps // G):
-                    graph.replay()
+                    graphs[pos[0] % NG].replay()
+                    pos[0] += 1
                 for t in range(steps % G):
-                    env.step_batch(actions[t])
+                    env.step_batch(actions[(pos[0] % NG) * G + t])
+            if NG > 1:                                      # short blocks: the event bracket holds the whole table as ONE graph (timed_blocks)
+                graph_b, _ = env.capture_steps(actions)
+                Kb = TT
+
+                def run_b(steps):
+                    graph_b.replay()
         elif mode == "many":
             # K ticks as K/G multi-tick launches (bsx_step_many_*): every tick's obs / rew / done go to their own slice of
             # [G, E, A, ...] buffers, nothing is skipped or overwritten within a launch
@@ -372,23 +394,25 @@ def main():
 
             def run(steps):
                 for _ in range(steps // G):
-                    env.step_many(actions, store=True, out=outs)
+                    env.step_many(actions[(pos[0] % NG) * G:(pos[0] % NG + 1) * G], store=True, out=outs)
+                    pos[0] += 1
                 r = steps % G
                 if r:
                     env.step_many(actions[:r], store=True, out=tuple(o[:r] for o in outs))
         else:
             def run(steps):
                 for t in range(steps):
-                    env.step_batch(actions[t % G])
+                    env.step_batch(actions[pos[0] % TT])
+                    pos[0] += 1
         if not restore:
             run(W)
             ramp(run, args.ramp_ms, K)
         else:
             ramp(lambda k: (restore(), graph.replay()), args.ramp_ms, K)
-        walls, kms = timed_blocks(run, K, R, restore)
+        walls, kms = timed_blocks(run, K, R, restore, run_b, Kb)
         if live is None and E * A <= (1 << 22):
             live = round(float(env.export_state(("bl_live",))["bl_live"].float().sum()) / (E * A), 3)
-        return dict(env=env, walls=walls, kms=kms, G=G, live=live)
+        return dict(env=env, walls=walls, kms=kms, G=G, live=live, Kb=Kb or K)
 
     def kernel_name(n, continuous, many):
         return f"bsx_step_kernel<{n if n <= 4 else 0},{'true' if continuous else 'false'},{'true' if many else 'false'},false>"
@@ -497,7 +521,7 @@ def main():
                        "rehearsal_all_ranks_on_device0": bool(args.rehearse_on_device0) or None},
             "timing": {"repeats": len(head["walls"]), "statistic": "median", "ramp_ms": args.ramp_ms,
                        "ms_per_step_samples": [round(w / K * 1e3, 6) for w in head["walls"]],
-                       "avg_launch_us_samples": [round(k * 1e3, 3) for k in head["kms"]],
+                       "avg_launch_us_samples": [round(k * 1e3, 3) for k in head["kms"]], "launches_per_event_bracket": head["Kb"],
                        "note": "ms_per_step: wall clock around K steps between barrier+synchronize pairs (at K = 20 the ~30 us of "
                                "synchronisation are 15 % of the block); avg_launch_us: HIP events around the same K steps queued behind "
                                "an untimed block, device time only"},

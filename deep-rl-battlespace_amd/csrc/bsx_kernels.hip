@@ -87,6 +87,18 @@ constexpr bool PACK_BULLETS = true;
 #endif
 #define BSX_LDS(T, arr) ((__attribute__((address_space(3))) T*)(uintptr_t)(arr))
 
+// The per-step kernel's STATE stores (plane / game records, bullet entries) can leave non-temporal as well -- the next launch
+// finds the L2 invalidated anyway.  Measured (same box, A/B): 65 536 x 4v4 28.6 -> 27.8 us, but 65 536 x 1v1 8.22 -> 8.44 and
+// 1 M x 1v1 73.4 -> 74.5: used for team sizes >= 2 only (NT_STATE below), never inside a multi-tick launch (the same wave reads
+// its bullet rows back one tick later).
+typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+template <bool NT, class T> __device__ inline void st_store(T* p, T v) {
+    if (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+__device__ inline v4u_t as_v4u(uint4 v) { return v4u_t{v.x, v.y, v.z, v.w}; }
+
 constexpr int FIELD_W = 1200, FIELD_H = 800;      // sprites.py:9-10
 constexpr int PLANE_HW = 25, PLANE_HH = 24;        // 50x48 sprite, half sizes (w>>1, h>>1)
 constexpr int PLANE_HP = 4;                        // battle_env.py:92
@@ -393,6 +405,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // dispatcher preloads into SGPRs (-amdgpu-kernarg-preload-count), so that a wave's first loads need nothing from the
     // kernarg segment and do not queue behind its cold scalar-cache fetch.
     STAMP(8);                                            // diagnostic builds: kernel entry, before any kernarg load
+    constexpr bool NT_STATE = !MULTI && N >= 2;
     constexpr int WAVES = ACTOR ? group_width(N > 0 ? N : 1) / 2 : WPB;
     const int n = (N > 0) ? N : p.n;
     const int A = 2 * n;
@@ -748,7 +761,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         double sn, cs;
         sincos(-(bdir * DEG2RAD), &sn, &cs);
         nd = make_double2(BULLET_STEP * cs, BULLET_STEP * sn);
-        p.st.bdir[size_t(ks) * EAt + gt] = bdir;       // ring by birth tick: never moves, read only by bsx_export_state
+        st_store<NT_STATE>(&p.st.bdir[size_t(ks) * EAt + gt], bdir);       // ring by birth tick: never moves, read only by bsx_export_state
     }
     if constexpr (PACK) {                                // this call's shot as the work slot will read it: list word (age 0) + step
         s_nw[tid] = pack_bullet(x, y, 0);
@@ -931,8 +944,8 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         auto flush_stores = [&]() {
             if (st_on) {
                 const size_t off = size_t(st_ps) * EAt + st_go;
-                p.st.bxy[off] = st_w;
-                if (st_dd) p.st.bd[off] = st_d;                                  // the entry moved down (or is new): its step moves with it
+                st_store<NT_STATE>(&p.st.bxy[off], st_w);
+                if (st_dd) st_store<NT_STATE>(reinterpret_cast<v2d_t*>(&p.st.bd[off]), v2d_t{st_d.x, st_d.y});   // the entry moved down (or is new): its step moves with it
             }
         };
         // what a slot needs from its owner's side of the game, read from the wave's LDS block: enemy base, enemy planes (post-move
@@ -1130,7 +1143,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     const bool last_tick = !MULTI || tk == p.T - 1;
     if (valid) {
         if (MULTI ? last_tick : (mode == M_PHYS || mode == M_RESET))
-            reinterpret_cast<uint4*>(p.st.plane)[gt] = pack_plane(x, y, live, hp, dir);
+            st_store<NT_STATE>(reinterpret_cast<v4u_t*>(p.st.plane) + gt, as_v4u(pack_plane(x, y, live, hp, dir)));
         out_store(&rew_t[gt], float(rew));
         out_store(&done_t[gt], er.done ? uint8_t(1) : uint8_t(alive ? 0 : 1));
     }
@@ -1181,7 +1194,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     }
     if (valid) {
         if (a == 0) {
-            if (MULTI ? last_tick : (mode != M_INERT)) reinterpret_cast<uint4*>(p.st.env)[e] = pack_env(er);
+            if (MULTI ? last_tick : (mode != M_INERT)) st_store<NT_STATE>(reinterpret_cast<v4u_t*>(p.st.env) + e, as_v4u(pack_env(er)));
             if (cnt_delta.x) {                           // game over: rare read-modify-write of the counters
                 int4 cnt = p.st.cnt[e];
                 cnt.x += cnt_delta.x; cnt.y += cnt_delta.y; cnt.z += cnt_delta.z; cnt.w += cnt_delta.w;

@@ -1,23 +1,40 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): the evidence bundle for one measurement series.
-#   tools/profile_round.sh <tag>      e.g. r01_b
-# 1) plain bench lines (C2 graph + cpu baseline, C3, 1M, eager)   2) rocprofv3 --kernel-trace --stats of the default
-# bench command   3) separate --pmc passes for FETCH_SIZE and WRITE_SIZE (never combined with other trace domains).
-# Output: gpurun_out/<tag>/...; copy what should be judged into profiles/ with tools/collect_profile.py.
+#   tools/profile_round.sh <tag>      e.g. r02_a
+# 1) plain bench lines (default run with every workload; the driver's `--steps 20 --warmup 5` form)
+# 2) rocprofv3 --kernel-trace --stats of both forms (kernel summary CSV)
+# 3) per workload, separate --pmc passes for FETCH_SIZE and WRITE_SIZE (never combined with other trace domains), plus SQ_* / TCC
+#    passes for the headline.  Output: gpurun_out/<tag>/...; condensed into profiles/ by tools/collect_profile.py <tag>.
+# A step that times out stops the script: nothing else touches the GPU afterwards.
 set -e
-cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 T=${1:-rXX}
 O=gpurun_out/$T
 mkdir -p $O
-timeout -k 10 300 python bench.py > $O/bench_C2.json
-timeout -k 10 200 python bench.py --mode eager --no-cpu-baseline --no-other-workloads > $O/bench_C2_eager.json
-timeout -k 10 200 python bench.py --n-agents 4 --steps 1000 --warmup 100 --no-cpu-baseline --no-other-workloads > $O/bench_C3.json
-timeout -k 10 200 python bench.py --steps 400 --warmup 50 --no-cpu-baseline --no-other-workloads --envs-per-gpu 1048576 > $O/bench_1M.json
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline --no-other-workloads > $O/bench_C2_under_rocprof.json 2> $O/stats.err
-P="python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-other-workloads --mode eager"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $P > /dev/null 2> $O/pmc_fetch.err
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $P > /dev/null 2> $O/pmc_write.err
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq -- $P > /dev/null 2> $O/pmc_sq.err
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_tcc -- $P > /dev/null 2> $O/pmc_tcc.err
-echo profile_round done
+B="--no-cpu-baseline --no-other-workloads"
+echo "[$(date +%T)] bench lines"
+timeout -k 10 400 python bench.py > $O/bench_default.json
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $O/bench_steps20.json
+echo "[$(date +%T)] rocprof stats"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py $B > $O/bench_C2_under_rocprof.json 2> $O/stats.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats20 -- python bench.py --steps 20 --warmup 5 $B > $O/bench_steps20_under_rocprof.json 2> $O/stats20.err
+pmc() {   # key, counters, bench args...
+  local key=$1 ctr=$2; shift 2
+  echo "[$(date +%T)] pmc $key $ctr"
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $O/pmc_${key}_$(echo $ctr | cut -d' ' -f1) -- python bench.py --steps 300 --warmup 30 --repeats 2 $B "$@" > /dev/null 2> $O/pmc_${key}.err
+}
+for spec in "E65536_n1|--mode eager" "E65536_n4|--mode eager --n-agents 4" "E1048576_n1|--mode eager --envs-per-gpu 1048576 --steps 100" \
+            "E65536_n1_dense|--action-mix dense" "E65536_n1_cont|--mode eager --continuous" "E65536_n4_cont|--mode eager --continuous --n-agents 4" \
+            "E65536_n1_many|--mode many"; do
+  key=${spec%%|*}; args=${spec#*|}
+  pmc $key FETCH_SIZE $args
+  pmc $key WRITE_SIZE $args
+done
+pmc E65536_n1 "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" --mode eager
+pmc E65536_n1 "TCC_HIT_sum TCC_MISS_sum" --mode eager
+pmc E65536_n4 "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" --mode eager --n-agents 4
+# condense on the box (the raw counter CSVs are tens of MB; only summaries travel back), then drop the raw directories
+python tools/collect_profile.py $T --on-box > $O/collect.log 2>&1 || cat $O/collect.log
+for d in $O/pmc_*/ $O/stats $O/stats20; do rm -rf $d; done
+for f in $O/*.err; do [ -s $f ] && { echo "== $f"; tail -3 $f; }; done
+echo "[$(date +%T)] profile_round done"
