@@ -45,7 +45,8 @@ constexpr int SPB = 64;    // step kernel: a game never spans a wavefront, so th
 constexpr int WPB = BSX_X_WPB;
 
 // Timing-only ablation mask for profiling builds (hipcc -DBSX_DIAG=<bits>; results are WRONG with any bit set):
-// 1 = skip observation math, 2 = skip the bullet loop, 4 = skip the ordered resolve.  The product build has 0.
+// 1 = skip observation math, 2 = skip the bullet loop, 4 = skip the ordered resolve, 8 = no Philox draw for the shot's jitter,
+// 16 = fast float sincos for the shot.  The product build has 0.
 #ifndef BSX_DIAG
 #define BSX_DIAG 0
 #endif
@@ -502,6 +503,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // trip, and the inputs of tick t+1 are fetched while tick t computes.  Bullet lists and counters go to memory every
     // tick, the plane and game records once, after the last one.
     int x = 0, y = 0, hp = 0, games = 0;
+    int4 cnt4 = make_int4(0, 0, 0, 0);                   // my game's counters (games, ties, red wins, blue wins): loaded with the other T0 words
     uint32_t live = 0;
     double dir = 0.0;
     EnvU er = {};
@@ -572,7 +574,8 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // (the kernel is latency-bound at 65 536 games -- 2 waves per SIMD -- so memory-level parallelism is what pays)
     if (!MULTI || tk == 0) {
         const uint4 erw = reinterpret_cast<const uint4*>(env_)[ec];
-        games = reinterpret_cast<const int*>(cnt_)[4 * ec];   // games finished so far = episode id of the RNG streams
+        cnt4 = cnt_[ec];                                 // .x = games finished so far = episode id of the RNG streams
+        games = cnt4.x;
         const uint4 prw = reinterpret_cast<const uint4*>(plane_)[gt];
         if (!MULTI) load_inputs(0, rin);
         unpack_plane(prw, x, y, live, hp, dir);
@@ -747,25 +750,28 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        cur = fetch_slot(0);
-        if (MULTI && !ACTOR && tk + 1 < p.T) load_inputs(tk + 1, rin_next);   // behind this tick's own loads
     }
     double2 nd = make_double2(0.0, 0.0);
     if (spawn) {
         double uu = uu_in;
-        if (!u_t) {
+        if (!u_t && !(DIAG & 8u)) {
             const uint4 r = draw4(seed_t, genv, STREAM_JITTER, uint32_t(games), (uint32_t(tick) << 8) | uint32_t(a));
             uu = uniform53(r.x, r.y);
         }
         const double bdir = d0 + (uu * 8.0 - 4.0);
         double sn, cs;
-        sincos(-(bdir * DEG2RAD), &sn, &cs);
+        if (DIAG & 16u) { float sf, cf; __sincosf(float(-(bdir * DEG2RAD)), &sf, &cf); sn = double(sf); cs = double(cf); }   // timing ablation: a few-instruction float sincos (directions right to ~1e-6, so the same bullet population)
+        else sincos(-(bdir * DEG2RAD), &sn, &cs);
         nd = make_double2(BULLET_STEP * cs, BULLET_STEP * sn);
         st_store<NT_STATE>(&p.st.bdir[size_t(ks) * EAt + gt], bdir);       // ring by birth tick: never moves, read only by bsx_export_state
     }
     if constexpr (PACK) {                                // this call's shot as the work slot will read it: list word (age 0) + step
         s_nw[tid] = pack_bullet(x, y, 0);
         s_nd[2 * tid] = nd.x; s_nd[2 * tid + 1] = nd.y;
+        // the first round's entries: requested HERE, behind the shot's Philox + sincos, which covered the slot table's LDS round
+        // trip; the loads themselves are covered by the move and the observation geometry
+        cur = fetch_slot(0);
+        if (MULTI && !ACTOR && tk + 1 < p.T) load_inputs(tk + 1, rin_next);   // behind this tick's own loads
     }
 
     if (mode == M_RESET) {
@@ -1195,10 +1201,9 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     if (valid) {
         if (a == 0) {
             if (MULTI ? last_tick : (mode != M_INERT)) st_store<NT_STATE>(reinterpret_cast<v4u_t*>(p.st.env) + e, as_v4u(pack_env(er)));
-            if (cnt_delta.x) {                           // game over: rare read-modify-write of the counters
-                int4 cnt = p.st.cnt[e];
-                cnt.x += cnt_delta.x; cnt.y += cnt_delta.y; cnt.z += cnt_delta.z; cnt.w += cnt_delta.w;
-                p.st.cnt[e] = cnt;
+            if (cnt_delta.x) {                           // game over: the counters were loaded with the game record, no second round trip
+                cnt4.x += cnt_delta.x; cnt4.y += cnt_delta.y; cnt4.z += cnt_delta.z; cnt4.w += cnt_delta.w;
+                p.st.cnt[e] = cnt4;
             }
             if (last_tick) {
                 if (p.env_done) p.env_done[e] = uint8_t(er.done);
@@ -1436,9 +1441,9 @@ int bsx_abi_version(void) { return BSX_ABI_VERSION; }
 
 int bsx_build_flags(void) {
 #ifdef BSX_STAMPS
-    return int(DIAG & 0xFu) | 0x100;
+    return int(DIAG & 0xFFu) | 0x100;
 #else
-    return int(DIAG & 0xFu);
+    return int(DIAG & 0xFFu);
 #endif
 }
 
