@@ -32,8 +32,10 @@ through it slice by slice, so the workload does not depend on K.  Rank 0 prints 
 roofline: the step kernel is HBM-bound integer/fp64 work.  achieved = ALGORITHMIC bytes per launch (SURVEY.md section 8d:
 260 B per agent-step at 1v1, 289.3 B at 4v4, x E*A agent-steps per launch) / the kernel's average launch duration (B).
 peak = 8 TB/s.  frac = achieved / peak is the contract figure; frac_on_traffic beside it is the same duration against the
-bytes that actually reached HBM (PMC FETCH_SIZE x 2 + WRITE_SIZE from a separate rocprofv3 pass of this workload, read
-from profiles/traffic.json -- `traffic_source` says which series; the counters cannot be read from inside this process).
+bytes that actually reached HBM: PMC FETCH_SIZE x 2 + WRITE_SIZE, collected by two child runs of this script under
+`rocprofv3 --kernel-trace --pmc` (one counter per pass, as MI355X_MICROARCH.md prescribes) right after the timed region --
+the counters cannot be read from inside this process; `traffic_source` says so, or names the profiles/traffic.json
+series that was used instead (`--no-live-traffic`, no rocprofv3, N > 1; always for `other_workloads`).
 cpu_baseline: the CPU oracle (oracle/battlespace_ref.py, the scalar Python restatement of the reference's step()) on
 configs[0] -- 1 game of 1v1, the same uniform random actions, reset on done -- timed on one host core of this box.
 """
@@ -144,6 +146,49 @@ def hashed_bits(T, lo, hi, A, k, seed, device):
     return (x >> 20) & 0x7FFFFFFF
 
 
+def live_traffic(args, kernel, grid_threads):
+    """HBM bytes per launch of the headline kernel, measured NOW: two child runs of this script under `rocprofv3 --kernel-trace
+    --pmc <counter>` -- FETCH_SIZE and WRITE_SIZE in SEPARATE passes, nothing else traced, as MI355X_MICROARCH.md's HBM section
+    prescribes -- on the same workload (eager launches, so every launch is its own dispatch record), per-launch mean over the
+    second half of the run.  Units are KiB; on gfx950 FETCH_SIZE counts half of a wide coalesced read stream, so the read side is
+    doubled (calibrated on this kernel in round 1, profiles/r01_traffic_calibration.json).  Returns (bytes, detail) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    many = args.mode == "many"
+    got = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="bsx_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+               "--steps", "100" if many else "200", "--warmup", "20", "--repeats", "1", "--ramp-ms", "0", "--mode", "many" if many else
+               ("graph" if args.action_mix == "dense" else "eager"), "--envs-per-gpu", str(args.envs_per_gpu), "--n-agents", str(args.n_agents),
+               "--action-mix", args.action_mix, "--no-cpu-baseline", "--no-other-workloads", "--no-live-traffic"]
+        if args.continuous:
+            cmd.append("--continuous")
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+            files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {ctr} pass failed (rc {r.returncode}): {(r.stderr or '')[-160:]}"
+            vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                    if row["Counter_Name"] == ctr and kernel.replace(",", ", ") in row["Kernel_Name"] and int(row["Grid_Size"]) == grid_threads]
+            vals = vals[len(vals) // 2:]
+            if not vals:
+                return None, f"no {kernel} launches in the {ctr} pass"
+            got[ctr] = (sum(vals) / len(vals), len(vals))
+        except Exception as exc:
+            return None, f"{type(exc).__name__}: {str(exc)[:160]}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    f_kib, w_kib = got["FETCH_SIZE"][0], got["WRITE_SIZE"][0]
+    ticks = 100 if many else 1
+    return int((2 * f_kib + w_kib) * 1024 / ticks), {"fetch_size_kib_raw": round(f_kib, 1), "write_size_kib_raw": round(w_kib, 1),
+                                                      "launches_averaged": got["FETCH_SIZE"][1], "ticks_per_launch": ticks}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,6 +208,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-stagger", action="store_true", help="leave all games on the same clock (time-limit ties in lock-step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the extra (non-headline) measurements")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) that measure the headline's HBM bytes; "
+                         "roofline.traffic then comes from profiles/traffic.json")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="process-group backend for the barrier / timing reduction (nccl = RCCL; gloo only to rehearse N>1 on a 1-GPU box)")
     ap.add_argument("--rehearse-on-device0", action="store_true",
@@ -509,6 +557,22 @@ def main():
         key = f"E{E}_n{n}" + ("_cont" if args.continuous else "") + ("_dense" if args.action_mix == "dense" else "") + ("_many" if many else "")
         te = traffic_entry(key) if args.action_mix in ("uniform", "dense") else None
         traffic = te["hbm_bytes_per_tick" if many else "hbm_bytes_per_launch"] if te else None
+        tsrc = (f"profiles/traffic.json[{key}] (series {te.get('series')}): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                "workload, read side x2 (MI355X_MICROARCH.md); a constant from that profile, not measured by this run") if te else None
+        tdetail = None
+        if world == 1 and not args.no_live_traffic:
+            Gw = 2
+            while Gw < A:
+                Gw *= 2
+            grid_threads = ((E + 64 // Gw - 1) // (64 // Gw)) * 64
+            live_b, info = live_traffic(args, kernel_name(n, args.continuous, many), grid_threads)
+            if live_b is not None:
+                traffic, tdetail = live_b, info
+                tsrc = ("measured by this run: two child passes of this script under rocprofv3 --kernel-trace --pmc (FETCH_SIZE, WRITE_SIZE "
+                        "separately), KiB units, read side x2 (MI355X_MICROARCH.md), mean per launch" +
+                        (f"; profiles/traffic.json[{key}] (series {te.get('series')}) holds {te['hbm_bytes_per_tick' if many else 'hbm_bytes_per_launch']}" if te else ""))
+            else:
+                tsrc = (tsrc or "none") + f" [live measurement unavailable: {info}]"
         mixname = {"uniform": "uniform random", "forward": "all-forward", "shoot": "all-shoot", "dense": "recorded keep-shooting"}[args.action_mix]
         out = {
             "metric": "agent-steps/sec", "value": round(agent_steps / wall, 1), "unit": "agent-steps/s",
@@ -528,8 +592,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "frac_on_traffic": round(traffic / (km * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
-                         "traffic_source": f"profiles/traffic.json[{key}] (series {te.get('series')}): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                           "workload, read side x2 (MI355X_MICROARCH.md); a constant from that profile, not measured by this run" if te else None,
+                         "traffic_source": tsrc, "traffic_detail": tdetail,
                          "kernel": kernel_name(n, args.continuous, many), "avg_launch_us": round(km * 1e3, 3),
                          "algorithmic_bytes_per_launch": round(bytes_per_launch), "bytes_per_agent_step": round(b_alg(n, args.continuous), 2),
                          # SURVEY.md section 8d asks for these beside it: the API-only lower bound (action in; obs, reward, done out)

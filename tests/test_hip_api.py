@@ -120,7 +120,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "300", "--warmup", "30", "--no-cpu-baseline",
-                          "--no-other-workloads"], capture_output=True, text=True, timeout=300, cwd=root)
+                          "--no-other-workloads", "--no-live-traffic"], capture_output=True, text=True, timeout=300, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
@@ -134,3 +134,22 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert d["value"] > 1e9 and abs(d["value"] - 65536 * 2 * 300 / (d["ms_per_step"] * 1e-3 * 300)) / d["value"] < 1e-3
+
+
+def test_bench_measures_the_headline_hbm_traffic_live():
+    """roofline.traffic is measured by the run itself: bench.py re-runs its workload in two child passes under `rocprofv3
+    --kernel-trace --pmc` (FETCH_SIZE, WRITE_SIZE separately) and reports (2 x fetch + write) KiB per launch, with the source
+    spelled out; frac_on_traffic follows from it."""
+    import json, os, shutil, subprocess, sys
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("rocprofv3 not installed")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "200", "--warmup", "20", "--repeats", "2", "--no-cpu-baseline",
+                          "--no-other-workloads"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    r = d["roofline"]
+    assert r["traffic_detail"] is not None and r["traffic_source"].startswith("measured by this run"), r["traffic_source"]
+    assert 8e6 < r["traffic"] < r["algorithmic_bytes_per_launch"]          # sparse bullets: less than the 12-slot algorithmic count
+    assert abs(r["traffic"] - (2 * r["traffic_detail"]["fetch_size_kib_raw"] + r["traffic_detail"]["write_size_kib_raw"]) * 1024) < 2048
+    assert abs(r["frac_on_traffic"] - r["traffic"] / (r["avg_launch_us"] * 1e-6) / 1e9 / r["peak"]) < 1e-3 and r["frac_on_traffic"] < r["frac"]

@@ -25,7 +25,7 @@ def _bench(args, timeout=600):
 
 
 def test_two_rank_job_equals_the_single_process_job(tmp_path):
-    common = ["--steps", "150", "--warmup", "10", "--repeats", "2", "--ramp-ms", "0", "--no-cpu-baseline", "--no-other-workloads"]
+    common = ["--steps", "150", "--warmup", "10", "--repeats", "2", "--ramp-ms", "0", "--no-cpu-baseline", "--no-other-workloads", "--no-live-traffic"]
     d2, d1 = str(tmp_path / "two"), str(tmp_path / "one")
     two = _bench(["--gpus", "2", "--rehearse-on-device0", "--envs-per-gpu", "65536", "--digest-dir", d2, *common])
     one = _bench(["--gpus", "1", "--envs-per-gpu", "131072", "--digest-dir", d1, *common])

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 T=${1:-rXX}
 O=gpurun_out/$T
 mkdir -p $O
-B="--no-cpu-baseline --no-other-workloads"
+B="--no-cpu-baseline --no-other-workloads --no-live-traffic"   # (the runs below are themselves under rocprofv3: no nested passes)
 echo "[$(date +%T)] bench lines"
 timeout -k 10 400 python bench.py > $O/bench_default.json
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $O/bench_steps20.json
