@@ -1154,9 +1154,39 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         out_store(&done_t[gt], er.done ? uint8_t(1) : uint8_t(alive ? 0 : 1));
     }
     // observation row: a dead observer sees all -1, a dead enemy is [-1,-1,-1] (battle_env.py:215-218,235-242).
-    // Rows are staged in LDS ([lane][D], D odd -> conflict-free) and leave as coalesced 16-byte stores: the wave's rows
-    // are one contiguous block of global memory when every lane is an agent (G == A).
+    // Compile-time team sizes outside the fused rollout: the row leaves straight from registers, 16 bytes at a time plus a tail
+    // (rows are 4 (3n + 2) bytes apart, so the stores are only dword-aligned -- fine for global_store_dwordx4).  Round 1 staged
+    // rows in LDS to emit fully coalesced 16-byte stores; with non-temporal stores that transpose only costs: C2 8.21 -> 7.92 us,
+    // 4v4 28.0 -> 24.9 (-DBSX_X_LDSOBS builds it for A/B).  The fused rollout keeps its rows in LDS (the actor reads them there).
+#ifdef BSX_X_LDSOBS
+    constexpr bool DIRECT_OBS = false;
+#else
+    constexpr bool DIRECT_OBS = !ACTOR && N > 0;
+#endif
+    if constexpr (DIRECT_OBS) {
+        constexpr int D = 3 * N + 2;
+        float row[D];
+        row[0] = alive ? ob_d : -1.0f;
+        row[1] = alive ? ob_a : -1.0f;
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const bool on = alive && ((N == 1) ? (mode == M_PHYS ? nhp_ - nplane : nhp_) : s_hp[eb + j]) > 0;
+            row[2 + 3 * j] = on ? 1.0f : -1.0f;
+            row[3 + 3 * j] = on ? oe_d[j] : -1.0f;
+            row[4 + 3 * j] = on ? oe_a[j] : -1.0f;
+        }
+        if (valid) {
+            float* out = obs_t + gt * size_t(D);
+#pragma unroll
+            for (int i = 0; i + 4 <= D; i += 4) out_store(reinterpret_cast<v4f_t*>(out + i), v4f_t{row[i], row[i + 1], row[i + 2], row[i + 3]});
+            typedef float v2f_t __attribute__((ext_vector_type(2)));
+            if constexpr ((D & 3) >= 2) out_store(reinterpret_cast<v2f_t*>(out + (D & ~3)), v2f_t{row[D & ~3], row[(D & ~3) + 1]});
+            if constexpr ((D & 1) != 0) out_store(out + D - 1, row[D - 1]);
+        }
+    } else
     {
+        // Rows are staged in LDS ([lane][D], D odd -> conflict-free) and leave as coalesced 16-byte stores: the wave's rows
+        // are one contiguous block of global memory when every lane is an agent (G == A).
         const int D = 3 * n + 2;
         float* srow = &s_obs[tid * D];
         srow[0] = alive ? ob_d : -1.0f;
