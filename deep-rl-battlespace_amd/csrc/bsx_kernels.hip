@@ -10,15 +10,17 @@
 //   * lane = agent, lanes of one env are adjacent (group width G = next pow2 >= 2n, G <= 32), so an env never
 //     straddles a 64-wide wavefront and a workgroup is ONE wavefront: LDS hand-offs are wave-private, no s_barrier.
 //     Every per-agent array is struct-of-arrays indexed e*A + a: consecutive lanes touch consecutive 16-byte records.
-//   * the kernel is latency-bound at 65 536 games and issue-bound at a million, so: all independent loads go out in one
-//     batch as raw 16-byte words (clamped indices, no per-lane branches); the single dependent batch (heading-table
-//     entry, first four bullet-list entries) follows as soon as the plane record lands and is covered by the fp64
-//     observation math; predicates are integer sign masks, not SGPR lane masks.
-//   * an agent's bullets are a dense creation-ordered list (row j = j-th bullet of every agent), so sparse bullets still
-//     read contiguous rows; survivors are written back compacted.
-//   * post-move plane poses and hit points of the wave's envs are staged in LDS; each lane reads the opposing team's
-//     block from there for bullet overlap tests, the ordered hit resolve and the all-pairs range / angle-off
-//     observations; observation rows leave through LDS as coalesced 16-byte stores.
+//   * the kernel is issue- and boundary-bound at 65 536 games (two waves per SIMD) and issue-bound at a million, so: all
+//     independent loads go out in one batch as raw 16-byte words (clamped indices, no per-lane branches); the dependent loads
+//     (heading-table entry, bullet entries) are covered by the shot's Philox + sincos and the fp64 observation math; predicates
+//     are integer sign masks, not SGPR lane masks.
+//   * an agent's bullets are a dense creation-ordered list (row j = j-th bullet of every agent).  For team sizes 1 .. 4 the
+//     bullets of ALL lanes of a wave are updated in WORK SLOTS packed across the wavefront (entry-major, so a round's lanes read
+//     and write along rows): under sparse play one round of 64 slots instead of ~7 mostly-empty per-lane rounds; the outcome
+//     returns to the owner through one LDS add per slot, survivors are stored straight to their compacted position.
+//   * post-move plane poses and hit points are handed to the other planes of the game by cross-lane moves (1v1) or wave-private
+//     LDS (larger teams); the all-pairs range / angle-off geometry of a team pair is computed once per pair; observation rows
+//     leave straight from registers with the non-temporal hint (the fused rollout keeps them in LDS for the actor's MFMAs).
 //   * the ordered plane-hit resolve walks bullet ages oldest-first; a wavefront ballot skips ages at which no lane of
 //     the wave has a candidate (almost all of them), and group ballots give the "nobody left alive" test.
 //   * HBM-bound integer/fp64 work, no dense contraction: no MFMA.
