@@ -169,7 +169,7 @@ def live_traffic(args, kernel, grid_threads):
         if args.continuous:
             cmd.append("--continuous")
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=120)
             files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
             if r.returncode != 0 or not files:
                 return None, f"rocprofv3 --pmc {ctr} pass failed (rc {r.returncode}): {(r.stderr or '')[-160:]}"
