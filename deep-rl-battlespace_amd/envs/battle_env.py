@@ -151,8 +151,14 @@ class parallel_env:
         self._winner = torch.empty(E, dtype=torch.uint8, device=dev)
         self._u = None
         self._reset_nonce = 0
+        # raw pointers of the env-owned buffers (never re-allocated): one attribute read per call instead of a data_ptr() each
+        self._p_state, self._p_obs, self._p_rew, self._p_done = (t.data_ptr() for t in (self._state, self._obs, self._rew, self._done))
+        self._p_env_done, self._p_winner = self._env_done.data_ptr(), self._winner.data_ptr()
+        self._cfg_ref = ctypes.byref(self._cfg)
+        self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)   # the current stream's handle without building a Stream object
         with self._guard():
             _lib.check(self._lib.bsx_state_init(self._state.data_ptr(), E, n, self._stream()), "bsx_state_init")
+        self._done_bool = self._done.view(torch.bool)
         self._env_done.fill_(1)
         self._winner.zero_()
         self._done.fill_(1)
@@ -171,6 +177,8 @@ class parallel_env:
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
+        if self._raw_stream is not None:
+            return self._raw_stream(self.device.index)
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def _guard(self):
@@ -307,6 +315,12 @@ class parallel_env:
         values to use for this call's shots instead of the generator.  Returns the env-owned tensors
         (obs [E, A, D] f32, rew [E, A] f32, done [E, A] bool), overwritten by the next call; copy=True returns fresh
         tensors instead (the reference hands out fresh arrays every step, battle_env.py:374-381)."""
+        if (u is None and not self._mirror and not copy and torch.is_tensor(actions) and actions.dtype == torch.int32
+                and not self.continuous_actions and actions.device == self.device and actions.shape == self._obs.shape[:2]
+                and actions.is_contiguous()):
+            # the common batched call: int32 [E, A] on the env's device -- nothing to convert, nothing to mirror
+            self._launch(actions.data_ptr(), _lib.ACT_I32, False, None, self._p_obs, self._p_rew, self._p_done)
+            return self._obs, self._rew, self._done_bool
         act_t, kind, empty = self._pack_actions(actions)
         if u is None and self.rng == "python":
             u = self._draw_jitter(act_t, kind, empty)
@@ -332,10 +346,11 @@ class parallel_env:
         flags = (_lib.F_AUTO_RESET if self.auto_reset else 0) | (_lib.F_EMPTY_CALL if empty else 0)
         fn = self._lib.bsx_step_continuous if self.continuous_actions else self._lib.bsx_step_discrete
         with self._guard():
-            _lib.check(fn(self._state.data_ptr(), self.n_envs, self.n_agents, act_ptr, kind, u_ptr,
-                          obs_ptr, rew_ptr, done_ptr, env_done_ptr if env_done_ptr is not None else self._env_done.data_ptr(),
-                          self._winner.data_ptr(),
-                          ctypes.byref(self._cfg), flags, self.seed, self.env_offset, self._stream()), "bsx_step")
+            rc = fn(self._p_state, self.n_envs, self.n_agents, act_ptr, kind, u_ptr, obs_ptr, rew_ptr, done_ptr,
+                    env_done_ptr if env_done_ptr is not None else self._p_env_done, self._p_winner,
+                    self._cfg_ref, flags, self.seed, self.env_offset, self._stream())
+        if rc:
+            _lib.check(rc, "bsx_step")
 
     def _check_action_series(self, actions):
         """actions for T calls: [T, E, A] int32 | [T, E, A, 4] float32 | [T, E, A, 3] float32/float64 (continuous) |
