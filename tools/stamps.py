@@ -49,9 +49,9 @@ if True:
         d = np.diff(s, axis=1)
         tot[:7] += d.mean(0); reps += 1
         span.append(((s[:, 7].max() - s[:, 0].min()), (s[:, 7] - s[:, 0]).mean(), (s[:, 0].max() - s[:, 0].min())))
-    names = ["T0 loads -> plane rec; issue T1", "classify, shot (philox, sincos), move, hand-off", "(moved into the phase above)", "obs geometry", "12-slot bullet loop", "resolve + rewards/finish", "stores"]
+    names = ["T0 loads -> plane record, heading-table request", "classify, slot table, shot (philox, sincos), move", "pose hand-off, staging", "obs geometry", "bullet rounds (packed pass, part 2)", "resolve + rewards / game end", "stores"]
     tot /= reps
-    print(f"E={E} n={n} waves={waves}; values are shader CYCLES x10 (s_memtime counts cycles)")
+    print(f"E={E} n={n} waves={waves}; s_memtime ticks, mean over waves (divide the printed value by 10 for shader cycles)")
     print(f"  {'kernel entry -> first kernarg use (p.E)':40s} {pre / reps * 10:9.1f} ns")
     for nme, v in zip(names, tot[:7]):
         print(f"  {nme:40s} {v*10:9.1f} ns")
