@@ -969,7 +969,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
             return c;
         };
         Ctx cx = fetch_ctx(cur.o);
-        for (int rd = 0; rd * SPB < slots; ++rd) {
+        auto do_round = [&](const int rd) {
             const int o = cur.o, k = cur.k; const bool isnew = cur.isnew, on = cur.on;
             uint32_t wd = cur.wd; double2 dd = cur.dd;
             const size_t go = cur.go;
@@ -1020,7 +1020,15 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
                     __hip_atomic_fetch_or(&s_pm[o], (unsigned long long)(ps) << (4 * age), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
-        }
+        };
+#ifdef BSX_X_NOPEEL
+        for (int rd = 0; rd * SPB < slots; ++rd) do_round(rd);
+#else
+        // the first round stands alone (under sparse play it is the only one in 85 % of the waves): straight-line code, no loop-carried
+        // copies of the prefetch registers
+        if (slots > 0) do_round(0);
+        for (int rd = 1; rd * SPB < slots; ++rd) do_round(rd);
+#endif
         if (slots > 0) flush_stores();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
