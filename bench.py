@@ -463,7 +463,7 @@ def main():
         return dict(env=env, walls=walls, kms=kms, G=G, live=live, Kb=Kb or K)
 
     def kernel_name(n, continuous, many):
-        return f"bsx_step_kernel<{n if n <= 4 else 0},{'true' if continuous else 'false'},{'true' if many else 'false'},false>"
+        return f"bsx_step_kernel<{n if n <= 4 else 0},{'true' if continuous else 'false'},{'true' if many else 'false'},false,false>"   # <N, CONT, MULTI, ACTOR, LG>
 
     def traffic_entry(key):
         try:

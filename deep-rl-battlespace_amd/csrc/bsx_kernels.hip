@@ -400,7 +400,10 @@ __device__ inline void obs_pair(int x, int y, double dir, int tx, int ty, float&
 // planes w and w + G/2 (tile 0 in its lower lane half's name, tile 1 in the upper's), lane l finishes row (game l & 31 of the
 // workgroup, that plane), and the arg-max travels back to the plane's own lane through LDS (one cross-lane move for 1v1).
 // Everything else stays private to a wave exactly as in the other variants: a wave still only touches its own games.
-template <int N, bool CONT, bool MULTI, bool ACTOR = false>
+// LG (discrete only): the actions are float32 [4] score vectors (arg-maxed here) instead of int32 indices -- a compile-time switch, so
+// that each encoding's kernel issues exactly its own action load in the first batch (an unconditional load of the unused encoding's
+// dummy line cost 1.6 % of the step; a load under a branch costs a second round trip, see load_inputs).
+template <int N, bool CONT, bool MULTI, bool ACTOR = false, bool LG = false>
 __global__ __launch_bounds__(SPB * (ACTOR ? group_width(N > 0 ? N : 1) / 2 : WPB)) __attribute__((amdgpu_waves_per_eu((ACTOR && N > 1) ? 2 : 1)))
 void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* const cnt_, const PlaneRec* const plane_, const void* const act_,
                      const int kind_, const StepArgs p) {
@@ -479,13 +482,11 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         const void* const at = MULTI ? static_cast<const void*>(static_cast<const char*>(act_) + int64_t(t) * p.act_tb) : act_;
         const double* const ut = (MULTI && p.u) ? p.u + int64_t(t) * p.u_ts : p.u;
         if (!CONT) {
-            // Both encodings are read by unconditional loads -- the one not in use from the heading table's first line (L1-hot) --
-            // because a load under a branch makes the compiler's wait-count pass drain EVERYTHING in flight before the other
-            // branch's load (it merges the register state of both paths): the action then cost a second full round trip.
-            const bool is_i32 = at && kind_ == BSX_ACT_I32, is_lg = at && kind_ != BSX_ACT_I32;
+            // one unconditional load (a load under a branch makes the compiler's wait-count pass drain EVERYTHING in flight before the
+            // other branch's load: the action then cost a second full round trip); an empty call reads a mapped dummy line
             const char* const dummy = reinterpret_cast<const char*>(env_);      // any mapped line will do: the first game record
-            r.ai = *reinterpret_cast<const int32_t*>(is_i32 ? static_cast<const char*>(at) + g * 4 : dummy);
-            r.lg = *reinterpret_cast<const float4*>(is_lg ? static_cast<const char*>(at) + g * 16 : dummy);
+            if constexpr (LG) r.lg = *reinterpret_cast<const float4*>(at ? static_cast<const char*>(at) + g * 16 : dummy);
+            else r.ai = *reinterpret_cast<const int32_t*>(at ? static_cast<const char*>(at) + g * 4 : dummy);
         } else if (at) {                                 // uniform branch
             if (kind_ == BSX_ACT_F32) {
                 const float* ap = static_cast<const float*>(at) + 3 * g;
@@ -515,7 +516,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         DecIn d = {-1, 0.0, 0.0, 0.0, 0.0};
         if (act_) {                                      // uniform branch
             if (!CONT) {
-                if (kind_ == BSX_ACT_I32) d.act = r.ai;
+                if constexpr (!LG) d.act = r.ai;
                 else {   // np.argmax: first maximum; a NaN compares as the maximum
                     const float v[4] = {r.lg.x, r.lg.y, r.lg.z, r.lg.w};
                     d.act = 0;
@@ -1425,6 +1426,17 @@ inline int grid_for(int64_t E, int n, int tpb = TPB) {
     return int((E + epb - 1) / epb);
 }
 
+template <bool CONT, bool MULTI, bool LG>
+void launch_for_n(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs& a) {
+    switch (n) {
+        case 1: hipLaunchKernelGGL((bsx_step_kernel<1, CONT, MULTI, false, LG>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        case 2: hipLaunchKernelGGL((bsx_step_kernel<2, CONT, MULTI, false, LG>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        case 3: hipLaunchKernelGGL((bsx_step_kernel<3, CONT, MULTI, false, LG>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        case 4: hipLaunchKernelGGL((bsx_step_kernel<4, CONT, MULTI, false, LG>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        default: hipLaunchKernelGGL((bsx_step_kernel<0, CONT, MULTI, false, LG>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+    }
+}
+
 // T == 0: one call (bsx_step_*);  T >= 1: bsx_step_many_* -- T calls in one launch, arrays with a leading T axis
 template <bool CONT>
 int launch_step(void* state, int64_t E, int n, const void* actions, int action_kind, const double* u, float* obs,
@@ -1452,22 +1464,13 @@ int launch_step(void* state, int64_t E, int n, const void* actions, int action_k
     a.obs_ts = store_all ? EA * (3 * n + 2) : 0; a.rew_ts = store_all ? EA : 0; a.done_ts = store_all ? EA : 0;
     const dim3 grid(grid_for(E, n, SPB * WPB)), block(SPB * WPB);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool lg = !CONT && action_kind == BSX_ACT_LOGITS_F32;
     if (T == 0) {
-        switch (n) {
-            case 1: hipLaunchKernelGGL((bsx_step_kernel<1, CONT, false>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-            case 2: hipLaunchKernelGGL((bsx_step_kernel<2, CONT, false>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-            case 3: hipLaunchKernelGGL((bsx_step_kernel<3, CONT, false>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-            case 4: hipLaunchKernelGGL((bsx_step_kernel<4, CONT, false>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-            default: hipLaunchKernelGGL((bsx_step_kernel<0, CONT, false>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-        }
+        if (lg) launch_for_n<CONT, false, !CONT>(n, grid, block, s, a);
+        else launch_for_n<CONT, false, false>(n, grid, block, s, a);
     } else {
-        switch (n) {
-            case 1: hipLaunchKernelGGL((bsx_step_kernel<1, CONT, true>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-            case 2: hipLaunchKernelGGL((bsx_step_kernel<2, CONT, true>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-            case 3: hipLaunchKernelGGL((bsx_step_kernel<3, CONT, true>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-            case 4: hipLaunchKernelGGL((bsx_step_kernel<4, CONT, true>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-            default: hipLaunchKernelGGL((bsx_step_kernel<0, CONT, true>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-        }
+        if (lg) launch_for_n<CONT, true, !CONT>(n, grid, block, s, a);
+        else launch_for_n<CONT, true, false>(n, grid, block, s, a);
     }
     return int(hipGetLastError());
 }

@@ -51,7 +51,7 @@ def kernel_filter(key):
     while G < 2 * n:
         G *= 2
     grid = ((E + 64 // G - 1) // (64 // G)) * 64
-    name = f"bsx_step_kernel<{n if n <= 4 else 0}, {'true' if cont else 'false'}, {'true' if many else 'false'}, false>"
+    name = f"bsx_step_kernel<{n if n <= 4 else 0}, {'true' if cont else 'false'}, {'true' if many else 'false'}, false, false>"   # <N, CONT, MULTI, ACTOR, LG>
     return name, grid, many
 
 
