@@ -7,7 +7,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/calib; mkdir -p $O
-P="python bench.py --steps 200 --warmup 30 --no-cpu-baseline --no-other-workloads --mode eager --envs-per-gpu 1048576 --action-mix forward"
+P="python bench.py --steps 200 --warmup 30 --no-cpu-baseline --no-other-workloads --no-live-traffic --mode eager --envs-per-gpu 1048576 --action-mix forward"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $P > /dev/null 2> $O/fetch.err
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- $P > /dev/null 2> $O/write.err
 python - <<PY
@@ -15,7 +15,7 @@ import csv, glob
 E = 1048576
 for name, exp in (("fetch", 72 * E), ("write", 100 * E)):
     f = glob.glob(f"$O/{name}/*/*_counter_collection.csv")[0]
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "bsx_step_kernel<1, false, false, false>" in r["Kernel_Name"] and int(r["Grid_Size"]) == 2 * E]
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "bsx_step_kernel<1, false, false, false, false>" in r["Kernel_Name"] and int(r["Grid_Size"]) == 2 * E]
     v = v[len(v) // 2:]          # steady state: after the first game's bullets... none here, but skip warm-up launches
     m = sum(v) / len(v) * 1024
     print(f"{name}: counter {m/1e6:.1f} MB per launch, known {exp/1e6:.1f} MB  -> true/counter = {exp/m:.3f}")

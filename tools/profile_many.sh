@@ -7,7 +7,7 @@ T=${1:-rXX}
 O=gpurun_out/$T
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-P="python bench.py --mode many --steps 1000 --warmup 100 --no-cpu-baseline --no-other-workloads"
+P="python bench.py --mode many --steps 1000 --warmup 100 --no-cpu-baseline --no-other-workloads --no-live-traffic"
 R="python tools/bench_rollout.py --one-launch --reps 10"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/many_stats -- $P > $O/bench_C2_many_under_rocprof.json 2> $O/many_stats.err
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/many_pmc_fetch -- $P > /dev/null 2> $O/many_pmc_fetch.err
