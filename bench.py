@@ -189,6 +189,33 @@ def live_traffic(args, kernel, grid_threads):
                                                       "launches_averaged": got["FETCH_SIZE"][1], "ticks_per_launch": ticks}
 
 
+def dropin_one_game(dev, calls=3000):
+    """BASELINE.json configs[0] through the DROP-IN surface: one game of 1v1 on the MI355X with the reference's return types (dicts
+    of numpy rows, Python numbers), stdlib `random` draws in the reference's order, uniform random actions, reset on done -- what a
+    maintainer who only swaps the import gets.  One upload, one launch, one download, one synchronisation per step()."""
+    import random
+    import numpy as np
+    import deep_rl_battlespace_amd as bsx
+    random.seed(1234)
+    env = bsx.parallel_env(n_agents=1, device=dev)
+    ids = env.possible_agents
+    acts = np.random.default_rng(1234).integers(0, 4, size=(calls + 200, 2)).tolist()
+    env.reset()
+    for k in range(200):
+        if env.env_done:
+            env.reset()
+        env.step({ids[0]: acts[k][0], ids[1]: acts[k][1]})
+    t0 = time.perf_counter()
+    for k in range(200, 200 + calls):
+        if env.env_done:
+            env.reset()
+        env.step({ids[0]: acts[k][0], ids[1]: acts[k][1]})
+    dt = time.perf_counter() - t0
+    return {"agent_steps_per_s": round(calls * 2 / dt, 1), "step_calls_per_s": round(calls / dt, 1), "us_per_call": round(dt / calls * 1e6, 1),
+            "calls": calls, "note": "1 game x 1v1 (configs[0]) on the GPU behind the reference's own surface; bounded by the per-call "
+                                    "host <-> device round trip, not by the kernel"}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -509,7 +536,7 @@ def main():
 
     # Not the headline: the same kernel on BASELINE.json configs[2], in the streaming regime (working set > Infinity Cache),
     # with many live bullets, with continuous actions, as a multi-tick launch, and with the policy in the loop (configs[4]).
-    others, multi, loop_sampling, rollouts = {}, None, None, None
+    others, multi, loop_sampling, rollouts, dropin = {}, None, None, None, None
     extra = world == 1 and not args.no_other_workloads and (n, E) == (1, 65536) and args.mode == "graph" \
         and args.action_mix == "uniform" and not args.continuous
     if extra:
@@ -548,6 +575,10 @@ def main():
             del m
             torch.cuda.empty_cache()
         rollouts = rollout_lines(dev, E, min(K, 320))
+        try:
+            dropin = dropin_one_game(dev)
+        except Exception as exc:
+            dropin = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
     if rank == 0:
         wall, km = statistics.median(head["walls"]), statistics.median(head["kms"])
         agent_steps = E * world * A * K
@@ -610,6 +641,7 @@ def main():
         out["multi_tick_launch"] = multi
         out["loop_incl_action_sampling"] = loop_sampling
         out["policy_rollouts"] = rollouts
+        out["drop_in_one_game"] = dropin
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

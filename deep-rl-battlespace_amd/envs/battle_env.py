@@ -151,6 +151,8 @@ class parallel_env:
         self._winner = torch.empty(E, dtype=torch.uint8, device=dev)
         self._u = None
         self._reset_nonce = 0
+        if self._compat:
+            self._init_compat_io()
         # raw pointers of the env-owned buffers (never re-allocated): one attribute read per call instead of a data_ptr() each
         self._p_state, self._p_obs, self._p_rew, self._p_done = (t.data_ptr() for t in (self._state, self._obs, self._rew, self._done))
         self._p_env_done, self._p_winner = self._env_done.data_ptr(), self._winner.data_ptr()
@@ -495,45 +497,109 @@ class parallel_env:
         return (self._agent_views(obs), self._agent_views(rew), self._agent_views(done),
                 {a: {} for a in self.possible_agents})
 
+    def _init_compat_io(self):
+        """Drop-in mode exchanges a few dozen bytes with the device per call: all outputs (obs, rew, done, env_done, winner) are
+        views of ONE device buffer and all inputs (the shots' random() values, the actions) of another, each mirrored by a pinned
+        host buffer -- one upload, one launch, one download, one synchronisation per step()."""
+        A, D, dev = self._A, self.obs_size, self.device
+        def carve(spec):
+            off, o = {}, 0
+            for name, nbytes in spec:
+                o = (o + 15) // 16 * 16
+                off[name] = (o, nbytes)
+                o += nbytes
+            return off, (o + 15) // 16 * 16
+        act_bytes = A * 3 * 8 if self.continuous_actions else A * 4
+        out_off, out_n = carve((("obs", A * D * 4), ("rew", A * 4), ("done", A), ("env_done", 1), ("winner", 1)))
+        in_off, in_n = carve((("u", A * 8), ("act", act_bytes)))
+        self._out_dev = torch.zeros(out_n, dtype=torch.uint8, device=dev)
+        self._in_dev = torch.zeros(in_n, dtype=torch.uint8, device=dev)
+        self._out_host = torch.zeros(out_n, dtype=torch.uint8).pin_memory()
+        self._in_host = torch.zeros(in_n, dtype=torch.uint8).pin_memory()
+
+        def view(buf, off, dtype, shape):
+            o, nb = off
+            return buf[o:o + nb].view(dtype).view(shape)
+        self._obs = view(self._out_dev, out_off["obs"], torch.float32, (1, A, D))
+        self._rew = view(self._out_dev, out_off["rew"], torch.float32, (1, A))
+        self._done = view(self._out_dev, out_off["done"], torch.uint8, (1, A))
+        self._env_done = view(self._out_dev, out_off["env_done"], torch.uint8, (1,))
+        self._winner = view(self._out_dev, out_off["winner"], torch.uint8, (1,))
+        hn = self._out_host.numpy()
+        self._ho_obs = hn[out_off["obs"][0]:][:A * D * 4].view(np.float32).reshape(A, D)
+        self._ho_rew = hn[out_off["rew"][0]:][:A * 4].view(np.float32)
+        self._ho_done = hn[out_off["done"][0]:][:A]
+        self._ho_flags = hn[out_off["env_done"][0]:]                    # [0] env_done ... winner at its own offset
+        self._ho_winner_at = out_off["winner"][0]
+        hi = self._in_host.numpy()
+        self._hi_u = hi[in_off["u"][0]:][:A * 8].view(np.float64)
+        if self.continuous_actions:
+            self._hi_act = hi[in_off["act"][0]:][:act_bytes].view(np.float64).reshape(A, 3)
+        else:
+            self._hi_act = hi[in_off["act"][0]:][:act_bytes].view(np.int32)
+        self._p_in_u = self._in_dev.data_ptr() + in_off["u"][0]
+        self._p_in_act = self._in_dev.data_ptr() + in_off["act"][0]
+
     def _step_compat(self, actions, u):
         ids = self.possible_agents
-        if self.continuous_actions and isinstance(actions, dict):      # battle_env.py:295-297 clips the caller's dict
+        if not isinstance(actions, dict):
+            raise TypeError("drop-in mode takes the reference's action dict {agent id: action} (battle_env.py:281)")
+        if self.continuous_actions:                                     # battle_env.py:295-297 clips the caller's dict
             for k, v in actions.items():
                 actions[k] = np.clip(v, -1.0, 1.0)
+        A = self._A
         was_done = bool(self._h_done[0])
         alive_before = self._h_alive[0].copy()
-        if isinstance(actions, dict) and len(actions) and not was_done:
-            missing = [a for i, a in enumerate(ids) if alive_before[i] and a not in actions]
-            if missing and alive_before.any() and self._h_tick[0] + 1 < self.tie_tick:
-                raise KeyError(missing[0])                              # battle_env.py:326
-        if isinstance(actions, dict) and len(actions):
-            # normalise per-agent values: ints, 0-d arrays, 4-vectors (arg-maxed, battle_env.py:327-328), 3-vectors
-            norm = {}
-            for a in ids:
-                v = actions.get(a)
-                if v is None:
-                    v = np.zeros(3) if self.continuous_actions else -1
-                v = np.asarray(v)
-                if self.continuous_actions:
-                    v = v.astype(np.float64).reshape(1, 3)
-                elif v.ndim >= 1 and v.size > 1:
-                    v = np.asarray([int(np.argmax(v))])
-                else:
-                    v = v.reshape(1).astype(np.int64)
-                norm[a] = v
-            actions = norm
-        obs, rew, done = self.step_batch(actions, None if u is None else np.asarray(u, np.float64).reshape(1, -1))
-        o = obs[0].cpu().numpy()
-        r = rew[0].cpu().numpy()
-        d = self._done[0].cpu().numpy().astype(bool)
-        ed = bool(self._h_done[0])
-        if ed and not was_done:
-            self.dones = {a: True for a in ids}                          # win()/tie() rebind the dict (:478,:494)
-            self._winner_name = _lib.WINNER_NAMES[int(self._winner[0])]
-        elif not was_done:
+        empty = len(actions) == 0
+        physics = not was_done and not empty and bool(alive_before.any()) and self._h_tick[0] + 1 < self.tie_tick
+        if physics:
             for i, a in enumerate(ids):
-                if d[i]:
-                    self.dones[a] = True
+                if alive_before[i] and a not in actions:
+                    raise KeyError(a)                                   # battle_env.py:326
+        # ---- inputs into the pinned staging buffer: actions (ints; 4-vectors arg-maxed, battle_env.py:327-328; 3-vectors), then the
+        #      random() value of every shot, drawn in the reference's order: live agents in id order, only when physics runs
+        hact, hu = self._hi_act, self._hi_u
+        hu[:] = np.nan
+        if not empty:
+            for i, a in enumerate(ids):
+                v = actions.get(a)
+                if self.continuous_actions:
+                    hact[i] = 0.0 if v is None else np.asarray(v, np.float64).reshape(3)
+                elif v is None:
+                    hact[i] = -1                                         # the reference only reads actions of live agents; absent = "no movement"
+                else:
+                    v = np.asarray(v)
+                    hact[i] = int(np.argmax(v)) if (v.ndim >= 1 and v.size > 1) else int(v.reshape(-1)[0])
+            if u is not None:
+                hu[:] = np.asarray(u, np.float64).reshape(-1)
+            elif self.rng == "python" and physics:
+                shoot = (np.clip(hact[:, 2], -1.0, 1.0) > 0) if self.continuous_actions else (hact == 1)
+                for i in range(A):
+                    if alive_before[i] and shoot[i]:
+                        hu[i] = _stdlib_random.random()
+        use_u = u is not None or self.rng == "python"
+        self._in_dev.copy_(self._in_host, non_blocking=True)
+        self._launch(None if empty else self._p_in_act, _lib.ACT_F64 if self.continuous_actions else _lib.ACT_I32, empty,
+                     self._p_in_u if use_u else None, self._p_obs, self._p_rew, self._p_done)
+        self._out_host.copy_(self._out_dev, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        o, r = self._ho_obs, self._ho_rew
+        d = self._ho_done.astype(bool)
+        ed = bool(self._ho_flags[0])
+        # ---- host mirrors (what `agents`, `env_done` and the next call's draws read)
+        if not was_done:
+            if not empty and alive_before.any():
+                self._h_tick[0] += 1                                    # physics or the time-limit tie: the clock advanced (battle_env.py:316)
+            self._h_done[0] = ed
+            if ed:
+                self._sync_mirror()                                     # game over (once per game): exact alive flags from the state
+                self.dones = {a: True for a in ids}                     # win()/tie() rebind the dict (:478,:494)
+                self._winner_name = _lib.WINNER_NAMES[int(self._out_host[self._ho_winner_at])]
+            else:
+                self._h_alive[0] = alive_before & ~d                    # a plane reported done in a running game has died
+                for i, a in enumerate(ids):
+                    if d[i]:
+                        self.dones[a] = True
         rewards = {a: (int(round(float(r[i]))) if self._int_rewards else float(r[i])) for i, a in enumerate(ids)}
         return ({a: o[i].copy() for i, a in enumerate(ids)}, rewards, self.dones, {a: {} for a in ids})
 
