@@ -661,7 +661,8 @@ def rollout_lines(dev, E, K):
     out = {}
     variants = [("graph of 2 kernels per tick, both teams on actors", dict(), False, False),
                 ("one launch for all ticks, both teams on actors", dict(one_launch=True), False, False),
-                ("one launch, 64x64 layer as split-bf16 matrix products", dict(one_launch=True, precision="bf16x3"), False, False),
+                ("one launch, 64x64 layer as six bf16 matrix products of three-term splits (float32-class accuracy)", dict(one_launch=True, precision="bf16x6"), False, False),
+                ("one launch, 64x64 layer as three bf16 matrix products of two-term splits (~1e-5 on a score)", dict(one_launch=True, precision="bf16x3"), False, False),
                 ("one launch, red = actor vs blue = scripted instinct opponent (main.py:119-122)", dict(one_launch=True), True, False),
                 ("continuous actions: graph of 2 kernels per tick", dict(), False, True),
                 ("continuous actions: one launch for all ticks", dict(one_launch=True), False, True)]

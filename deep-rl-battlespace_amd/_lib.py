@@ -8,11 +8,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # bsx_build_flags() is non-zero (results are not the reference's) is refused unless BSX_ALLOW_DIAG=1 is set as well.
 LIB_PATH = os.environ.get("BSX_LIB_PATH") or os.path.join(_HERE, "csrc", "libbattlespace_hip.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 BULLET_SLOTS = 12
 MAX_N = 16
 MAX_T = 65535
-ACTOR_F32, ACTOR_BF16X3 = 0, 1
+ACTOR_F32, ACTOR_BF16X3, ACTOR_BF16X6 = 0, 1, 2
 F_AUTO_RESET = 1
 F_EMPTY_CALL = 2
 ACT_I32, ACT_LOGITS_F32 = 0, 1

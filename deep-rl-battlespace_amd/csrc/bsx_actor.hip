@@ -40,9 +40,9 @@ struct ActorArgs {
     int64_t E; int A; int D; BsxActorNoise nz; uint64_t seed; uint64_t seq; const uint64_t* seq_base; int64_t env_offset;
 };
 
-// BF16X3 = false: exact f32, both 32-row tiles of the wave interleaved (four independent accumulators).
-// BF16X3 = true: the 64 x 64 layer as split-bf16 MFMAs (bsx_actor_core.h), one tile after the other.
-template <bool BF16X3>
+// PREC = BSX_ACTOR_F32: exact f32, both 32-row tiles of the wave interleaved (four independent accumulators).
+// PREC = BSX_ACTOR_BF16X3 / _BF16X6: the 64 x 64 layer as split-bf16 MFMAs (bsx_actor_core.h), one tile after the other.
+template <int PREC>
 __global__ __launch_bounds__(TPB) void bsx_actor_kernel(const ActorArgs p) {
 #pragma clang fp contract(fast)
     const int D = p.D, Dp = dpad(D);
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(TPB) void bsx_actor_kernel(const ActorArgs p) {
 
     const int64_t row0 = (int64_t(blockIdx.x) * (TPB / 64) + wave) * ROWS_PER_WAVE;   // first env of this wave
     float4 o[2];
-    if constexpr (BF16X3) {
+    if constexpr (PREC != BSX_ACTOR_F32) {
         __syncthreads();
         o[0] = make_float4(0.f, 0.f, 0.f, 0.f); o[1] = o[0];
 #pragma nounroll
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(TPB) void bsx_actor_kernel(const ActorArgs p) {
             const float* xr = p.obs + (size_t(en < p.E ? en : p.E - 1) * p.A + a) * D;
             const float* Wn = W;
             asm volatile("" : "+s"(Wn));                 // keeps the weight loads inside the loop (hoisted, they double the registers)
-            const float4 t = tile_forward<true>(Wn, s_small, D, lane, [&](int k) { return k < D ? xr[k] : 0.f; });
+            const float4 t = tile_forward<PREC>(Wn, s_small, D, lane, [&](int k) { return k < D ? xr[k] : 0.f; });
             if (nt == 0) o[0] = t; else o[1] = t;
         }
     } else {
@@ -177,7 +177,7 @@ int bsx_actor_forward(const float* weights, const float* obs, float* scores, int
                       const BsxActorNoise* noise, uint64_t seed, uint64_t seq, const uint64_t* seq_base, int64_t env_offset,
                       void* stream) {
     if (!weights || !obs || !scores || E <= 0 || E > BSX_MAX_E || n < 1 || n > BSX_MAX_N) return BSX_E_ARG;
-    if (precision != BSX_ACTOR_F32 && precision != BSX_ACTOR_BF16X3) return BSX_E_ARG;
+    if (precision != BSX_ACTOR_F32 && precision != BSX_ACTOR_BF16X3 && precision != BSX_ACTOR_BF16X6) return BSX_E_ARG;
     if (!aligned(weights, 16) || !aligned(scores, 16) || !aligned(obs, 4)) return BSX_E_ALIGN;
     BsxActorNoise nz = {0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr};
     if (noise) nz = *noise;
@@ -188,8 +188,9 @@ int bsx_actor_forward(const float* weights, const float* obs, float* scores, int
     ActorArgs a{weights, obs, scores, E, A, D, nz, seed, seq, seq_base, env_offset};
     const int rows_per_block = (TPB / 64) * ROWS_PER_WAVE;
     const dim3 grid(unsigned((E + rows_per_block - 1) / rows_per_block), unsigned(A)), block(TPB);
-    if (precision == BSX_ACTOR_BF16X3) hipLaunchKernelGGL(bsx_actor_kernel<true>, grid, block, 0, static_cast<hipStream_t>(stream), a);
-    else hipLaunchKernelGGL(bsx_actor_kernel<false>, grid, block, 0, static_cast<hipStream_t>(stream), a);
+    if (precision == BSX_ACTOR_BF16X6) hipLaunchKernelGGL(bsx_actor_kernel<BSX_ACTOR_BF16X6>, grid, block, 0, static_cast<hipStream_t>(stream), a);
+    else if (precision == BSX_ACTOR_BF16X3) hipLaunchKernelGGL(bsx_actor_kernel<BSX_ACTOR_BF16X3>, grid, block, 0, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(bsx_actor_kernel<BSX_ACTOR_F32>, grid, block, 0, static_cast<hipStream_t>(stream), a);
     return int(hipGetLastError());
 }
 

@@ -25,8 +25,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   small: b1p g1p be1p b2p g2p be2p, each [hh 2][mo 2][v 16] = value[nid(mo, v, hh)]
 //   W3P[hh 2][mt 2][v 16][4]                   W3[k = nid(mt, v, hh)][0..3]
 //   b3[4]
-//   W2B[mo 2][s 4][term 2][lane 64][i 8] bf16  the 64 x 64 layer once more, for BSX_ACTOR_BF16X3: term 0 = bf16(W2), term 1 =
-//                                              bf16(W2 - term 0), of W2[k = nid(s>>1, 8*(s&1) + i, lane>>5)][32*mo + (lane&31)]
+//   W2B[mo 2][s 4][term 3][lane 64][i 8] bf16  the 64 x 64 layer once more, split in bf16 terms: term 0 = bf16(W2), term 1 =
+//                                              bf16(W2 - term 0), term 2 = bf16(W2 - term 0 - term 1), of
+//                                              W2[k = nid(s>>1, 8*(s&1) + i, lane>>5)][32*mo + (lane&31)]
+//                                              (BSX_ACTOR_BF16X3 reads terms 0-1, BSX_ACTOR_BF16X6 all three)
 // nid(m, v, hh) = 32*m + (v&3) + 8*(v>>2) + 4*hh  -- the neuron held by accumulator register v of tile m in lane half hh
 __host__ __device__ constexpr int dpad(int D) { return (D + 1) & ~1; }
 __host__ __device__ constexpr int off_w2(int D) { return H * dpad(D); }
@@ -34,7 +36,7 @@ __host__ __device__ constexpr int off_small(int D) { return off_w2(D) + H * H; }
 __host__ __device__ constexpr int off_w3(int D) { return off_small(D) + 6 * H; }
 __host__ __device__ constexpr int off_b3(int D) { return off_w3(D) + H * NA; }
 __host__ __device__ constexpr int off_w2b(int D) { return off_b3(D) + NA; }            // 16-byte aligned: every section is a multiple of 4 floats
-__host__ __device__ constexpr int blob_floats(int D) { return off_w2b(D) + H * H; }     // 2 bf16 terms = 4 bytes per weight
+__host__ __device__ constexpr int blob_floats(int D) { return off_w2b(D) + H * H * 3 / 2; }     // 3 bf16 terms = 6 bytes per weight
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -143,14 +145,20 @@ __device__ inline float4 finish_row(float4 r4, const float4 b3, const BsxActorNo
 //   sm  the agent's SMALL block in LDS
 //   xb  xb(k) = this lane's layer-1 B operand: observation value k of row (lane & 31), 0 for k >= D
 //
-// BF16X3: the 64 x 64 layer on the bf16 matrix path with both operands split in two bf16 terms, x = xh + xl, w = wh + wl, and
-// three products wh*xh + wh*xl + wl*xh accumulated in f32 (the dropped wl*xl and the split residue are ~2^-16 relative: about
-// 1e-5 on a score, against 4e-3 for plain bf16).  v_mfma_f32_32x32x16_bf16 retires 16x the multiply-adds per cycle of the f32
-// MFMA -- whose rate equals packed-f32 VALU and which does not overlap with vector instructions -- so the layer costs 24
-// matrix instructions of 32 cycles instead of 64 of 64.  Layer 1 (K = 6) and everything else stay f32.
-template <bool BF16X3, class XB>
+// PREC = BSX_ACTOR_BF16X3 (1): the 64 x 64 layer on the bf16 matrix path with both operands split in two bf16 terms, x = xh + xl,
+// w = wh + wl, and three products wh*xh + wh*xl + wl*xh accumulated in f32 (the dropped wl*xl and the split residue are ~2^-16
+// relative: about 1e-5 on a score, against 4e-3 for plain bf16).  v_mfma_f32_32x32x16_bf16 retires 16x the multiply-adds per cycle of
+// the f32 MFMA -- whose rate equals packed-f32 VALU and which does not overlap with vector instructions -- so the layer costs 24
+// matrix instructions of 32 cycles instead of 64 of 64.
+// PREC = BSX_ACTOR_BF16X6 (2): THREE terms per operand (8 + 8 + 8 significant bits = float32's 24) and the six products of order up to
+// 2^-16 -- wh*xh, wh*xm, wm*xh, wh*xl, wm*xm, wl*xh, added smallest first; what is dropped is below 2^-24 relative, the size of a
+// float32 rounding -- 48 matrix instructions of 32 cycles: float32-class accuracy (not the fmaf chain's bits) at 2.7x the f32 MFMA rate.
+// Layer 1 (K = 6) and everything else stay f32 in every mode.
+template <int PREC, class XB>
 __device__ inline float4 tile_forward(const float* __restrict__ W, const float* __restrict__ sm_agent, int D, int lane, XB xb) {
 #pragma clang fp contract(fast)
+    constexpr bool BF = PREC != BSX_ACTOR_F32;
+    constexpr int NT = PREC == BSX_ACTOR_BF16X6 ? 3 : 2;                        // bf16 terms read per weight
     const int Dp = dpad(D), hh = lane >> 5;
     const float* sm = sm_agent + hh * 32;      // this lane half's [mo][v] slice of each 64-float vector ([hh][mo][v])
     f32x16 acc1[2];
@@ -167,38 +175,56 @@ __device__ inline float4 tile_forward(const float* __restrict__ W, const float* 
     }
     // The 64 x 64 layer's operands are fetched HERE, behind layer 1's own loads: vmcnt counts in order, so any load issued
     // after these would have to wait for all 16 KB of them; the LayerNorm below (~1 k cycles of VALU) covers their latency.
-    float4 w2[2][2][4];                        // f32: [mo][mt][vq] x 4 k-steps;  bf16x3: the same 64 registers hold [mo][s][term] x 8 bf16
+    float4 w2[2][2][4];                        // f32: [mo][mt][vq] x 4 k-steps
+    float4 wb[2][4][NT];                       // bf16 modes: [mo][s][term] x 8 bf16
+    if constexpr (!BF) {
 #pragma unroll
-    for (int mo = 0; mo < 2; ++mo)
+        for (int mo = 0; mo < 2; ++mo)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int vq = 0; vq < 4; ++vq)
-                w2[mo][mt][vq] = reinterpret_cast<const float4*>(W + (BF16X3 ? off_w2b(D) : off_w2(D)))[((mo * 2 + mt) * 4 + vq) * 64 + lane];
+                for (int vq = 0; vq < 4; ++vq)
+                    w2[mo][mt][vq] = reinterpret_cast<const float4*>(W + off_w2(D))[((mo * 2 + mt) * 4 + vq) * 64 + lane];
+    } else {
+#pragma unroll
+        for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    wb[mo][s][t] = reinterpret_cast<const float4*>(W + off_w2b(D))[((mo * 4 + s) * 3 + t) * 64 + lane];
+    }
     ln_relu_tile(acc1[0], acc1[1], sm + 1 * H, sm + 2 * H);
     f32x16 acc2[2];
 #pragma unroll
     for (int mo = 0; mo < 2; ++mo)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc2[mo][v] = sm[3 * H + mo * 16 + v];
-    if constexpr (BF16X3) {
+    if constexpr (BF) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {          // K step s = accumulator registers 8*(s&1) .. +7 of layer-1 tile s>>1
-            bf16x8 xh, xl;
+            bf16x8 xh, xm, xl;                 // two-term mode: xm is the low term, xl unused
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float x = acc1[s >> 1][8 * (s & 1) + i];
                 const __bf16 h = static_cast<__bf16>(x);                       // round to nearest even
-                xh[i] = h;
-                xl[i] = static_cast<__bf16>(x - static_cast<float>(h));
+                const float r1 = x - static_cast<float>(h);                    // exact
+                const __bf16 m = static_cast<__bf16>(r1);
+                xh[i] = h; xm[i] = m;
+                xl[i] = static_cast<__bf16>(r1 - static_cast<float>(m));
             }
 #pragma unroll
             for (int mo = 0; mo < 2; ++mo) {
-                // w2[mo][s >> 1][2 * (s & 1) + term] is W2B[mo][s][term] (same linear index as the f32 load above)
-                const bf16x8 wh = __builtin_bit_cast(bf16x8, w2[mo][s >> 1][2 * (s & 1) + 0]);
-                const bf16x8 wl = __builtin_bit_cast(bf16x8, w2[mo][s >> 1][2 * (s & 1) + 1]);
-                acc2[mo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc2[mo], 0, 0, 0);
-                acc2[mo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc2[mo], 0, 0, 0);
+                const bf16x8 wh = __builtin_bit_cast(bf16x8, wb[mo][s][0]);
+                const bf16x8 wm = __builtin_bit_cast(bf16x8, wb[mo][s][1]);
+                if constexpr (PREC == BSX_ACTOR_BF16X6) {
+                    const bf16x8 wl = __builtin_bit_cast(bf16x8, wb[mo][s][NT - 1]);
+                    acc2[mo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc2[mo], 0, 0, 0);
+                    acc2[mo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xm, acc2[mo], 0, 0, 0);
+                    acc2[mo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc2[mo], 0, 0, 0);
+                }
+                acc2[mo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xh, acc2[mo], 0, 0, 0);
+                acc2[mo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xm, acc2[mo], 0, 0, 0);
                 acc2[mo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc2[mo], 0, 0, 0);
             }
         }

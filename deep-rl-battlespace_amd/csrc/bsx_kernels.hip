@@ -606,8 +606,10 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
             const float* const Wn = p.aw + size_t(ag) * bsx_actor::blob_floats(D);
             const float* const smn = s_small + ag * bsx_actor::SMALL;
             auto xb = [&](int k) { return k < D ? s_obs_all[(c * G_ + ag) * D + k] : 0.f; };
-            const float4 o = p.aprec == BSX_ACTOR_BF16X3 ? bsx_actor::tile_forward<true>(Wn, smn, D, lane, xb)      // uniform branch
-                                                         : bsx_actor::tile_forward<false>(Wn, smn, D, lane, xb);
+            float4 o;                                    // uniform branches
+            if (p.aprec == BSX_ACTOR_BF16X3) o = bsx_actor::tile_forward<BSX_ACTOR_BF16X3>(Wn, smn, D, lane, xb);
+            else if (N == 1 && p.aprec == BSX_ACTOR_BF16X6) o = bsx_actor::tile_forward<(N == 1 ? BSX_ACTOR_BF16X6 : BSX_ACTOR_F32)>(Wn, smn, D, lane, xb);   // 1v1 only: 96 weight registers
+            else o = bsx_actor::tile_forward<BSX_ACTOR_F32>(Wn, smn, D, lane, xb);
             if (hh == ti) r4 = o;                        // lower half finishes the wave's first tile, upper half the second
         }
         const float4 b3 = *reinterpret_cast<const float4*>(s_small + mine_c * bsx_actor::SMALL + 6 * bsx_actor::H + bsx_actor::H * bsx_actor::NA);
@@ -1581,7 +1583,8 @@ int launch_rollout(void* state, int64_t E, int n, int T, const float* weights, i
                    int64_t env_offset, void* stream) {
     if (!state || E <= 0 || E > BSX_MAX_E || n < 1 || n > 4 || T < 1 || T > BSX_MAX_T || !weights || !obs || !scores || !rew || !done || !cfg)
         return BSX_E_ARG;
-    if ((flags & BSX_F_EMPTY_CALL) || (precision != BSX_ACTOR_F32 && precision != BSX_ACTOR_BF16X3) || scripted_team < -1 || scripted_team > 1) return BSX_E_ARG;
+    if ((flags & BSX_F_EMPTY_CALL) || (precision != BSX_ACTOR_F32 && precision != BSX_ACTOR_BF16X3 && !(precision == BSX_ACTOR_BF16X6 && n == 1)) ||
+        scripted_team < -1 || scripted_team > 1) return BSX_E_ARG;
     if (CONT && scripted_team != -1) return BSX_E_ARG;
     if (!aligned(state, 256) || !aligned(weights, 16) || !aligned(scores, 16) || !aligned(obs, 4) || !aligned(rew, 4)) return BSX_E_ALIGN;
     BsxActorNoise nz = {0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr};

@@ -56,8 +56,8 @@ class StackedActor(nn.Module):
           W2A[mo 2][mt 2][vq 4][lane 64][t 4]   = W2[nid(mt, 4 vq + t, lane>>5)][32 mo + (lane&31)]
           b1 g1 be1 b2 g2 be2, each [hh 2][mo 2][v 16] = vec[nid(mo, v, hh)]
           W3P[hh 2][mt 2][v 16][4]              = W3[nid(mt, v, hh)][:]        b3[4]
-          W2B[mo 2][s 4][term 2][lane 64][i 8]  bfloat16: term 0 = bf16(W2), term 1 = bf16(W2 - term 0) of
-                                                W2[nid(s>>1, 8 (s&1) + i, lane>>5)][32 mo + (lane&31)]  (precision="bf16x3")
+          W2B[mo 2][s 4][term 3][lane 64][i 8]  bfloat16: term 0 = bf16(W2), term 1 = bf16(W2 - term 0), term 2 = bf16(the rest) of
+                                                W2[nid(s>>1, 8 (s&1) + i, lane>>5)][32 mo + (lane&31)]  (precision="bf16x3" / "bf16x6")
         with nid(m, v, hh) = 32 m + (v&3) + 8 (v>>2) + 4 hh, the neuron that accumulator register v of 32-neuron tile m
         holds in lane half hh.  float32, contiguous, [n_actors, floats]."""
         if self.w1.shape[2] != 64 or self.w2.shape[2] != 64 or self.n_actions not in (3, 4):
@@ -92,16 +92,17 @@ class StackedActor(nn.Module):
             w3 = torch.cat([w3, torch.zeros_like(w3[:, :, :1])], dim=2)
             b3 = torch.cat([b3, torch.zeros_like(b3[:, :, :1])], dim=2)
         W3P = w3[:, idx, :].reshape(A, -1)                                         # [hh][mt][v][4]: same index pattern with mt for mo
-        # W2B[a, mo, s, term, lane, i]: the 64 x 64 layer split in two bfloat16 terms (precision="bf16x3")
+        # W2B[a, mo, s, term, lane, i]: the 64 x 64 layer split in three bfloat16 terms (precision="bf16x3" reads two, "bf16x6" all)
         mo6 = torch.arange(2, device=dev).view(2, 1, 1, 1); s6 = torch.arange(4, device=dev).view(1, 4, 1, 1)
         l6 = lane.view(1, 1, 64, 1); i6 = torch.arange(8, device=dev).view(1, 1, 1, 8)
         kb = nid(s6 >> 1, 8 * (s6 & 1) + i6, l6 >> 5).expand(2, 4, 64, 8)
         jb = (32 * mo6 + (l6 & 31)).expand(2, 4, 64, 8)
         wsel = self.w2.float()[:, kb, jb]                                          # [A, mo, s, lane, i]
         wh = wsel.to(torch.bfloat16)
-        wl = (wsel - wh.float()).to(torch.bfloat16)
-        W2B = torch.stack([wh, wl], dim=3).contiguous().view(torch.int16).reshape(A, -1)     # [A, mo, s, term, lane, i]
-        W2B = W2B.view(torch.float32)                                              # 2 bf16 per float slot: [A, 4096]
+        wm = (wsel - wh.float()).to(torch.bfloat16)
+        wl = (wsel - wh.float() - wm.float()).to(torch.bfloat16)
+        W2B = torch.stack([wh, wm, wl], dim=3).contiguous().view(torch.int16).reshape(A, -1)  # [A, mo, s, term 3, lane, i]
+        W2B = W2B.view(torch.float32)                                              # 2 bf16 per float slot: [A, 6144]
         blob = torch.cat([W1A, W2A, *small, W3P, b3.reshape(A, -1), W2B], dim=1).contiguous()
         if out is not None:
             out.copy_(blob)
@@ -125,10 +126,11 @@ class FusedActor:
     `bsx_actor_forward`: f32 MFMA, exact f32): a row never leaves the register file -- 4*D bytes in, 16 bytes out --
     instead of ~20 memory-bound torch passes over [A, E, 64] activations.  Holds a packed copy of a StackedActor's weights; call `refresh()` after the learner updates them.
     Optional exploration noise (Gaussian, then clamp(-1, 1) as maddpg/agent.py:31) is drawn in-kernel.
-    precision: "f32" = exact float32 everywhere; "bf16x3" = the 64 x 64 layer as three bf16 matrix products of two-term
+    precision: "f32" = exact float32 everywhere; "bf16x6" = the 64 x 64 layer as six bf16 matrix products of three-term splits of
+    both operands (float32-class accuracy, ~1e-7, 2.7x the matrix rate); "bf16x3" = three bf16 matrix products of two-term
     splits of both operands (about 1e-5 on a score, 16x the matrix rate); everything else stays float32."""
 
-    PRECISIONS = {"f32": _lib.ACTOR_F32, "bf16x3": _lib.ACTOR_BF16X3}
+    PRECISIONS = {"f32": _lib.ACTOR_F32, "bf16x3": _lib.ACTOR_BF16X3, "bf16x6": _lib.ACTOR_BF16X6}
 
     def __init__(self, actor, n_agents_per_team, seed=0, precision="f32", env_offset=0):
         """env_offset: global index of the shard's first game (sharding.make_shard): exploration noise is keyed by the GLOBAL row,

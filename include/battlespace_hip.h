@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define BSX_ABI_VERSION 9
+#define BSX_ABI_VERSION 10
 #define BSX_BULLET_SLOTS 12 /* a bullet is removed at the latest on its 12th update (sprites.py:334-337: 12*45 >= 500) */
 #define BSX_MAX_N 16
 #define BSX_MAX_E (INT64_C(1) << 30)   /* games per call: keeps every grid below 2^31 workgroups; 2^30 games of 1v1 is ~0.8 TB of state */
@@ -147,8 +147,9 @@ int bsx_export_state(const void* state, int64_t E, int n, const BsxExport* out, 
  *              W2A[mo 2][mt 2][vq 4][lane 64][t 4] = W2[nid(mt, 4vq + t, lane>>5)][32mo + (lane&31)]
  *              b1 ln1_gain ln1_bias b2 ln2_gain ln2_bias, each [hh 2][mo 2][v 16] = vec[nid(mo, v, hh)]
  *              W3P[hh 2][mt 2][v 16][4] = W3[nid(mt, v, hh)][0..3];  b3[4]
- *              W2B[mo 2][s 4][term 2][lane 64][i 8] bfloat16 (4096 floats' worth): term 0 = bf16(W2), term 1 = bf16(W2 - term 0)
- *                  of W2[nid(s>>1, 8(s&1) + i, lane>>5)][32mo + (lane&31)]  -- read only with BSX_ACTOR_BF16X3
+ *              W2B[mo 2][s 4][term 3][lane 64][i 8] bfloat16 (6144 floats' worth): term 0 = bf16(W2), term 1 = bf16(W2 - term 0),
+ *                  term 2 = bf16(W2 - term 0 - term 1), of W2[nid(s>>1, 8(s&1) + i, lane>>5)][32mo + (lane&31)]  -- read only with
+ *                  BSX_ACTOR_BF16X3 (terms 0-1) / BSX_ACTOR_BF16X6 (all three)
  *            (W[k][j] multiplies input k into output j, i.e. the transpose of torch's Linear.weight.)
  *   obs      float32[E*A*D] (what bsx_step_* / bsx_reset wrote);  scores float32[E*A*4], 16-byte aligned: feed it to
  *            bsx_step_discrete with BSX_ACT_LOGITS_F32.
@@ -172,6 +173,8 @@ typedef struct BsxActorNoise {
  * three bf16 matrix products accumulated in float32 (about 1e-5 on a score; 16x the matrix rate).  All else is float32. */
 #define BSX_ACTOR_F32 0
 #define BSX_ACTOR_BF16X3 1
+#define BSX_ACTOR_BF16X6 2   /* three bf16 terms per operand, six products: float32-class accuracy (~1e-7), 48 matrix instructions of 32 cycles
+                               instead of 64 of 64; bsx_actor_forward for any n, the one-launch rollouts for n = 1 */
 int bsx_actor_blob_floats(int obs_len, int* floats_per_agent);
 int bsx_actor_forward(const float* weights, const float* obs, float* scores, int64_t E, int n, int precision,
                       const BsxActorNoise* noise, uint64_t seed, uint64_t seq, const uint64_t* seq_base, int64_t env_offset,

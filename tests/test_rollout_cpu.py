@@ -102,7 +102,7 @@ def test_packed_actor_blob_drives_the_mfma_fragment_arithmetic(n):
     blob = act.pack().numpy()
     Dp = (D + 1) & ~1
     ow2 = 64 * Dp; osm = ow2 + 4096; ow3 = osm + 384; ob3 = ow3 + 256
-    assert blob.shape == (A, ob3 + 4 + 4096)
+    assert blob.shape == (A, ob3 + 4 + 6144)
     obs = torch.rand(64, A, D) * 2 - 1
     want = act(obs).detach().numpy()
     lanes = np.arange(64); hh = lanes >> 5
@@ -142,24 +142,31 @@ def test_packed_actor_blob_drives_the_mfma_fragment_arithmetic(n):
                 for mo in range(2):
                     for nt in range(2):
                         _mfma_32x32x2(w2[mo, mt, v >> 2, :, v & 3], acc1[mt, nt, v], acc2[mo, nt])
-        # the same layer from the bfloat16 section (precision "bf16x3"): W2B[mo][s][term][lane][i], three products per K step
-        w2b = (W[ob3 + 4:ob3 + 4 + 4096].view(np.uint16).astype(np.uint32) << 16).view(np.float32).astype(np.float64).reshape(2, 4, 2, 64, 8)
-        acc2b = np.zeros((2, 2, 16, 64))
+        # the same layer from the bfloat16 section: W2B[mo][s][term 3][lane][i]; "bf16x3" = three products of the first two terms per
+        # K step, "bf16x6" = six products of all three terms (float32-class accuracy)
+        w2b = (W[ob3 + 4:ob3 + 4 + 6144].view(np.uint16).astype(np.uint32) << 16).view(np.float32).astype(np.float64).reshape(2, 4, 3, 64, 8)
+        w2ref = np.zeros((2, 4, 64, 8))                                                # the float32 weights the terms sum to
+        nid = lambda m, v, h2: 32 * m + (v & 3) + 8 * (v >> 2) + 4 * h2              # noqa: E731
+        acc2b = np.zeros((2, 2, 16, 64)); acc2c = np.zeros((2, 2, 16, 64))
         for mo in range(2):
             for nt in range(2):
-                acc2b[mo, nt] = sm[3][hh, mo].T
+                acc2b[mo, nt] = sm[3][hh, mo].T; acc2c[mo, nt] = sm[3][hh, mo].T
         for s4 in range(4):
             for nt in range(2):
                 x = np.stack([acc1[s4 >> 1, nt, 8 * (s4 & 1) + i] for i in range(8)], axis=1)          # [lane, 8]
-                xh = _bf16(x); xl = _bf16(x - xh)
+                x = x.astype(np.float32).astype(np.float64)                              # the kernel splits float32 accumulator values
+                xh = _bf16(x); xm = _bf16(x - xh); xl = _bf16(x - xh - xm)
                 for mo in range(2):
-                    wh, wl = w2b[mo, s4, 0], w2b[mo, s4, 1]
-                    _mfma_32x32x16(wl, xh, acc2b[mo, nt]); _mfma_32x32x16(wh, xl, acc2b[mo, nt]); _mfma_32x32x16(wh, xh, acc2b[mo, nt])
+                    wh, wm, wl = w2b[mo, s4, 0], w2b[mo, s4, 1], w2b[mo, s4, 2]
+                    _mfma_32x32x16(wm, xh, acc2b[mo, nt]); _mfma_32x32x16(wh, xm, acc2b[mo, nt]); _mfma_32x32x16(wh, xh, acc2b[mo, nt])
+                    for wa, xa in ((wl, xh), (wm, xm), (wh, xl), (wm, xh), (wh, xm), (wh, xh)):
+                        _mfma_32x32x16(wa, xa, acc2c[mo, nt])
+        assert np.abs(acc2c - acc2).max() < 3e-6 * max(1.0, np.abs(acc2).max())   # six products: float32-class (the emulation's acc1 is float64)
         err_split = np.abs(acc2b - acc2).max()
         assert err_split < 2e-4 * max(1.0, np.abs(acc2).max()), err_split         # ~2^-16 relative; plain bf16 would be ~4e-3
-        ln(acc2, 4, 5); ln(acc2b, 4, 5)
+        ln(acc2, 4, 5); ln(acc2b, 4, 5); ln(acc2c, 4, 5)
         w3 = W[ow3:ow3 + 256].reshape(2, 2, 16, 4); b3 = W[ob3:ob3 + 4]
-        for acc, tol in ((acc2, 2e-5), (acc2b, 1e-4)):
+        for acc, tol in ((acc2, 2e-5), (acc2b, 1e-4), (acc2c, 2e-5)):
             out = np.zeros((64, 4))
             for nt in range(2):
                 for c in range(32):
