@@ -13,7 +13,7 @@ ap.add_argument("--envs", type=int, default=65536); ap.add_argument("--n-agents"
 ap.add_argument("--T", type=int, default=32); ap.add_argument("--reps", type=int, default=40)
 ap.add_argument("--noise", type=float, default=0.1); ap.add_argument("--torch-actor", action="store_true")
 ap.add_argument("--one-launch", action="store_true", help="all T ticks in one kernel (bsx_rollout_discrete; 1v1)")
-ap.add_argument("--precision", default="f32", choices=("f32", "bf16x3"), help="the actor's 64 x 64 layer")
+ap.add_argument("--precision", default="f32", choices=("f32", "bf16x3", "bf16x6"), help="the actor's 64 x 64 layer")
 ap.add_argument("--scripted-blue", action="store_true", help="blue is the scripted opponent (instinct.Team), red the actor: main.py:119-122")
 args = ap.parse_args()
 E, n, T = args.envs, args.n_agents, args.T
