@@ -194,7 +194,16 @@ class parallel_env:
         return draw_spawn(self.n_agents)
 
     def _agent_views(self, t):
-        return {a: t[:, i] for i, a in enumerate(self.possible_agents)}
+        """{agent id: column i of t}.  The env-owned output tensors never change identity, so their column views are built once and
+        every call returns a fresh dict of the same views (the reference hands out a new dict per step, battle_env.py:374-381)."""
+        cache = self.__dict__.setdefault("_view_cache", {})
+        key = (t.data_ptr(), t.dtype, tuple(t.shape))
+        views = cache.get(key)
+        if views is None:
+            views = {a: t[:, i] for i, a in enumerate(self.possible_agents)}
+            if any(t is own for own in (self._obs, self._rew, self._done_bool)):
+                cache[key] = views                                   # only the persistent tensors are cached (copies come and go)
+        return dict(views)
 
     # ------------------------------------------------------------------ spaces (battle_env.py:186-200)
     def observation_space(self, agent):
@@ -338,8 +347,8 @@ class parallel_env:
         if self._mirror:
             self._sync_mirror()
         if copy:
-            return self._obs.clone(), self._rew.clone(), self._done.view(torch.bool).clone()
-        return self._obs, self._rew, self._done.view(torch.bool)
+            return self._obs.clone(), self._rew.clone(), self._done_bool.clone()
+        return self._obs, self._rew, self._done_bool
 
     def _launch(self, act_ptr, kind, empty, u_ptr, obs_ptr, rew_ptr, done_ptr, env_done_ptr=None):
         """Enqueue one fused step kernel on the current stream (no sync, no allocation: graph-capturable).
@@ -494,6 +503,8 @@ class parallel_env:
         if self._compat:
             return self._step_compat(actions, u)
         obs, rew, done = self.step_batch(actions, u, copy=copy)
+        if not copy:
+            done = self._done_bool                                       # the one persistent bool view (a fresh .view() each call would defeat the cache)
         return (self._agent_views(obs), self._agent_views(rew), self._agent_views(done),
                 {a: {} for a in self.possible_agents})
 
