@@ -47,3 +47,25 @@ def test_two_rank_job_equals_the_single_process_job(tmp_path):
     # both lines count the same finished games: the logging all-reduce summed the two shards' counters
     assert two["games_finished"] == one["games_finished"] > 0 and two["ties"] == one["ties"]
     assert int(whole["counters"][:, 0].sum()) == one["games_finished"]
+
+
+def test_bench_under_torch_distributed_run_uses_the_ranks_it_is_given():
+    """The driver's launch shape -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- with N = 2 on this one card (gloo rehearsal): bench.py reads RANK / WORLD_SIZE /
+    MASTER_* from the environment instead of starting ranks itself, rank 0 prints the one JSON line for the whole job."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                        "--rehearse-on-device0", "--no-cpu-baseline", "--no-other-workloads"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 65536 * 2 * 20 / (d["ms_per_step"] * 1e-3 * 20)) / d["value"] < 1e-3
+    assert d["roofline"]["traffic_source"] is None or "profiles/traffic.json" in d["roofline"]["traffic_source"]     # no live PMC passes at N > 1
