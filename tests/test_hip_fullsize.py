@@ -258,6 +258,12 @@ def test_continuous_actions_vs_c_oracle(n, f32):
     _compare_generic(8192, n, 150, seed=300 + n, cont=True, f32=f32)
 
 
+def test_C2_size_continuous_actions_vs_c_oracle():
+    """The continuous mode (the reference's own driver test_env.py:22-43 steps the env with [speed, turn, shoot] boxes) at the
+    headline batch size: 65 536 games of 1v1, float32 actions, 135 calls across the 121-call tie and the re-spawns."""
+    _compare_generic(65536, 1, 135, seed=901, cont=True, f32=True)
+
+
 def test_score_vector_actions_vs_c_oracle():
     """[E, A, 4] score vectors arg-maxed in-kernel (battle_env.py:327-328)."""
     _compare_generic(8192, 2, 150, seed=77, logits=True)
