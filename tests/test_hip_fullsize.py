@@ -97,6 +97,33 @@ def test_deterministic_and_shard_invariant():
         assert torch.equal(outs[0][1], other[1])
 
 
+def test_C4_524288_games_as_eight_shards_equal_one_batch():
+    """BASELINE.json configs[3] at its real size, on one card: 524 288 games of 1v1 as ONE batch and as the eight contiguous shards
+    of 65 536 the 8-GPU layout gives its ranks (sharding.make_shard: env_offset = first global index), stepped with the same global
+    action table, end in the same state bit for bit -- spawns, bullet jitter and auto-resets are keyed by the global game index."""
+    from deep_rl_battlespace_amd import sharding
+    E, n, T, W = 524288, 1, 130, 8
+    acts = _actions(T, E, 2, 4321)
+    whole = _env(n_agents=n, n_envs=E, seed=77, auto_reset=True); whole.reset()
+    shards = [sharding.make_shard(E, r, W, n_agents=n, seed=77, auto_reset=True) for r in range(W)]
+    assert [s.env_offset for s in shards] == [r * 65536 for r in range(W)] and all(s.n_envs == 65536 for s in shards)
+    for s in shards:
+        s.reset()
+    for t in range(T):
+        ow, rw, dw = whole.step_batch(acts[t])
+        for r, s in enumerate(shards):
+            o, rr, d = s.step_batch(acts[t, r * 65536:(r + 1) * 65536].contiguous())
+            if t % 43 == 0 or t == T - 1:
+                sl = slice(r * 65536, (r + 1) * 65536)
+                assert torch.equal(o, ow[sl]) and torch.equal(rr, rw[sl]) and torch.equal(d, dw[sl]), (t, r)
+    sw = whole.export_state()
+    for r, s in enumerate(shards):
+        ss = s.export_state(); sl = slice(r * 65536, (r + 1) * 65536)
+        for f in ("px", "py", "pdir", "php", "bhp", "tick", "env_done", "winner", "bl_live", "bl_x", "bl_y", "bl_dir", "counters"):
+            assert torch.equal(ss[f], sw[f][sl]), (r, f)
+    assert int(sw["counters"][:, 0].sum()) >= E                  # every game crossed its first game end
+
+
 def test_largest_batch_offsets_past_4GB_play_the_same_games():
     """Maximum sizes: 16 M + 5 games of 1v1 in ONE batch (12 GB of state; bullet-step rows start beyond 4 GB, the grid is
     524 289 wavefronts, the last one ragged).  The in-kernel generator is keyed by the global env index, so the last 4 096
