@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # bsx_build_flags() is non-zero (results are not the reference's) is refused unless BSX_ALLOW_DIAG=1 is set as well.
 LIB_PATH = os.environ.get("BSX_LIB_PATH") or os.path.join(_HERE, "csrc", "libbattlespace_hip.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 BULLET_SLOTS = 12
 MAX_N = 16
 MAX_T = 65535
@@ -67,6 +67,7 @@ SIGNATURES = {
     "bsx_observe": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "bsx_export_state": (c_int, [c_void_p, c_int64, c_int, ctypes.POINTER(BsxExport), c_void_p]),
     "bsx_tie_tick": (c_int, [c_int]),
+    "bsx_stream_synchronize": (c_int, [c_void_p]),
     "bsx_instinct_discrete": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     "bsx_instinct_continuous": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_uint64, c_uint64, c_void_p, c_void_p]),
     "bsx_actor_blob_floats": (c_int, [c_int, ctypes.POINTER(c_int)]),

@@ -183,6 +183,10 @@ class parallel_env:
             return self._raw_stream(self.device.index)
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def _sync(self):
+        """Drop-in mode: wait for the launches of this call (their outputs sit in pinned host memory, read by the host next)."""
+        _lib.check(self._lib.bsx_stream_synchronize(self._stream()), "bsx_stream_synchronize")
+
     def _guard(self):
         """HIP launches go to the calling thread's current device: make that the env's device for the duration of a call
         (a no-op context when it already is, which is the normal one-process-per-GPU case)."""
@@ -252,7 +256,8 @@ class parallel_env:
         if self._compat:
             self.dones = {a: False for a in self.possible_agents}
             self._winner_name = "none"
-            o = self._obs[0].cpu().numpy()
+            self._sync()
+            o = self._ho_obs
             return {a: o[i].copy() for i, a in enumerate(self.possible_agents)}
         return self._agent_views(self._obs)
 
@@ -509,9 +514,10 @@ class parallel_env:
                 {a: {} for a in self.possible_agents})
 
     def _init_compat_io(self):
-        """Drop-in mode exchanges a few dozen bytes with the device per call: all outputs (obs, rew, done, env_done, winner) are
-        views of ONE device buffer and all inputs (the shots' random() values, the actions) of another, each mirrored by a pinned
-        host buffer -- one upload, one launch, one download, one synchronisation per step()."""
+        """Drop-in mode exchanges a few dozen bytes with the device per call, so nothing is copied: all outputs (obs, rew, done,
+        env_done, winner) are views of ONE pinned host buffer and all inputs (the shots' random() values, the actions) of another;
+        hipHostMalloc memory is mapped into the device's address space at the same address, the kernels read and write it
+        directly over the link -- one launch and one synchronisation per step(), no upload, no download."""
         A, D, dev = self._A, self.obs_size, self.device
         def carve(spec):
             off, o = {}, 0
@@ -523,19 +529,17 @@ class parallel_env:
         act_bytes = A * 3 * 8 if self.continuous_actions else A * 4
         out_off, out_n = carve((("obs", A * D * 4), ("rew", A * 4), ("done", A), ("env_done", 1), ("winner", 1)))
         in_off, in_n = carve((("u", A * 8), ("act", act_bytes)))
-        self._out_dev = torch.zeros(out_n, dtype=torch.uint8, device=dev)
-        self._in_dev = torch.zeros(in_n, dtype=torch.uint8, device=dev)
         self._out_host = torch.zeros(out_n, dtype=torch.uint8).pin_memory()
         self._in_host = torch.zeros(in_n, dtype=torch.uint8).pin_memory()
 
         def view(buf, off, dtype, shape):
             o, nb = off
             return buf[o:o + nb].view(dtype).view(shape)
-        self._obs = view(self._out_dev, out_off["obs"], torch.float32, (1, A, D))
-        self._rew = view(self._out_dev, out_off["rew"], torch.float32, (1, A))
-        self._done = view(self._out_dev, out_off["done"], torch.uint8, (1, A))
-        self._env_done = view(self._out_dev, out_off["env_done"], torch.uint8, (1,))
-        self._winner = view(self._out_dev, out_off["winner"], torch.uint8, (1,))
+        self._obs = view(self._out_host, out_off["obs"], torch.float32, (1, A, D))
+        self._rew = view(self._out_host, out_off["rew"], torch.float32, (1, A))
+        self._done = view(self._out_host, out_off["done"], torch.uint8, (1, A))
+        self._env_done = view(self._out_host, out_off["env_done"], torch.uint8, (1,))
+        self._winner = view(self._out_host, out_off["winner"], torch.uint8, (1,))
         hn = self._out_host.numpy()
         self._ho_obs = hn[out_off["obs"][0]:][:A * D * 4].view(np.float32).reshape(A, D)
         self._ho_rew = hn[out_off["rew"][0]:][:A * 4].view(np.float32)
@@ -548,8 +552,8 @@ class parallel_env:
             self._hi_act = hi[in_off["act"][0]:][:act_bytes].view(np.float64).reshape(A, 3)
         else:
             self._hi_act = hi[in_off["act"][0]:][:act_bytes].view(np.int32)
-        self._p_in_u = self._in_dev.data_ptr() + in_off["u"][0]
-        self._p_in_act = self._in_dev.data_ptr() + in_off["act"][0]
+        self._p_in_u = self._in_host.data_ptr() + in_off["u"][0]
+        self._p_in_act = self._in_host.data_ptr() + in_off["act"][0]
 
     def _step_compat(self, actions, u):
         ids = self.possible_agents
@@ -562,7 +566,8 @@ class parallel_env:
         was_done = bool(self._h_done[0])
         alive_before = self._h_alive[0].copy()
         empty = len(actions) == 0
-        physics = not was_done and not empty and bool(alive_before.any()) and self._h_tick[0] + 1 < self.tie_tick
+        any_alive = bool(alive_before.any())
+        physics = not was_done and not empty and any_alive and self._h_tick[0] + 1 < self.tie_tick
         if physics:
             for i, a in enumerate(ids):
                 if alive_before[i] and a not in actions:
@@ -578,6 +583,8 @@ class parallel_env:
                     hact[i] = 0.0 if v is None else np.asarray(v, np.float64).reshape(3)
                 elif v is None:
                     hact[i] = -1                                         # the reference only reads actions of live agents; absent = "no movement"
+                elif type(v) is int:
+                    hact[i] = v if -2147483648 <= v <= 2147483647 else -1   # any integer outside 0..3 is "no movement" (battle_env.py:399-417)
                 else:
                     v = np.asarray(v)
                     hact[i] = int(np.argmax(v)) if (v.ndim >= 1 and v.size > 1) else int(v.reshape(-1)[0])
@@ -589,17 +596,15 @@ class parallel_env:
                     if alive_before[i] and shoot[i]:
                         hu[i] = _stdlib_random.random()
         use_u = u is not None or self.rng == "python"
-        self._in_dev.copy_(self._in_host, non_blocking=True)
         self._launch(None if empty else self._p_in_act, _lib.ACT_F64 if self.continuous_actions else _lib.ACT_I32, empty,
                      self._p_in_u if use_u else None, self._p_obs, self._p_rew, self._p_done)
-        self._out_host.copy_(self._out_dev, non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()
+        self._sync()                                                    # the kernel wrote the pinned output buffer itself
         o, r = self._ho_obs, self._ho_rew
         d = self._ho_done.astype(bool)
         ed = bool(self._ho_flags[0])
         # ---- host mirrors (what `agents`, `env_done` and the next call's draws read)
         if not was_done:
-            if not empty and alive_before.any():
+            if not empty and any_alive:
                 self._h_tick[0] += 1                                    # physics or the time-limit tie: the clock advanced (battle_env.py:316)
             self._h_done[0] = ed
             if ed:
@@ -621,7 +626,8 @@ class parallel_env:
                                              self._stream()), "bsx_observe")
         i = self._idx[agent]
         if self._compat:
-            return self._obs[0, i].cpu().numpy().copy()
+            self._sync()
+            return self._ho_obs[i].copy()
         return self._obs[:, i]
 
     # ------------------------------------------------------------------ public attributes callers read

@@ -35,6 +35,8 @@ class Team:
         when discrete; float64 [E, A, 3] when continuous.  Returns `out`."""
         env = self.env
         obs = env._obs if obs is None else obs
+        if not obs.is_cuda and not obs.is_pinned():            # (drop-in mode keeps the env's rows in pinned host memory, which the kernel reads directly)
+            obs = obs.to(env.device)
         E, A = env.n_envs, env._A
         stream = torch.cuda.current_stream(env.device).cuda_stream
         if out is None:
@@ -73,7 +75,7 @@ class Team:
         env = self.env
         obs = None
         if env._compat and isinstance(observations, dict):
-            o = env._obs.clone()
+            o = env._obs.to(env.device)                       # drop-in mode: the env's rows live in pinned host memory
             for a in self.agent_list:
                 if a in observations:
                     o[0, env._idx[a]] = torch.as_tensor(np.asarray(observations[a], np.float32), device=env.device)

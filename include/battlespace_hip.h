@@ -9,8 +9,11 @@
  *   - E = number of independent games (envs), n = planes per team, A = 2n agents per env, D = 3n+2 observation floats.
  *   - Agent a of env e is row e*A + a of every per-agent array; a < n is red ("plane{a}"), a >= n blue -- the order
  *     of `possible_agents` (battle_env.py:106-108).
- *   - All pointers are DEVICE memory owned by the caller.  Calls only enqueue work on `stream` and return; they never
- *     synchronise and never allocate.  Return value: 0 = ok, <0 = argument error (BSX_E_*), >0 = a hipError_t.
+ *   - All pointers are DEVICE-ACCESSIBLE memory owned by the caller: device memory for batches; for a single game
+ *     (the drop-in surface: a few dozen bytes per call) pinned host memory (hipHostMalloc, mapped at the same address)
+ *     works as well and saves both copies.  Calls only enqueue work on `stream` and return; they never synchronise
+ *     (bsx_stream_synchronize is the one exception, by name) and never allocate.
+ *     Return value: 0 = ok, <0 = argument error (BSX_E_*), >0 = a hipError_t.
  *   - Outputs are overwritten by the next call; inputs are read-only for the duration of the kernel.
  *   - Supported n: 1..16.
  */
@@ -24,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BSX_ABI_VERSION 10
+#define BSX_ABI_VERSION 11
 #define BSX_BULLET_SLOTS 12 /* a bullet is removed at the latest on its 12th update (sprites.py:334-337: 12*45 >= 500) */
 #define BSX_MAX_N 16
 #define BSX_MAX_E (INT64_C(1) << 30)   /* games per call: keeps every grid below 2^31 workgroups; 2^30 games of 1v1 is ~0.8 TB of state */
@@ -223,6 +226,10 @@ int bsx_instinct_continuous(const float* obs, double* actions, const double* rnd
 /* Host helper: the call number on which the time-limit tie fires for n-per-team -- the reference accumulates
  * total_time += 0.1 in binary64 and compares >= 10+2n (battle_env.py:168,316-319): 121, 141, 161, 181, 200 ... */
 int bsx_tie_tick(int n);
+
+/* hipStreamSynchronize(stream) for a binding that links no HIP runtime of its own: the single-game drop-in surface
+ * returns host values from step() (battle_env.py:374-381), so it has to wait for the launch it just enqueued. */
+int bsx_stream_synchronize(void* stream);
 
 #ifdef __cplusplus
 }

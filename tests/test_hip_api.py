@@ -169,3 +169,24 @@ def test_bench_bullet_heavy_workload_really_holds_many_bullets():
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["roofline"]["live_bullets_per_agent"] > 6.0, d["roofline"]["live_bullets_per_agent"]
     assert "keep-shooting" in d["config"]["workload"] and d["config"]["graph_len"] == 150
+
+
+def test_dropin_io_lives_in_pinned_host_memory_and_custom_rows_still_reach_the_device():
+    """Drop-in mode: the kernels read the action / random() block from and write obs / rewards / dones to pinned host memory
+    (no staging copies); a tensor that is neither device nor pinned memory must never be handed to a kernel -- the scripted
+    team uploads such rows first (instinct/team.py:10-15 surface)."""
+    import random as _r
+    from deep_rl_battlespace_amd.instinct import Team
+    _r.seed(5)
+    env = _env(n_agents=2)
+    for t in (env._obs, env._rew, env._done, env._env_done, env._winner):
+        assert not t.is_cuda and t.is_pinned()
+    obs = env.reset()
+    blue = Team(env.possible_blue, env.possible_red, env)
+    a1 = blue.choose_actions(obs)                                   # dict rows -> uploaded copy
+    a2 = blue.choose_actions()                                      # the env's own (pinned) rows
+    assert a1 == a2
+    acts = {a: 0 for a in env.possible_red}; acts.update(a1)
+    o, r, d, _ = env.step(acts)
+    assert set(o) == set(env.possible_agents) and all(v.dtype == np.float32 and v.shape == (env.obs_size,) for v in o.values())
+    np.testing.assert_array_equal(env.observe("plane0"), o["plane0"])
