@@ -69,6 +69,22 @@ __device__ unsigned long long* g_stamps = nullptr;
 #else
 #define STAMP(i) do { } while (0)
 #endif
+// -DBSX_STAMPS -DBSX_STAMPS_FINE: stamps 3..6 move INSIDE the shot phase (after the slot table / the Philox draw / sincos / the
+// first slot fetch); FSTAMP stores from every active lane (it sits in divergent code), the phase stamps 3..6 are off.
+#if defined(BSX_STAMPS) && defined(BSX_STAMPS_FINE)
+#define FSTAMP(i)                                                                                  \
+    do {                                                                                           \
+        unsigned long long t_;                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (g_stamps) g_stamps[size_t(blockIdx.x) * 10 + (i)] = t_;                                \
+    } while (0)
+#define PSTAMP(i) do { if ((i) < 3 || (i) > 6) STAMP(i); } while (0)
+#else
+#define FSTAMP(i) do { } while (0)
+#define PSTAMP(i) STAMP(i)
+#endif
 
 // obs / rew / done leave with the non-temporal hint: nothing on the step path reads them back, so they need not sit dirty in
 // the L2 until the end-of-kernel write-back (C2: 8.21 -> 8.02 us per step; -DBSX_X_PLAINSTORE builds ordinary stores for A/B).
@@ -200,15 +216,73 @@ __device__ inline double rotate_dir(double d, double ang) {
     d = d < 0.0 ? d + 360.0 : d;
     return d;
 }
+// a * b + c with c a compile-time constant held in an SGPR pair.  gfx950's VOP3 encoding takes no 64-bit literal, and for a Horner
+// step the compiler's choice is v_fmac into a VGPR pair it first fills with two v_mov: three vector instructions per coefficient
+// where one vector and two scalar ones do -- the scalar unit is otherwise idle here, the vector unit is what the step is bound by.
+__device__ inline double fma_k(double a, double b, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+// math.atan2(iy, ix) (battle_env.py:39) for integer pixel differences (|.| < 2^11): the device library's atan2, operation for
+// operation -- q = min / max of the magnitudes (correctly rounded quotient: reciprocal estimate, two Newton steps, one residual
+// correction), q + q * t * P(t) with t = q * q and its 20-coefficient odd minimax polynomial, then the octant / quadrant selects
+// and the sign of y -- minus what integers in this range never need (the quotient's range scaling and fix-up, infinities, NaNs),
+// and with the polynomial's coefficients in SGPRs (fma_k): 47 vector instructions instead of 88, the same bits (a device test
+// compares it with the library on every argument pair; -DBSX_X_LIBATAN builds the library call).
+// K independent evaluations in lockstep: with two waves per SIMD nothing else fills the ~8 cycles a dependent float64 operation
+// waits for its predecessor, so K chains advance together, stage by stage, and every coefficient is materialised once for all K.
+template <int K>
+__device__ inline void atan2_pixels_n(const int (&iy)[K], const int (&ix)[K], double (&out)[K]) {
+#ifdef BSX_X_LIBATAN
+#pragma unroll
+    for (int k = 0; k < K; ++k) out[k] = atan2(double(iy[k]), double(ix[k]));
+#else
+    double ax[K], ay[K], u[K], v[K], y[K], e[K], q[K], r[K], t[K], p[K];
+#define BSX_EACH _Pragma("unroll") for (int k = 0; k < K; ++k)
+    BSX_EACH { ax[k] = fabs(double(ix[k])); ay[k] = fabs(double(iy[k])); }
+    BSX_EACH { u[k] = fmax(fmax(ax[k], ay[k]), 1.0); v[k] = fmin(ax[k], ay[k]); }   // (1.0 only for ix = iy = 0: quotient 0, result 0, as the library's y == 0 case)
+    BSX_EACH y[k] = __builtin_amdgcn_rcp(u[k]);
+    BSX_EACH e[k] = __builtin_fma(-u[k], y[k], 1.0);
+    BSX_EACH y[k] = __builtin_fma(y[k], e[k], y[k]);
+    BSX_EACH e[k] = __builtin_fma(-u[k], y[k], 1.0);
+    BSX_EACH y[k] = __builtin_fma(y[k], e[k], y[k]);
+    BSX_EACH q[k] = v[k] * y[k];
+    BSX_EACH r[k] = __builtin_fma(-u[k], q[k], v[k]);
+    BSX_EACH q[k] = __builtin_fma(r[k], y[k], q[k]);
+    BSX_EACH t[k] = q[k] * q[k];
+    BSX_EACH p[k] = fma_k(t[k], 0x1.ba404b5e68a13p-17, -0x1.3e260bd3237f4p-13);
+#define BSX_HORNER(c) BSX_EACH p[k] = fma_k(t[k], p[k], c);
+    BSX_HORNER(0x1.b2bb069efb384p-11) BSX_HORNER(-0x1.7952daf56de9bp-9) BSX_HORNER(0x1.d6d43a595c56fp-8) BSX_HORNER(-0x1.c6ea4a57d9582p-7)
+    BSX_HORNER(0x1.67e295f08b19fp-6) BSX_HORNER(-0x1.e9ae6fc27006ap-6) BSX_HORNER(0x1.2c15b5711927ap-5) BSX_HORNER(-0x1.59976e82d3ff0p-5)
+    BSX_HORNER(0x1.82d5d6ef28734p-5) BSX_HORNER(-0x1.ae5ce6a214619p-5) BSX_HORNER(0x1.e1bb48427b883p-5) BSX_HORNER(-0x1.110e48b207f05p-4)
+    BSX_HORNER(0x1.3b13657b87036p-4) BSX_HORNER(-0x1.745d119378e4fp-4) BSX_HORNER(0x1.c71c717e1913cp-4) BSX_HORNER(-0x1.2492492376b7dp-3)
+    BSX_HORNER(0x1.99999999952ccp-3) BSX_HORNER(-0x1.5555555555523p-2)
+#undef BSX_HORNER
+    constexpr double PI_ = 0x1.921fb54442d18p+1, PI_2 = 0x1.921fb54442d18p+0;
+    BSX_EACH {
+        double a = __builtin_fma(q[k], t[k] * p[k], q[k]);
+        a = ay[k] > ax[k] ? PI_2 - a : a;
+        a = ix[k] < 0 ? PI_ - a : a;                                 // (the library's separate y == 0 case -- pi or 0 by the sign of x -- is what
+        out[k] = iy[k] < 0 ? -a : a;                                 //  q = 0 gives here anyway); copysign(a, y): a >= 0, and iy = 0 keeps +a
+    }
+#undef BSX_EACH
+#endif
+}
+__device__ inline double atan2_pixels(int iy, int ix) {
+    const int ys[1] = {iy}, xs[1] = {ix};
+    double o[1];
+    atan2_pixels_n<1>(ys, xs, o);
+    return o[0];
+}
 // rel_angle (battle_env.py:38-52), p0 = observer, p1 = target
 __device__ inline double rel_angle(int x0, int y0, double a0, int x1, int y1) {
-    double rads = atan2(double(y0 - y1), double(x0 - x1));
-    if (rads < 0.0) rads += TWO_PI;   // Python float %: fmod is exact for |rads| <= pi; -0.0 -> +0.0
-    else if (rads == 0.0) rads = 0.0;
+    double rads = atan2_pixels(y0 - y1, x0 - x1);
+    rads = rads < 0.0 ? rads + TWO_PI : (rads == 0.0 ? 0.0 : rads);   // Python float %: fmod is exact for |rads| <= pi; -0.0 -> +0.0
     const double degs = rads * RAD2DEG;
     double r = (180.0 + a0) - (360.0 - degs);
-    if (r < -180.0) r += 360.0;
-    if (r > 180.0) r -= 360.0;
+    r = r < -180.0 ? r + 360.0 : r;
+    r = r > 180.0 ? r - 360.0 : r;
     return r;
 }
 // rel_angle's second half: from rads (already reduced to [0, 2 pi)) to the wrapped difference with the observer's heading
@@ -220,10 +294,8 @@ __device__ inline double rel_from_rads(double rads, double a0) {
     return r;
 }
 __device__ inline double pair_rads(int x0, int y0, int x1, int y1) {   // rel_angle's first half: atan2 % 2 pi, observer p0
-    double rads = atan2(double(y0 - y1), double(x0 - x1));
-    if (rads < 0.0) rads += TWO_PI;
-    else if (rads == 0.0) rads = 0.0;
-    return rads;
+    const double rads = atan2_pixels(y0 - y1, x0 - x1);
+    return rads < 0.0 ? rads + TWO_PI : (rads == 0.0 ? 0.0 : rads);
 }
 // The two divisions by constants (battle_env.py:230-231) are multiplications by the float64 reciprocal here: the
 // float64 result can differ in its last bit, which survives the single rounding to float32 with probability ~2^-29.
@@ -251,6 +323,35 @@ __device__ inline double sqrt_pixels(int q) {
 __device__ inline float obs_dist(int x0, int y0, int x1, int y1) {
     const int dx = x0 - x1, dy = y0 - y1;
     return float(sqrt_pixels(dx * dx + dy * dy) * (2.0 / FIELD_DIAG) - 1.0);
+}
+// Range (obs_dist) and bearing (pair_rads) from (x, y) to K targets, the K evaluations in lockstep (see atan2_pixels_n).
+template <int K>
+__device__ inline void geometry_n(int x, int y, const int (&tx)[K], const int (&ty)[K], float (&d)[K], double (&rads)[K]) {
+    int dx[K], dy[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { dx[k] = x - tx[k]; dy[k] = y - ty[k]; }
+#ifdef BSX_X_LIBSQRT
+#pragma unroll
+    for (int k = 0; k < K; ++k) d[k] = obs_dist(x, y, tx[k], ty[k]);
+#else
+    double q[K], w[K], g[K], h[K], r[K], c[K];
+#define BSX_EACH _Pragma("unroll") for (int k = 0; k < K; ++k)
+    BSX_EACH q[k] = double(__mul24(dx[k], dx[k]) + __mul24(dy[k], dy[k]));           // |dx|, |dy| < 2^11
+    BSX_EACH w[k] = __builtin_amdgcn_rsq(q[k]);
+    BSX_EACH { g[k] = q[k] * w[k]; h[k] = w[k] * 0.5; }
+    BSX_EACH r[k] = __builtin_fma(-h[k], g[k], 0.5);
+    BSX_EACH { g[k] = __builtin_fma(g[k], r[k], g[k]); h[k] = __builtin_fma(h[k], r[k], h[k]); }
+    BSX_EACH c[k] = __builtin_fma(-g[k], g[k], q[k]);
+    BSX_EACH g[k] = __builtin_fma(c[k], h[k], g[k]);
+    BSX_EACH c[k] = __builtin_fma(-g[k], g[k], q[k]);
+    BSX_EACH g[k] = __builtin_fma(c[k], h[k], g[k]);
+    BSX_EACH d[k] = float((q[k] == 0.0 ? 0.0 : g[k]) * (2.0 / FIELD_DIAG) - 1.0);
+#undef BSX_EACH
+#endif
+    double a[K];
+    atan2_pixels_n<K>(dy, dx, a);
+#pragma unroll
+    for (int k = 0; k < K; ++k) rads[k] = a[k] < 0.0 ? a[k] + TWO_PI : (a[k] == 0.0 ? 0.0 : a[k]);
 }
 __device__ inline float obs_angle(int x0, int y0, double a0, int x1, int y1) {
     return float(rel_angle(x0, y0, a0, x1, y1) * (1.0 / 360.0));
@@ -338,6 +439,19 @@ __device__ inline void spawn_plane(uint64_t seed, int64_t genv, uint32_t stream,
 }
 
 enum Mode : int { M_INERT = 0, M_TIE = 1, M_PHYS = 2, M_RESET = 3 };
+
+// bsx_tie_tick(n) at compile time (battle_env.py:168,316-319: total_time += 0.1 in binary64 until >= 10 + 2n), for the kernels
+// templated on n: one kernel argument fewer to fetch -- it was the one scalar load the compiler issued inside the branch that
+// needs it, a fully exposed round trip of ~900 cycles (in-kernel stamps, r02am).
+constexpr int tie_tick_const(int n) {
+    const double max_time = double(10 + n * 2);
+    double t = 0.0;
+    int k = 0;
+    do { t += 0.1; ++k; } while (!(t >= max_time));
+    return k;
+}
+static_assert(tie_tick_const(1) == 121 && tie_tick_const(2) == 141 && tie_tick_const(3) == 161 && tie_tick_const(4) == 181 &&
+              tie_tick_const(5) == 200, "time-limit tick");
 
 // The scripted opponent's target choice and discrete action (instinct/agent.py:10-39,56-62) from one observation row,
 // ob(k) = value k of the row: score every target by dist * |angle| (base first, strict '<' keeps the first minimum, a dead
@@ -449,7 +563,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     __shared__ double s_pr_all[(N >= 2) ? WAVES * SPB * N : 1];     // the owner's bearing in radians, [0, 2 pi)
     // wave-packed bullet pass (N = 1 .. 4): the bullets of ALL lanes of the wave are laid out back to back as work slots
     constexpr bool PACK = PACK_BULLETS && N >= 1 && N <= 4;
-    constexpr int OWN_CAP = SPB * (K + 1);                 // every lane with a full list plus this call's shot
+    constexpr int OWN_CAP = SPB * (K + 1) + 2;             // every lane with a full list plus this call's shot (+ one scratch entry, see part 1)
     __shared__ uint16_t s_own_all[PACK ? WAVES * OWN_CAP : 1];   // slot -> owner lane | item index << 8 | "this call's shot" << 15
     __shared__ uint32_t s_agg_all[PACK ? WAVES * SPB : 1];       // per owner: survivor bit per entry | misses << 16 | base hits << 24
     __shared__ uint32_t s_eb_all[PACK ? WAVES * SPB : 1];        // per owner: enemy base x | y << 16
@@ -499,6 +613,9 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
                 r.c0 = ap[0]; r.c1 = ap[1]; r.c2 = ap[2];
             }
         }
+        // (the loads above need nothing but preloaded kernel arguments: they must be in flight BEFORE anything waits for the
+        //  kernarg segment's scalar fetch -- p.u is the first thing that does)
+        __builtin_amdgcn_sched_barrier(0);
         if (ut) r.uu = ut[g];                            // uniform branch
     };
     // MULTI: what one call hands to the next stays in REGISTERS -- my plane, my game's record and episode count (every
@@ -563,6 +680,9 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // values all of that hangs on through an empty asm makes it per-tick work again, as in the one-call kernel.
     size_t gt = g, EAt = EA;
     uint64_t seed_t = p.seed;
+    int64_t env_offset_t = p.env_offset;
+    constexpr int TIE_C = tie_tick_const(N > 0 ? N : 1);
+    int tie_tick = (N > 0) ? TIE_C : p.tie_tick;
     if (MULTI) {
         asm volatile("" : "+v"(gt));
         asm volatile("" : "+s"(EAt));
@@ -581,6 +701,12 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         games = cnt4.x;
         const uint4 prw = reinterpret_cast<const uint4*>(plane_)[gt];
         if (!MULTI) load_inputs(0, rin);
+        if (!MULTI) {
+            // every kernel argument the step needs later is fetched HERE, in the shadow of the first vector loads: left to
+            // the compiler, the ones first used inside a branch are loaded there -- a cold scalar fetch with nothing to hide it
+            asm volatile("" : "+s"(seed_t), "+s"(env_offset_t));
+            if (N == 0) asm volatile("" : "+s"(tie_tick));
+        }
         unpack_plane(prw, x, y, live, hp, dir);
         er = unpack_env(erw);
     }
@@ -698,14 +824,14 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     else if ((p.flags & BSX_F_EMPTY_CALL) || !any_alive) mode = M_TIE;
     else {
         tick += 1;
-        mode = (tick >= p.tie_tick) ? M_TIE : M_PHYS;
+        mode = (tick >= tie_tick) ? M_TIE : M_PHYS;
     }
     if (!env_ok) mode = M_INERT;
 
     int4 cnt_delta = make_int4(0, 0, 0, 0);              // games, ties, red wins, blue wins
     const int x0 = x, y0 = y;
     const double d0 = dir;
-    const int64_t genv = p.env_offset + ec;
+    const int64_t genv = env_offset_t + ec;
     // does this call fire? (battle_env.py:404-406 / :423; the shot leaves from the PRE-move pose, so it is prepared first:
     // its Philox draw and sincos run while the heading-table entry of the move below is still on its way from the L2)
     if (CONT) a2 = fmin(fmax(a2, -1.0), 1.0);
@@ -721,6 +847,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // so the lanes of a round read and write along rows, as coalesced as a per-lane walk -- also when lists are long.
     // Slot w is served by lane w % 64 in round w / 64; the slot of (lane l, entry k) = #entries below k in the wave + #lanes
     // below l that have an entry k: one ballot per k.
+    FSTAMP(3);
     int slots = 0;                                       // wave total
     struct Slot { int o, k; bool isnew, on; uint32_t wd; double2 dd; size_t go; };   // owner lane, list index, "this call's shot", in use; entry; owner's row
     Slot cur = {0, 0, false, false, 0u, make_double2(0.0, 0.0), 0};
@@ -741,8 +868,24 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     };
     if constexpr (PACK) {
         const int ci = phys ? cnt0 + (spawn ? 1 : 0) : 0;
-        for (int k = 0;; ++k) {
-            const unsigned long long hk = __ballot(k < ci);          // lanes that have an entry k
+        // The first UNR list indices straight-line: a loop iteration here is a chain of vector compare -> scalar test -> branch
+        // (~230 cycles each in the stamps, 5 to 6 of them under uniform play); without the branches an index costs ~10
+        // instructions -- a lane without an entry k writes the scratch entry behind the table instead of being masked off.
+#ifdef BSX_X_SLOTLOOP
+        constexpr int UNR = 0;
+#else
+        constexpr int UNR = 6;
+#endif
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            const bool h = k < ci;
+            const unsigned long long hk = __ballot(h);               // lanes that have an entry k
+            const int w = slots + int(__builtin_amdgcn_mbcnt_hi(uint32_t(hk >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(hk), 0u)));
+            s_own[h ? w : OWN_CAP - 1] = uint16_t(uint32_t(lane) | (uint32_t(k) << 8) | ((k == cnt0) ? 0x8000u : 0u));
+            slots += __popcll(hk);
+        }
+        for (int k = UNR;; ++k) {
+            const unsigned long long hk = __ballot(k < ci);
             if (hk == 0ull) break;
             if (k < ci) {
                 const int w = slots + int(__builtin_amdgcn_mbcnt_hi(uint32_t(hk >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(hk), 0u)));
@@ -750,12 +893,14 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
             }
             slots += __popcll(hk);
         }
+        FSTAMP(4);
         s_agg[tid] = 0u;
         s_eb[tid] = pack_xy(team == 0 ? er.bbx : er.brx, team == 0 ? er.bby : er.bry);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    FSTAMP(5);
     double2 nd = make_double2(0.0, 0.0);
     if (spawn) {
         double uu = uu_in;
@@ -778,7 +923,9 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         cur = fetch_slot(0);
         if (MULTI && !ACTOR && tk + 1 < p.T) load_inputs(tk + 1, rin_next);   // behind this tick's own loads
     }
+    FSTAMP(6);
 
+    STAMP(2);
     if (mode == M_RESET) {
         // re-spawn in place of the inert call; episode id = games played so far
         EnvRec nb; memset(&nb, 0, sizeof(nb));
@@ -824,19 +971,25 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         __builtin_amdgcn_wave_barrier();
     }
 
-    STAMP(2);
-    STAMP(3);                                            // (the shot is prepared before the move now: phase 2 -> 3 is empty)
+    PSTAMP(3);
     // ---- observation geometry (battle_env.py:202-244) from the staged block, BEFORE the bullets: poses are final after
     //      the move, only the alive flags can still change; this fp64 math runs while the bullet-step loads are in flight.
     const int obx = team == 0 ? er.bbx : er.brx, oby = team == 0 ? er.bby : er.bry;   // enemy base
     float ob_d = -1.0f, ob_a = -1.0f;
     float oe_d[NE], oe_a[NE];
     int ex[NE], ey[NE];
-    if (!(DIAG & 1u)) obs_pair(x, y, dir, obx, oby, ob_d, ob_a);
-    if constexpr (N == 1) {
+    if constexpr (N == 0) {                                          // runtime-n build: the enemy planes' pairs are worked out at row assembly
+        if (!(DIAG & 1u)) obs_pair(x, y, dir, obx, oby, ob_d, ob_a);
+    } else if constexpr (N == 1) {
         ex[0] = nx_; ey[0] = ny_;
         oe_d[0] = -1.0f; oe_a[0] = -1.0f;
-        if (!(DIAG & 1u)) obs_pair(x, y, dir, ex[0], ey[0], oe_d[0], oe_a[0]);
+        if (!(DIAG & 1u)) {                                          // enemy base and enemy plane, the two evaluations in lockstep
+            const int tx[2] = {obx, nx_}, ty[2] = {oby, ny_};
+            float d[2]; double rd[2];
+            geometry_n<2>(x, y, tx, ty, d, rd);
+            ob_d = d[0]; ob_a = float(rel_from_rads(rd[0], dir) * (1.0 / 360.0));
+            oe_d[0] = d[1]; oe_a[0] = float(rel_from_rads(rd[1], dir) * (1.0 / 360.0));
+        }
     } else if constexpr (N >= 2) {
         // The range of a pair is symmetric and its bearing differs by pi between the two ends, so each red-blue pair is
         // worked out once -- by red plane i for blue j when i + j is even, by blue j otherwise -- in (N + 1) / 2 rounds of
@@ -848,16 +1001,25 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
 #pragma unroll
         for (int j = 0; j < NE; ++j) { ex[j] = s_x[eb + j]; ey[j] = s_y[eb + j]; oe_d[j] = -1.0f; oe_a[j] = -1.0f; }
         if (!(DIAG & 1u)) {
+            // the enemy base and the (N + 1) / 2 pairs this lane owns: all evaluations in lockstep (geometry_n)
+            constexpr int R = (N + 1) / 2;
+            int tx[R + 1], ty[R + 1], ojc[R];
+            float d[R + 1]; double rd[R + 1];
+            tx[0] = obx; ty[0] = oby;
 #pragma unroll
-            for (int r = 0; r < (N + 1) / 2; ++r) {
+            for (int r = 0; r < R; ++r) {
                 const int oj = (team == 0 ? (mi & 1) : ((mi + 1) & 1)) + 2 * r;   // the enemy I own in this round
+                ojc[r] = min(oj, N - 1);
+                tx[r + 1] = s_x[eb + ojc[r]]; ty[r + 1] = s_y[eb + ojc[r]];
+            }
+            geometry_n<R + 1>(x, y, tx, ty, d, rd);
+            ob_d = d[0]; ob_a = float(rel_from_rads(rd[0], dir) * (1.0 / 360.0));
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int oj = (team == 0 ? (mi & 1) : ((mi + 1) & 1)) + 2 * r;
                 const bool own = oj < N && a < A;
-                const int ojc = min(oj, N - 1);
-                const int tx = s_x[eb + ojc], ty = s_y[eb + ojc];
-                const float d = obs_dist(x, y, tx, ty);
-                const double rads = pair_rads(x, y, tx, ty);
-                const int slot = (gl + (team == 0 ? mi : ojc)) * N + (team == 0 ? ojc : mi);   // [red plane of my game][blue index]
-                if (own) { s_pd[slot] = d; s_pr[slot] = rads; }
+                const int slot = (gl + (team == 0 ? mi : ojc[r])) * N + (team == 0 ? ojc[r] : mi);   // [red plane of my game][blue index]
+                if (own) { s_pd[slot] = d[r + 1]; s_pr[slot] = rd[r + 1]; }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -876,7 +1038,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         }
     }
 
-    STAMP(4);
+    PSTAMP(4);
     // ---- Bullet.update (sprites.py:321-351) per list entry ("item"), predicates as integer sign masks (0 / -1).
     //      Survivors are written back compacted (position `pos` <= own index), which keeps creation order.
     constexpr int FW = (N > 0 && N <= 4) ? 4 : 16;       // bits per overlap field, indexed by AGE (1..11)
@@ -1077,7 +1239,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         if (N != 1 && nbase) __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)(&s_bhit[gl + team]), nbase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (phys) live = uint32_t(pos);
     }
-    STAMP(5);
+    PSTAMP(5);
     // ---- ordered plane-hit resolve (battle_env.py:332-360 with sprites.py:348-350): creation order = oldest age
     //      first, then shooter id; a plane killed earlier in the walk no longer stops later bullets.
     uint64_t any_ovl = 0;
@@ -1156,7 +1318,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         er.winner = BSX_WINNER_TIE; er.done = 1; cnt_delta.x += 1; cnt_delta.y += 1;
     }
 
-    STAMP(6);
+    PSTAMP(6);
     if (MULTI && !ACTOR && tk + 1 < p.T) din_next = decode(rin_next);   // the prefetch has long arrived; no store of this tick is out yet
     // ---- write back (MULTI: plane and game records travel in registers; memory gets them once, after the last tick)
     const bool last_tick = !MULTI || tk == p.T - 1;
@@ -1630,6 +1792,29 @@ int bsx_rollout_continuous(void* state, int64_t E, int n, int T, const float* we
                            int64_t env_offset, void* stream) {
     return launch_rollout<true>(state, E, n, T, weights, precision, -1, obs, scores, rew, done, env_done, winner, env_done_t, cfg, flags,
                                 noise, actor_seed, seq, seq_base, seed, env_offset, stream);
+}
+
+// Self-test of atan2_pixels against the device library on the square [-R, R]^2 of argument pairs: out[0] = pairs whose 64-bit
+// results differ, out[1] = pairs tested.
+__global__ void bsx_selftest_atan2_kernel(int R, unsigned long long* out) {
+    const int W = 2 * R + 1;
+    const long long total = (long long)W * W;
+    unsigned long long bad = 0, seen = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int iy = int(i / W) - R, ix = int(i % W) - R;
+        const double mine = atan2_pixels(iy, ix), lib = atan2(double(iy), double(ix));
+        bad += (__double_as_longlong(mine) != __double_as_longlong(lib)) ? 1ull : 0ull;
+        seen += 1ull;
+    }
+    atomicAdd(&out[0], bad); atomicAdd(&out[1], seen);
+}
+int bsx_selftest_atan2(int R, uint64_t* out, void* stream) {
+    if (!out || R < 0 || R > 4096) return BSX_E_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t err = hipMemsetAsync(out, 0, 2 * sizeof(uint64_t), st);
+    if (err != hipSuccess) return int(err);
+    bsx_selftest_atan2_kernel<<<1024, 256, 0, st>>>(R, reinterpret_cast<unsigned long long*>(out));
+    return int(hipGetLastError());
 }
 
 int bsx_observe(void* state, int64_t E, int n, float* obs, void* stream) {

@@ -227,6 +227,12 @@ int bsx_instinct_continuous(const float* obs, double* actions, const double* rnd
  * total_time += 0.1 in binary64 and compares >= 10+2n (battle_env.py:168,316-319): 121, 141, 161, 181, 200 ... */
 int bsx_tie_tick(int n);
 
+/* Self-test: the step path computes math.atan2 of pixel differences (battle_env.py:39) with its own instruction sequence --
+ * the device library's algorithm with its constants held in scalar registers.  Counts the argument pairs (iy, ix) of
+ * [-R, R]^2, R <= 4096 (the field is 1200 x 800), whose binary64 result differs from the library's: out[0] = differing,
+ * out[1] = tested (device uint64[2]). */
+int bsx_selftest_atan2(int R, uint64_t* out, void* stream);
+
 /* hipStreamSynchronize(stream) for a binding that links no HIP runtime of its own: the single-game drop-in surface
  * returns host values from step() (battle_env.py:374-381), so it has to wait for the launch it just enqueued. */
 int bsx_stream_synchronize(void* stream);

@@ -4,10 +4,11 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 # the stamped build is a VARIANT next to the product library (tools/build_variant.py), selected through BSX_LIB_PATH for this
 # process only -- the product file is never renamed or overwritten, so a kill or timeout here cannot leave a wrong library behind
-V = os.path.join(ROOT, "deep-rl-battlespace_amd/csrc/variants/lib_stamps.so")
+V = os.path.join(ROOT, "deep-rl-battlespace_amd/csrc/variants", os.environ.get("BSX_STAMPS_LIB", "lib_stamps.so"))   # another stamped variant: BSX_STAMPS_LIB=lib_<name>.so
 if not os.path.exists(V):
     subprocess.run([sys.executable, os.path.join(ROOT, "tools/build_variant.py"), "stamps", "-DBSX_STAMPS"], check=True)
 os.environ["BSX_LIB_PATH"], os.environ["BSX_ALLOW_DIAG"] = V, "1"
+FINE = "fine" in os.path.basename(V)                                   # a -DBSX_STAMPS_FINE variant: stamps 3..6 sit inside the shot phase
 if True:
     import deep_rl_battlespace_amd as bsx
     from deep_rl_battlespace_amd import _lib
@@ -45,11 +46,17 @@ if True:
             env.step_batch(acts[t])
         torch.cuda.synchronize()
         s10 = buf.cpu().numpy().reshape(waves, 10).astype(np.float64)
-        s = s10[:, :8]; pre += (s10[:, 0] - s10[:, 8]).mean(); fence += (s10[:, 9] - s10[:, 7]).mean()
+        s = s10[:, :8]
+        if FINE:
+            s = s[:, [0, 1, 3, 4, 5, 6, 2, 7]]
+        pre += (s10[:, 0] - s10[:, 8]).mean(); fence += (s10[:, 9] - s10[:, 7]).mean()
         d = np.diff(s, axis=1)
         tot[:7] += d.mean(0); reps += 1
         span.append(((s[:, 7].max() - s[:, 0].min()), (s[:, 7] - s[:, 0]).mean(), (s[:, 0].max() - s[:, 0].min())))
-    names = ["T0 loads -> plane record, heading-table request", "classify, slot table, shot (philox, sincos), move", "pose hand-off, staging", "obs geometry", "bullet rounds (packed pass, part 2)", "resolve + rewards / game end", "stores"]
+    names = ["T0 loads -> plane record, heading-table request", "classify, slot table, shot (philox, sincos), first slot fetch", "move (or re-spawn), pose hand-off, staging", "obs geometry", "bullet rounds (packed pass, part 2)", "resolve + rewards / game end", "stores"]
+    if FINE:
+        names = ["T0 loads -> plane record, heading-table request", "group ballot, call mode", "slot table (one ballot + LDS write per list index)", "LDS init, wave barrier",
+                 "shot (Philox, sincos, ring store), first slot fetch", "move (or re-spawn) -> hand-off [phase stamps 3..6 are off]", "everything else up to the stores' end"]
     tot /= reps
     print(f"E={E} n={n} waves={waves}; s_memtime ticks, mean over waves (divide the printed value by 10 for shader cycles)")
     print(f"  {'kernel entry -> first kernarg use (p.E)':40s} {pre / reps * 10:9.1f} ns")
