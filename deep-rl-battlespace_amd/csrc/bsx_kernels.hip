@@ -901,6 +901,12 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     FSTAMP(5);
+#ifndef BSX_X_LATEFETCH
+    // the first round's entries are requested as soon as the slot table exists -- BEFORE the shot: the ~150 cycles of the table's
+    // LDS round trip are exposed here, and the loads leave ~1.5k cycles (Philox + sincos) earlier; they are what the bullet
+    // rounds wait for, and the move + observation geometry alone are shorter than a round trip to the MALL / HBM
+    if constexpr (PACK) cur = fetch_slot(0);
+#endif
     double2 nd = make_double2(0.0, 0.0);
     if (spawn) {
         double uu = uu_in;
@@ -918,9 +924,9 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     if constexpr (PACK) {                                // this call's shot as the work slot will read it: list word (age 0) + step
         s_nw[tid] = pack_bullet(x, y, 0);
         s_nd[2 * tid] = nd.x; s_nd[2 * tid + 1] = nd.y;
-        // the first round's entries: requested HERE, behind the shot's Philox + sincos, which covered the slot table's LDS round
-        // trip; the loads themselves are covered by the move and the observation geometry
-        cur = fetch_slot(0);
+#ifdef BSX_X_LATEFETCH
+        cur = fetch_slot(0);                             // (round 2's first placement: behind the shot, which covered the table's LDS round trip)
+#endif
         if (MULTI && !ACTOR && tk + 1 < p.T) load_inputs(tk + 1, rin_next);   // behind this tick's own loads
     }
     FSTAMP(6);
