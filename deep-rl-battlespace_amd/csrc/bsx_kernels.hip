@@ -232,6 +232,11 @@ __device__ inline double fma_k(double a, double b, double c) {
 // compares it with the library on every argument pair; -DBSX_X_LIBATAN builds the library call).
 // K independent evaluations in lockstep: with two waves per SIMD nothing else fills the ~8 cycles a dependent float64 operation
 // waits for its predecessor, so K chains advance together, stage by stage, and every coefficient is materialised once for all K.
+__constant__ double ATAN2_COEF[20] = {
+    0x1.ba404b5e68a13p-17, -0x1.3e260bd3237f4p-13, 0x1.b2bb069efb384p-11, -0x1.7952daf56de9bp-9, 0x1.d6d43a595c56fp-8,
+    -0x1.c6ea4a57d9582p-7, 0x1.67e295f08b19fp-6, -0x1.e9ae6fc27006ap-6, 0x1.2c15b5711927ap-5, -0x1.59976e82d3ff0p-5,
+    0x1.82d5d6ef28734p-5, -0x1.ae5ce6a214619p-5, 0x1.e1bb48427b883p-5, -0x1.110e48b207f05p-4, 0x1.3b13657b87036p-4,
+    -0x1.745d119378e4fp-4, 0x1.c71c717e1913cp-4, -0x1.2492492376b7dp-3, 0x1.99999999952ccp-3, -0x1.5555555555523p-2};
 template <int K>
 __device__ inline void atan2_pixels_n(const int (&iy)[K], const int (&ix)[K], double (&out)[K]) {
 #ifdef BSX_X_LIBATAN
@@ -251,14 +256,31 @@ __device__ inline void atan2_pixels_n(const int (&iy)[K], const int (&ix)[K], do
     BSX_EACH r[k] = __builtin_fma(-u[k], q[k], v[k]);
     BSX_EACH q[k] = __builtin_fma(r[k], y[k], q[k]);
     BSX_EACH t[k] = q[k] * q[k];
-    BSX_EACH p[k] = fma_k(t[k], 0x1.ba404b5e68a13p-17, -0x1.3e260bd3237f4p-13);
+#ifdef BSX_X_ATAN_LITERALS
+    constexpr bool TABLE = false;
+#else
+    constexpr bool TABLE = K <= 2;                       // measured: 1v1 (K = 2) 7.40 -> 7.34 us; 4v4 (K = 3) 24.0 -> 24.4, so literals there
+#endif
+    if constexpr (TABLE) {
+        // The 20 coefficients come from constant memory: three scalar loads (8 + 8 + 4 doubles) instead of forty s_mov.  With two
+        // waves per SIMD the step is bound by the SIMD's issue port -- one instruction of ANY class per ~4 cycles
+        // (tools/micro/issue_rates.hip) -- so what counts is the number of instructions, not which unit runs them.
+        typedef const double __attribute__((address_space(4))) * const_f64_ptr;   // constant address space: uniform reads become s_load
+        const_f64_ptr C = (const_f64_ptr)(unsigned long long)(&ATAN2_COEF[0]);
+        asm("" : "+s"(C));                                   // (an opaque address: otherwise the table is folded back into 40 literal moves)
+        BSX_EACH p[k] = __builtin_fma(t[k], C[0], C[1]);
+#pragma unroll
+        for (int i = 2; i < 20; ++i) { BSX_EACH p[k] = __builtin_fma(t[k], p[k], C[i]); }
+    } else {
+        BSX_EACH p[k] = fma_k(t[k], 0x1.ba404b5e68a13p-17, -0x1.3e260bd3237f4p-13);
 #define BSX_HORNER(c) BSX_EACH p[k] = fma_k(t[k], p[k], c);
-    BSX_HORNER(0x1.b2bb069efb384p-11) BSX_HORNER(-0x1.7952daf56de9bp-9) BSX_HORNER(0x1.d6d43a595c56fp-8) BSX_HORNER(-0x1.c6ea4a57d9582p-7)
-    BSX_HORNER(0x1.67e295f08b19fp-6) BSX_HORNER(-0x1.e9ae6fc27006ap-6) BSX_HORNER(0x1.2c15b5711927ap-5) BSX_HORNER(-0x1.59976e82d3ff0p-5)
-    BSX_HORNER(0x1.82d5d6ef28734p-5) BSX_HORNER(-0x1.ae5ce6a214619p-5) BSX_HORNER(0x1.e1bb48427b883p-5) BSX_HORNER(-0x1.110e48b207f05p-4)
-    BSX_HORNER(0x1.3b13657b87036p-4) BSX_HORNER(-0x1.745d119378e4fp-4) BSX_HORNER(0x1.c71c717e1913cp-4) BSX_HORNER(-0x1.2492492376b7dp-3)
-    BSX_HORNER(0x1.99999999952ccp-3) BSX_HORNER(-0x1.5555555555523p-2)
+        BSX_HORNER(0x1.b2bb069efb384p-11) BSX_HORNER(-0x1.7952daf56de9bp-9) BSX_HORNER(0x1.d6d43a595c56fp-8) BSX_HORNER(-0x1.c6ea4a57d9582p-7)
+        BSX_HORNER(0x1.67e295f08b19fp-6) BSX_HORNER(-0x1.e9ae6fc27006ap-6) BSX_HORNER(0x1.2c15b5711927ap-5) BSX_HORNER(-0x1.59976e82d3ff0p-5)
+        BSX_HORNER(0x1.82d5d6ef28734p-5) BSX_HORNER(-0x1.ae5ce6a214619p-5) BSX_HORNER(0x1.e1bb48427b883p-5) BSX_HORNER(-0x1.110e48b207f05p-4)
+        BSX_HORNER(0x1.3b13657b87036p-4) BSX_HORNER(-0x1.745d119378e4fp-4) BSX_HORNER(0x1.c71c717e1913cp-4) BSX_HORNER(-0x1.2492492376b7dp-3)
+        BSX_HORNER(0x1.99999999952ccp-3) BSX_HORNER(-0x1.5555555555523p-2)
 #undef BSX_HORNER
+    }
     constexpr double PI_ = 0x1.921fb54442d18p+1, PI_2 = 0x1.921fb54442d18p+0;
     BSX_EACH {
         double a = __builtin_fma(q[k], t[k] * p[k], q[k]);
@@ -1808,8 +1830,15 @@ __global__ void bsx_selftest_atan2_kernel(int R, unsigned long long* out) {
     unsigned long long bad = 0, seen = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int iy = int(i / W) - R, ix = int(i % W) - R;
-        const double mine = atan2_pixels(iy, ix), lib = atan2(double(iy), double(ix));
-        bad += (__double_as_longlong(mine) != __double_as_longlong(lib)) ? 1ull : 0ull;
+        const double lib = atan2(double(iy), double(ix));
+        const double one = atan2_pixels(iy, ix);                       // K = 1: coefficients from the constant table
+        const int ys[3] = {iy, ix, -iy}, xs[3] = {ix, iy, ix};        // K = 3: coefficients as literals (the 3v3 / 4v4 kernels)
+        double three[3];
+        atan2_pixels_n<3>(ys, xs, three);
+        const bool ok = __double_as_longlong(one) == __double_as_longlong(lib) && __double_as_longlong(three[0]) == __double_as_longlong(lib) &&
+                        __double_as_longlong(three[1]) == __double_as_longlong(atan2(double(ix), double(iy))) &&
+                        __double_as_longlong(three[2]) == __double_as_longlong(atan2(double(-iy), double(ix)));
+        bad += ok ? 0ull : 1ull;
         seen += 1ull;
     }
     atomicAdd(&out[0], bad); atomicAdd(&out[1], seen);
