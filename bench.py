@@ -238,7 +238,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not run the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) that measure the headline's HBM bytes; "
                          "roofline.traffic then comes from profiles/traffic.json")
-    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default=None,
                     help="process-group backend for the barrier / timing reduction (nccl = RCCL; gloo only to rehearse N>1 on a 1-GPU box)")
     ap.add_argument("--rehearse-on-device0", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (implies --backend gloo; at most 6 ranks may share the card)")
@@ -297,8 +297,8 @@ def self_launch(args):
 
 def main():
     args = parse_args()
-    if args.rehearse_on_device0:
-        args.backend = "gloo"
+    if args.backend is None:
+        args.backend = "gloo" if args.rehearse_on_device0 else "nccl"
     if args.gpus > 1 and "RANK" not in os.environ:
         self_launch(args)
 
@@ -312,15 +312,33 @@ def main():
     dev_index = 0 if args.rehearse_on_device0 else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    red_dev = dev if args.backend == "nccl" else torch.device("cpu")
+    backend_note = None
     if world > 1:                                           # used for the barrier / max-time reduction only
+        import datetime
         if args.backend == "nccl":
+            # RCCL carries nothing but the barrier and two tiny reductions here (the step path has no collective), so a node on
+            # which it cannot come up must not cost the measurement: every rank then falls back to gloo, and the line says so
             try:
-                dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
-            except TypeError:                                   # older torch: no device_id argument
-                dist.init_process_group("nccl")
+                try:
+                    dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=180))  # RCCL over xGMI
+                except TypeError:                                   # older torch: no device_id argument
+                    dist.init_process_group("nccl", timeout=datetime.timedelta(seconds=180))
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize(dev)
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"all_reduce probe returned {probe.item()} for world size {world}")
+            except Exception as exc:                            # noqa: BLE001 -- whatever RCCL raised, the fallback is the same
+                backend_note = f"nccl (RCCL) did not come up: {type(exc).__name__}: {str(exc)[:160]}; gloo carries the barrier instead"
+                try:
+                    dist.destroy_process_group()
+                except Exception:                               # noqa: BLE001
+                    pass
+                args.backend = "gloo"
+                dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=180))
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=180))
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -613,6 +631,7 @@ def main():
                                    f"staggered game clocks (BASELINE.json configs[{1 if n == 1 else 2}]{' x ' + str(world) + ' shards' if world > 1 else ''})",
                        "envs_per_gpu": E, "n_agents_per_team": n, "agents_per_env": A, "launch": args.mode,
                        "graph_len": head["G"] if args.mode == "graph" else None, "parallelism": f"{world} independent env shards, no collective",
+                       "process_group": (args.backend if world > 1 else None), "process_group_note": backend_note,
                        "rehearsal_all_ranks_on_device0": bool(args.rehearse_on_device0) or None},
             "timing": {"repeats": len(head["walls"]), "statistic": "median", "ramp_ms": args.ramp_ms,
                        "ms_per_step_samples": [round(w / K * 1e3, 6) for w in head["walls"]],
