@@ -507,8 +507,10 @@ def main():
             live = round(float(env.export_state(("bl_live",))["bl_live"].float().sum()) / (E * A), 3)
         return dict(env=env, walls=walls, kms=kms, G=G, live=live, Kb=Kb or K)
 
-    def kernel_name(n, continuous, many):
-        return f"bsx_step_kernel<{n if n <= 4 else 0},{'true' if continuous else 'false'},{'true' if many else 'false'},false,false>"   # <N, CONT, MULTI, ACTOR, LG>
+    def kernel_name(n, continuous, many, E):
+        narrow = E * 2 * n * 200 <= 0xFFFFFFFF            # csrc narrow_offsets_ok(): 32-bit offsets while every array stays below 4 GB
+        return (f"bsx_step_kernel<{n if n <= 4 else 0},{'true' if continuous else 'false'},{'true' if many else 'false'},false,false,"
+                f"{'true' if narrow else 'false'}>")       # <N, CONT, MULTI, ACTOR, LG, OFF32>
 
     def traffic_entry(key):
         try:
@@ -522,7 +524,7 @@ def main():
         km, wall = statistics.median(m["kms"]), statistics.median(m["walls"])
         ach = b_alg(n, continuous) * E * A / (km * 1e-3) / 1e9
         out = {"agent_steps_per_s": round(E * A * K / wall, 1), "avg_launch_us": round(km * 1e3, 3), "roofline_frac": round(ach / HBM_PEAK_GBS, 4),
-               "kernel": kernel_name(n, continuous, many), "steps": K, "repeats": len(m["kms"]),
+               "kernel": kernel_name(n, continuous, many, E), "steps": K, "repeats": len(m["kms"]),
                "live_bullets_per_agent": m["live"]}
         te = traffic_entry(key) if key else None
         if te:
@@ -614,7 +616,7 @@ def main():
             while Gw < A:
                 Gw *= 2
             grid_threads = ((E + 64 // Gw - 1) // (64 // Gw)) * 64
-            live_b, info = live_traffic(args, kernel_name(n, args.continuous, many), grid_threads)
+            live_b, info = live_traffic(args, kernel_name(n, args.continuous, many, E), grid_threads)
             if live_b is not None:
                 traffic, tdetail = live_b, info
                 tsrc = ("measured by this run: two child passes of this script under rocprofv3 --kernel-trace --pmc (FETCH_SIZE, WRITE_SIZE "
@@ -643,7 +645,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "frac_on_traffic": round(traffic / (km * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
                          "traffic_source": tsrc, "traffic_detail": tdetail,
-                         "kernel": kernel_name(n, args.continuous, many), "avg_launch_us": round(km * 1e3, 3),
+                         "kernel": kernel_name(n, args.continuous, many, E), "avg_launch_us": round(km * 1e3, 3),
                          "algorithmic_bytes_per_launch": round(bytes_per_launch), "bytes_per_agent_step": round(b_alg(n, args.continuous), 2),
                          # SURVEY.md section 8d asks for these beside it: the API-only lower bound (action in; obs, reward, done out)
                          "io_only_bytes_per_agent_step": b_io(n, args.continuous),

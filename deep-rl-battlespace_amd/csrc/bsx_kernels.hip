@@ -28,6 +28,7 @@
 // truncate in the reference, sprites.py:130-131,332-333, and must round exactly as CPython rounds them).
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
@@ -539,7 +540,17 @@ __device__ inline void obs_pair(int x, int y, double dir, int tx, int ty, float&
 // LG (discrete only): the actions are float32 [4] score vectors (arg-maxed here) instead of int32 indices -- a compile-time switch, so
 // that each encoding's kernel issues exactly its own action load in the first batch (an unconditional load of the unused encoding's
 // dummy line cost 1.6 % of the step; a load under a branch costs a second round trip, see load_inputs).
-template <int N, bool CONT, bool MULTI, bool ACTOR = false, bool LG = false>
+// Row and byte offsets of the step kernel come in two widths (template parameter OFF32).  A job whose largest array stays below
+// 4 GB -- every measured configuration; 192 bytes of step vectors per agent are the largest rows, so up to 22 M agents -- addresses
+// memory as SGPR base + 32-bit VGPR byte offset: one shift or 24-bit multiply-add per dependent access where 64-bit offsets take two
+// 64 x 32 multiply-adds, two moves and a 64-bit shift-add (C2 7.33 -> 7.22 us, bullet-heavy 14.96 -> 14.73).  Larger jobs (2^30 games
+// are allowed) and BSX_F_WIDE_OFFSETS take the 64-bit kernels.
+template <class T> __device__ inline T* elem(T* base, uint32_t i) {
+    typedef typename std::conditional<std::is_const<T>::value, const char, char>::type byte_t;
+    return reinterpret_cast<T*>(reinterpret_cast<byte_t*>(base) + uint32_t(i * uint32_t(sizeof(T))));
+}
+template <class T> __device__ inline T* elem(T* base, size_t i) { return base + i; }
+template <int N, bool CONT, bool MULTI, bool ACTOR = false, bool LG = false, bool OFF32 = false>
 __global__ __launch_bounds__(SPB * (ACTOR ? group_width(N > 0 ? N : 1) / 2 : WPB)) __attribute__((amdgpu_waves_per_eu((ACTOR && N > 1) ? 2 : 1)))
 void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* const cnt_, const PlaneRec* const plane_, const void* const act_,
                      const int kind_, const StepArgs p) {
@@ -547,6 +558,8 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // dispatcher preloads into SGPRs (-amdgpu-kernarg-preload-count), so that a wave's first loads need nothing from the
     // kernarg segment and do not queue behind its cold scalar-cache fetch.
     STAMP(8);                                            // diagnostic builds: kernel entry, before any kernarg load
+    typedef typename std::conditional<OFF32, uint32_t, size_t>::type ix_t;     // row / element offsets
+    typedef typename std::conditional<OFF32, int32_t, int64_t>::type ixs_t;    // game indices
     constexpr bool NT_STATE = !MULTI && N >= 2;
     constexpr int WAVES = ACTOR ? group_width(N > 0 ? N : 1) / 2 : WPB;
     const int n = (N > 0) ? N : p.n;
@@ -555,16 +568,16 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     const int EPB = SPB / G;
     const int wave = (WAVES > 1) ? int(threadIdx.x >> 6) : 0;
     const int tid = (WAVES > 1) ? int(threadIdx.x & 63) : int(threadIdx.x);   // position in my wave = LDS index in its private arrays
-    const int64_t wblk = (WAVES > 1) ? int64_t(blockIdx.x) * WAVES + wave : int64_t(blockIdx.x);   // which 64 lanes of the job I am
+    const ixs_t wblk = (WAVES > 1) ? ixs_t(blockIdx.x) * WAVES + wave : ixs_t(blockIdx.x);   // which 64 lanes of the job I am
     const int a = tid & (G - 1);
     const int gl = tid & ~(G - 1);                       // first thread of my env's group
-    const int64_t e = wblk * EPB + (tid / G);
+    const ixs_t e = wblk * EPB + (tid / G);
     const bool env_ok = e < E_;
     const bool valid = env_ok && a < A;
-    const size_t EA = size_t(E_) * size_t(A);
+    const ix_t EA = ix_t(E_) * ix_t(A);
     // out-of-range lanes read a valid row (the last one) and never store: loads stay unconditional
-    const int64_t ec = env_ok ? e : E_ - 1;
-    const size_t g = size_t(ec) * A + (a < A ? a : A - 1);
+    const ixs_t ec = env_ok ? e : ixs_t(E_ - 1);
+    const ix_t g = ix_t(ec) * A + (a < A ? a : A - 1);
     const int lane = tid;
     const int team = (a < n) ? 0 : 1;                    // 0 red, 1 blue
     const int eb = gl + (team == 0 ? n : 0);             // first enemy lane (thread index)
@@ -621,8 +634,9 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
             // one unconditional load (a load under a branch makes the compiler's wait-count pass drain EVERYTHING in flight before the
             // other branch's load: the action then cost a second full round trip); an empty call reads a mapped dummy line
             const char* const dummy = reinterpret_cast<const char*>(env_);      // any mapped line will do: the first game record
-            if constexpr (LG) r.lg = *reinterpret_cast<const float4*>(at ? static_cast<const char*>(at) + g * 16 : dummy);
-            else r.ai = *reinterpret_cast<const int32_t*>(at ? static_cast<const char*>(at) + g * 4 : dummy);
+            const char* const abase = at ? static_cast<const char*>(at) : dummy;       // uniform
+            if constexpr (LG) r.lg = *reinterpret_cast<const float4*>(elem(abase, at ? g * 16 : ix_t(0)));
+            else r.ai = *reinterpret_cast<const int32_t*>(elem(abase, at ? g * 4 : ix_t(0)));
         } else if (at) {                                 // uniform branch
             if (kind_ == BSX_ACT_F32) {
                 const float* ap = static_cast<const float*>(at) + 3 * g;
@@ -700,7 +714,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // In the tick loop the compiler would hoist everything loop-invariant -- 36 row addresses, the Philox key schedule,
     // every fp64 constant -- and run out of registers (256 VGPRs, 1-2 waves per SIMD, SGPR spills).  Passing the three
     // values all of that hangs on through an empty asm makes it per-tick work again, as in the one-call kernel.
-    size_t gt = g, EAt = EA;
+    ix_t gt = g, EAt = EA;
     uint64_t seed_t = p.seed;
     int64_t env_offset_t = p.env_offset;
     constexpr int TIE_C = tie_tick_const(N > 0 ? N : 1);
@@ -718,10 +732,10 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // ================= T0: every load that depends on no other load, issued back to back, raw 16-byte words ========
     // (the kernel is latency-bound at 65 536 games -- 2 waves per SIMD -- so memory-level parallelism is what pays)
     if (!MULTI || tk == 0) {
-        const uint4 erw = reinterpret_cast<const uint4*>(env_)[ec];
-        cnt4 = cnt_[ec];                                 // .x = games finished so far = episode id of the RNG streams
+        const uint4 erw = *elem(reinterpret_cast<const uint4*>(env_), ix_t(ec));
+        cnt4 = *elem(cnt_, ix_t(ec));                                 // .x = games finished so far = episode id of the RNG streams
         games = cnt4.x;
-        const uint4 prw = reinterpret_cast<const uint4*>(plane_)[gt];
+        const uint4 prw = *elem(reinterpret_cast<const uint4*>(plane_), gt);
         if (!MULTI) load_inputs(0, rin);
         if (!MULTI) {
             // every kernel argument the step needs later is fetched HERE, in the shadow of the first vector loads: left to
@@ -871,9 +885,9 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // below l that have an entry k: one ballot per k.
     FSTAMP(3);
     int slots = 0;                                       // wave total
-    struct Slot { int o, k; bool isnew, on; uint32_t wd; double2 dd; size_t go; };   // owner lane, list index, "this call's shot", in use; entry; owner's row
+    struct Slot { int o, k; bool isnew, on; uint32_t wd; double2 dd; ix_t go; };   // owner lane, list index, "this call's shot", in use; entry; owner's row
     Slot cur = {0, 0, false, false, 0u, make_double2(0.0, 0.0), 0};
-    size_t gbt = size_t(wblk * EPB) * size_t(A);         // row of lane 0's agent; owner lane o sits (o / G) * A + (o % G) rows on
+    ix_t gbt = ix_t(wblk * EPB) * ix_t(A);         // row of lane 0's agent; owner lane o sits (o / G) * A + (o % G) rows on
     if (MULTI) asm volatile("" : "+v"(gbt));
     auto fetch_slot = [&](int rd) {                      // slot rd * 64 + lane: who owns it, and its list entry (loads in flight on return)
         Slot f;
@@ -881,11 +895,11 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         f.on = w < slots;
         const uint32_t v = f.on ? uint32_t(s_own[w]) : 0u;
         f.o = int(v & 63u); f.k = int((v >> 8) & 15u); f.isnew = (v >> 15) != 0u;
-        f.go = gbt + size_t(f.o / G) * size_t(A) + size_t(f.o & (G - 1));
+        f.go = gbt + ix_t(f.o / G) * ix_t(A) + ix_t(f.o & (G - 1));
         const bool ld = f.on && !f.isnew;
-        const size_t off = size_t(f.k) * EAt + f.go;     // one 64-bit multiply for both arrays
-        f.wd = *(ld ? p.st.bxy + off : reinterpret_cast<const uint32_t*>(p.st.lut));
-        f.dd = *(ld ? p.st.bd + off : p.st.lut);
+        const ix_t off = ix_t(f.k) * EAt + f.go;         // one multiply for both arrays
+        f.wd = *elem(p.st.bxy, ld ? off : ix_t(0));       // (a slot that loads nothing reads element 0: one shared line, any mapped address will do)
+        f.dd = *elem(p.st.bd, ld ? off : ix_t(0));
         return f;
     };
     if constexpr (PACK) {
@@ -941,7 +955,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         if (DIAG & 16u) { float sf, cf; __sincosf(float(-(bdir * DEG2RAD)), &sf, &cf); sn = double(sf); cs = double(cf); }   // timing ablation: a few-instruction float sincos (directions right to ~1e-6, so the same bullet population)
         else sincos(-(bdir * DEG2RAD), &sn, &cs);
         nd = make_double2(BULLET_STEP * cs, BULLET_STEP * sn);
-        st_store<NT_STATE>(&p.st.bdir[size_t(ks) * EAt + gt], bdir);       // ring by birth tick: never moves, read only by bsx_export_state
+        st_store<NT_STATE>(elem(p.st.bdir, ix_t(ks) * EAt + gt), bdir);       // ring by birth tick: never moves, read only by bsx_export_state
     }
     if constexpr (PACK) {                                // this call's shot as the work slot will read it: list word (age 0) + step
         s_nw[tid] = pack_bullet(x, y, 0);
@@ -1141,12 +1155,12 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         // a round's survivor stores are issued at the START of the next round (after the loop for the last one), i.e. BEFORE the
         // loads of the round after: loads and stores share the in-order vmcnt, so a wait for loads issued ahead of stores would
         // also sit out the stores' acknowledgement; issued behind them, both are long done when the entries are needed
-        bool st_on = false, st_dd = false; size_t st_go = 0; int st_ps = 0; uint32_t st_w = 0u; double2 st_d = make_double2(0.0, 0.0);
+        bool st_on = false, st_dd = false; ix_t st_go = 0; int st_ps = 0; uint32_t st_w = 0u; double2 st_d = make_double2(0.0, 0.0);
         auto flush_stores = [&]() {
             if (st_on) {
-                const size_t off = size_t(st_ps) * EAt + st_go;
-                st_store<NT_STATE>(&p.st.bxy[off], st_w);
-                if (st_dd) st_store<NT_STATE>(reinterpret_cast<v2d_t*>(&p.st.bd[off]), v2d_t{st_d.x, st_d.y});   // the entry moved down (or is new): its step moves with it
+                const ix_t off = ix_t(st_ps) * EAt + st_go;
+                st_store<NT_STATE>(elem(p.st.bxy, off), st_w);
+                if (st_dd) st_store<NT_STATE>(reinterpret_cast<v2d_t*>(elem(p.st.bd, off)), v2d_t{st_d.x, st_d.y});   // the entry moved down (or is new): its step moves with it
             }
         };
         // what a slot needs from its owner's side of the game, read from the wave's LDS block: enemy base, enemy planes (post-move
@@ -1165,7 +1179,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         auto do_round = [&](const int rd) {
             const int o = cur.o, k = cur.k; const bool isnew = cur.isnew, on = cur.on;
             uint32_t wd = cur.wd; double2 dd = cur.dd;
-            const size_t go = cur.go;
+            const ix_t go = cur.go;
             const Ctx c = cx;
             if (rd > 0) flush_stores();
             // more than 64 bullets in the wave: the next round's entries and context are fetched while this one is worked on
@@ -1308,7 +1322,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         while (consumed) {
             const int ag = __builtin_ctz(consumed);
             consumed &= consumed - 1u;
-            p.st.bxy[size_t((posmap >> (4 * ag)) & 15u) * EAt + gt] = pack_bullet(0, 0, int(TOMBSTONE_AGE));
+            *elem(p.st.bxy, ix_t((posmap >> (4 * ag)) & 15u) * EAt + gt) = pack_bullet(0, 0, int(TOMBSTONE_AGE));
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1352,9 +1366,9 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     const bool last_tick = !MULTI || tk == p.T - 1;
     if (valid) {
         if (MULTI ? last_tick : (mode == M_PHYS || mode == M_RESET))
-            st_store<NT_STATE>(reinterpret_cast<v4u_t*>(p.st.plane) + gt, as_v4u(pack_plane(x, y, live, hp, dir)));
-        out_store(&rew_t[gt], float(rew));
-        out_store(&done_t[gt], er.done ? uint8_t(1) : uint8_t(alive ? 0 : 1));
+            st_store<NT_STATE>(elem(reinterpret_cast<v4u_t*>(p.st.plane), gt), as_v4u(pack_plane(x, y, live, hp, dir)));
+        out_store(elem(rew_t, gt), float(rew));
+        out_store(elem(done_t, gt), er.done ? uint8_t(1) : uint8_t(alive ? 0 : 1));
     }
     // observation row: a dead observer sees all -1, a dead enemy is [-1,-1,-1] (battle_env.py:215-218,235-242).
     // Compile-time team sizes outside the fused rollout: the row leaves straight from registers, 16 bytes at a time plus a tail
@@ -1379,7 +1393,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
             row[4 + 3 * j] = on ? oe_a[j] : -1.0f;
         }
         if (valid) {
-            float* out = obs_t + gt * size_t(D);
+            float* out = elem(obs_t, gt * ix_t(D));
 #pragma unroll
             for (int i = 0; i + 4 <= D; i += 4) out_store(reinterpret_cast<v4f_t*>(out + i), v4f_t{row[i], row[i + 1], row[i + 2], row[i + 3]});
             typedef float v2f_t __attribute__((ext_vector_type(2)));
@@ -1433,14 +1447,14 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     }
     if (valid) {
         if (a == 0) {
-            if (MULTI ? last_tick : (mode != M_INERT)) st_store<NT_STATE>(reinterpret_cast<v4u_t*>(p.st.env) + e, as_v4u(pack_env(er)));
+            if (MULTI ? last_tick : (mode != M_INERT)) st_store<NT_STATE>(elem(reinterpret_cast<v4u_t*>(p.st.env), ix_t(e)), as_v4u(pack_env(er)));
             if (cnt_delta.x) {                           // game over: the counters were loaded with the game record, no second round trip
                 cnt4.x += cnt_delta.x; cnt4.y += cnt_delta.y; cnt4.z += cnt_delta.z; cnt4.w += cnt_delta.w;
-                p.st.cnt[e] = cnt4;
+                *elem(p.st.cnt, ix_t(e)) = cnt4;
             }
             if (last_tick) {
-                if (p.env_done) p.env_done[e] = uint8_t(er.done);
-                if (p.winner) p.winner[e] = uint8_t(er.winner);
+                if (p.env_done) *elem(p.env_done, ix_t(e)) = uint8_t(er.done);
+                if (p.winner) *elem(p.winner, ix_t(e)) = uint8_t(er.winner);
             }
             if (MULTI && p.env_done_t) p.env_done_t[int64_t(tk) * E_ + e] = uint8_t(er.done);
         }
@@ -1618,15 +1632,29 @@ inline int grid_for(int64_t E, int n, int tpb = TPB) {
     return int((E + epb - 1) / epb);
 }
 
+template <bool CONT, bool MULTI, bool LG, bool OFF32>
+void launch_for_n_w(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs& a) {
+    switch (n) {
+        case 1: hipLaunchKernelGGL((bsx_step_kernel<1, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        case 2: hipLaunchKernelGGL((bsx_step_kernel<2, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        case 3: hipLaunchKernelGGL((bsx_step_kernel<3, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        case 4: hipLaunchKernelGGL((bsx_step_kernel<4, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        default: hipLaunchKernelGGL((bsx_step_kernel<0, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+    }
+}
+// 32-bit offsets when every array of the job stays below 4 GB: the widest rows are the bullets' step vectors (12 x 16 bytes per agent)
+// and an observation row is at most 4 (3 * 16 + 2) = 200 bytes per agent.
+inline bool narrow_offsets_ok(int64_t E, int n, uint32_t flags) {
+#ifdef BSX_X_OFF64
+    return false;
+#else
+    return !(flags & BSX_F_WIDE_OFFSETS) && uint64_t(E) * uint64_t(2 * n) * 200ull <= 0xFFFFFFFFull;
+#endif
+}
 template <bool CONT, bool MULTI, bool LG>
 void launch_for_n(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs& a) {
-    switch (n) {
-        case 1: hipLaunchKernelGGL((bsx_step_kernel<1, CONT, MULTI, false, LG>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-        case 2: hipLaunchKernelGGL((bsx_step_kernel<2, CONT, MULTI, false, LG>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-        case 3: hipLaunchKernelGGL((bsx_step_kernel<3, CONT, MULTI, false, LG>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-        case 4: hipLaunchKernelGGL((bsx_step_kernel<4, CONT, MULTI, false, LG>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-        default: hipLaunchKernelGGL((bsx_step_kernel<0, CONT, MULTI, false, LG>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-    }
+    if (narrow_offsets_ok(a.E, n, a.flags)) launch_for_n_w<CONT, MULTI, LG, true>(n, grid, block, s, a);
+    else launch_for_n_w<CONT, MULTI, LG, false>(n, grid, block, s, a);
 }
 
 // T == 0: one call (bsx_step_*);  T >= 1: bsx_step_many_* -- T calls in one launch, arrays with a leading T axis

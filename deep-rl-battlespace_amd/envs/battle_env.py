@@ -72,7 +72,7 @@ class parallel_env:
 
     def __init__(self, n_agents=1, show=False, hit_base_reward=100, hit_plane_reward=10, miss_punishment=-1,
                  die_punishment=-5, lose_punishment=-20, fps=20, continuous_actions=False,
-                 n_envs=None, device=None, seed=0, auto_reset=False, env_offset=0, rng=None):
+                 n_envs=None, device=None, seed=0, auto_reset=False, env_offset=0, rng=None, wide_offsets=False):
         """First nine arguments: exactly the reference constructor (battle_env.py:73).
 
         n_envs      None = drop-in single game (reference return types); int = batched on-device tensors
@@ -81,6 +81,8 @@ class parallel_env:
         auto_reset  batched mode: a step() on a finished game re-spawns it instead of the reference's inert call
         env_offset  global index of this object's env 0 (sharding: rank r owns [r*E, (r+1)*E))
         rng         "python" (stdlib random, reference draw order; default when n_envs is None) or "philox"
+        wide_offsets  take the 64-bit-offset kernels (BSX_F_WIDE_OFFSETS) although the job is small enough for 32-bit offsets;
+                    the library switches by itself above 4 GB per array -- same results, for tests
         """
         if not isinstance(n_agents, (int, np.integer)) or not 1 <= n_agents <= _lib.MAX_N:
             raise ValueError(f"n_agents must be an int in 1..{_lib.MAX_N}, got {n_agents!r}")
@@ -131,6 +133,7 @@ class parallel_env:
                                     float(die_punishment), float(lose_punishment))
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.auto_reset = bool(auto_reset)
+        self._base_flags = (_lib.F_AUTO_RESET if self.auto_reset else 0) | (_lib.F_WIDE_OFFSETS if wide_offsets else 0)
         self.env_offset = int(env_offset)
         self.rng = rng if rng is not None else ("python" if self._compat else "philox")
         if self.rng not in ("python", "philox"):
@@ -359,7 +362,7 @@ class parallel_env:
         """Enqueue one fused step kernel on the current stream (no sync, no allocation: graph-capturable).
         env_done_ptr: where this call's env_done [E] goes instead of the env-owned tensor (a rollout's per-tick record; the
         caller copies the last one back into `self._env_done`)."""
-        flags = (_lib.F_AUTO_RESET if self.auto_reset else 0) | (_lib.F_EMPTY_CALL if empty else 0)
+        flags = self._base_flags | (_lib.F_EMPTY_CALL if empty else 0)
         fn = self._lib.bsx_step_continuous if self.continuous_actions else self._lib.bsx_step_discrete
         with self._guard():
             rc = fn(self._p_state, self.n_envs, self.n_agents, act_ptr, kind, u_ptr, obs_ptr, rew_ptr, done_ptr,
@@ -429,7 +432,7 @@ class parallel_env:
         if env_done_out is not None and (env_done_out.shape != (T, E) or env_done_out.dtype != torch.uint8
                                          or not env_done_out.is_contiguous() or env_done_out.device != self.device):
             raise ValueError(f"env_done_out must be a contiguous uint8 [{T}, {E}] tensor on the env's device")
-        flags = _lib.F_AUTO_RESET if self.auto_reset else 0
+        flags = self._base_flags
         fn = self._lib.bsx_step_many_continuous if self.continuous_actions else self._lib.bsx_step_many_discrete
         with self._guard():
             _lib.check(fn(self._state.data_ptr(), E, self.n_agents, T, actions.data_ptr(), kind, u_ptr, obs.data_ptr(),
@@ -446,7 +449,7 @@ class parallel_env:
         """Enqueue bsx_rollout_discrete / bsx_rollout_continuous: T ticks of (actor -> step) in one launch (rollout.PolicyRollout)."""
         if self.n_agents > 4:
             raise ValueError("the one-launch rollout is built for 1v1 ... 4v4")
-        flags = _lib.F_AUTO_RESET if self.auto_reset else 0
+        flags = self._base_flags
         common = (self._env_done.data_ptr(), self._winner.data_ptr(), env_done_t_ptr, ctypes.byref(self._cfg), flags,
                   ctypes.byref(noise) if noise is not None else None, int(actor_seed), int(seq), seq_base_ptr, self.seed,
                   self.env_offset, self._stream())

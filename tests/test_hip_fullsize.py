@@ -124,6 +124,32 @@ def test_C4_524288_games_as_eight_shards_equal_one_batch():
     assert int(sw["counters"][:, 0].sum()) >= E                  # every game crossed its first game end
 
 
+@pytest.mark.parametrize("n,cont", [(1, False), (4, False), (2, True), (6, False)])
+def test_wide_and_narrow_offset_kernels_play_the_same_games(n, cont):
+    """A job whose arrays stay below 4 GB runs kernels with 32-bit row / byte offsets (SGPR base + 32-bit VGPR offset), larger jobs
+    the 64-bit ones; BSX_F_WIDE_OFFSETS (parallel_env(wide_offsets=True)) takes the 64-bit kernels at any size.  Both must leave the
+    same state and the same outputs, per step, as one launch per step and as multi-tick launches."""
+    E, T = 3000, 150
+    A = 2 * n
+    kw = dict(n_agents=n, n_envs=E, seed=123, auto_reset=True, continuous_actions=cont)
+    a, b = _env(**kw), _env(wide_offsets=True, **kw)
+    a.reset(); b.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    if cont:
+        acts = torch.rand((T, E, A, 3), generator=g, device="cuda") * 2 - 1
+    else:
+        acts = torch.randint(0, 4, (T, E, A), generator=g, device="cuda", dtype=torch.int32)
+        acts = torch.where(torch.rand((T, E, A), generator=g, device="cuda") < 0.4, torch.ones_like(acts), acts)
+    for t in range(T // 2):
+        oa, ra, da = a.step_batch(acts[t]); ob, rb, db = b.step_batch(acts[t])
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db), t
+    oa, ra, da = a.step_many(acts[T // 2:].contiguous(), store=True); ob, rb, db = b.step_many(acts[T // 2:].contiguous(), store=True)
+    assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db)
+    sa, sb = a.export_state(), b.export_state()
+    for f in sa:
+        assert torch.equal(sa[f], sb[f]), f
+
+
 def test_largest_batch_offsets_past_4GB_play_the_same_games():
     """Maximum sizes: 16 M + 5 games of 1v1 in ONE batch (12 GB of state; bullet-step rows start beyond 4 GB, the grid is
     524 289 wavefronts, the last one ragged).  The in-kernel generator is keyed by the global env index, so the last 4 096

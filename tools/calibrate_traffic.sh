@@ -15,7 +15,7 @@ import csv, glob
 E = 1048576
 for name, exp in (("fetch", 72 * E), ("write", 100 * E)):
     f = glob.glob(f"$O/{name}/*/*_counter_collection.csv")[0]
-    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "bsx_step_kernel<1, false, false, false, false>" in r["Kernel_Name"] and int(r["Grid_Size"]) == 2 * E]
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "bsx_step_kernel<1, false, false, false, false, true>" in r["Kernel_Name"] and int(r["Grid_Size"]) == 2 * E]
     v = v[len(v) // 2:]          # steady state: after the first game's bullets... none here, but skip warm-up launches
     m = sum(v) / len(v) * 1024
     print(f"{name}: counter {m/1e6:.1f} MB per launch, known {exp/1e6:.1f} MB  -> true/counter = {exp/m:.3f}")

@@ -51,7 +51,9 @@ def kernel_filter(key):
     while G < 2 * n:
         G *= 2
     grid = ((E + 64 // G - 1) // (64 // G)) * 64
-    name = f"bsx_step_kernel<{n if n <= 4 else 0}, {'true' if cont else 'false'}, {'true' if many else 'false'}, false, false>"   # <N, CONT, MULTI, ACTOR, LG>
+    narrow = E * 2 * n * 200 <= 0xFFFFFFFF
+    name = (f"bsx_step_kernel<{n if n <= 4 else 0}, {'true' if cont else 'false'}, {'true' if many else 'false'}, false, false, "
+            f"{'true' if narrow else 'false'}>")   # <N, CONT, MULTI, ACTOR, LG, OFF32>
     return name, grid, many
 
 
