@@ -1796,6 +1796,15 @@ int bsx_step_many_continuous(void* state, int64_t E, int n, int T, const void* a
 
 namespace {
 // T x (actor -> step) in one launch; CONT = continuous actions (three actor outputs, BSX_ACT_F32X4 rows)
+template <bool CONT, bool OFF32>
+void launch_rollout_w(int n, dim3 grid, hipStream_t s, const StepArgs& a) {
+    switch (n) {
+        case 1: hipLaunchKernelGGL((bsx_step_kernel<1, CONT, true, true, false, OFF32>), grid, dim3(SPB * 1), 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        case 2: hipLaunchKernelGGL((bsx_step_kernel<2, CONT, true, true, false, OFF32>), grid, dim3(SPB * 2), 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        case 3: hipLaunchKernelGGL((bsx_step_kernel<3, CONT, true, true, false, OFF32>), grid, dim3(SPB * 4), 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        default: hipLaunchKernelGGL((bsx_step_kernel<4, CONT, true, true, false, OFF32>), grid, dim3(SPB * 4), 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+    }
+}
 template <bool CONT>
 int launch_rollout(void* state, int64_t E, int n, int T, const float* weights, int precision, int scripted_team, float* obs, float* scores, float* rew,
                    uint8_t* done, uint8_t* env_done, uint8_t* winner, uint8_t* env_done_t, const BsxRewards* cfg, uint32_t flags,
@@ -1822,12 +1831,8 @@ int launch_rollout(void* state, int64_t E, int n, int T, const float* weights, i
     a.aseq_base = seq_base;
     const dim3 grid(unsigned((E + 31) / 32));            // a workgroup = 32 games = G/2 waves
     hipStream_t s = static_cast<hipStream_t>(stream);
-    switch (n) {
-        case 1: hipLaunchKernelGGL((bsx_step_kernel<1, CONT, true, true>), grid, dim3(SPB * 1), 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-        case 2: hipLaunchKernelGGL((bsx_step_kernel<2, CONT, true, true>), grid, dim3(SPB * 2), 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-        case 3: hipLaunchKernelGGL((bsx_step_kernel<3, CONT, true, true>), grid, dim3(SPB * 4), 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-        default: hipLaunchKernelGGL((bsx_step_kernel<4, CONT, true, true>), grid, dim3(SPB * 4), 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-    }
+    if (narrow_offsets_ok(E, n, flags)) launch_rollout_w<CONT, true>(n, grid, s, a);
+    else launch_rollout_w<CONT, false>(n, grid, s, a);
     return int(hipGetLastError());
 }
 }  // namespace

@@ -8,7 +8,7 @@ python - <<PY
 import csv, glob, collections
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(glob.glob("$O/p/*/*_counter_collection.csv")[0])):
-    if "bsx_step_kernel<1, false, true, true, false>" in r["Kernel_Name"]:
+    if "bsx_step_kernel<1, false, true, true, false, true>" in r["Kernel_Name"]:
         agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 print({k: round(sum(v) / len(v)) for k, v in agg.items()})
 PY
