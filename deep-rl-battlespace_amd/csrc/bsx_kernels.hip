@@ -572,7 +572,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     const int a = tid & (G - 1);
     const int gl = tid & ~(G - 1);                       // first thread of my env's group
     const ixs_t e = wblk * EPB + (tid / G);
-    const bool env_ok = e < E_;
+    const bool env_ok = e < ixs_t(E_);
     const bool valid = env_ok && a < A;
     const ix_t EA = ix_t(E_) * ix_t(A);
     // out-of-range lanes read a valid row (the last one) and never store: loads stay unconditional
@@ -625,6 +625,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     lds_vint* const s_bhit = (lds_vint*)(uintptr_t)(s_bhit_all) + wave * SPB;
     float* const s_obs = s_obs_all + wave * SPB * DROW;
 
+    const bool has_act = kind_ >= 0;                     // an empty call (step({})) comes with action_kind -1 and a dummy, mapped action pointer
     // Raw inputs of one call (decoded at the top of the tick that uses them).
     struct RawIn { int ai; float4 lg; float f0, f1, f2; double c0, c1, c2, uu; };
     auto load_inputs = [&](int t, RawIn& r) {
@@ -633,11 +634,11 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         if (!CONT) {
             // one unconditional load (a load under a branch makes the compiler's wait-count pass drain EVERYTHING in flight before the
             // other branch's load: the action then cost a second full round trip); an empty call reads a mapped dummy line
-            const char* const dummy = reinterpret_cast<const char*>(env_);      // any mapped line will do: the first game record
-            const char* const abase = at ? static_cast<const char*>(at) : dummy;       // uniform
-            if constexpr (LG) r.lg = *reinterpret_cast<const float4*>(elem(abase, at ? g * 16 : ix_t(0)));
-            else r.ai = *reinterpret_cast<const int32_t*>(elem(abase, at ? g * 4 : ix_t(0)));
-        } else if (at) {                                 // uniform branch
+            // (the host passes a mapped address for it -- the state block -- and action_kind -1: no pointer select in front of the first loads)
+            const char* const abase = static_cast<const char*>(at);
+            if constexpr (LG) r.lg = *reinterpret_cast<const float4*>(elem(abase, has_act ? g * 16 : ix_t(0)));
+            else r.ai = *reinterpret_cast<const int32_t*>(elem(abase, has_act ? g * 4 : ix_t(0)));
+        } else if (has_act) {                            // uniform branch
             if (kind_ == BSX_ACT_F32) {
                 const float* ap = static_cast<const float*>(at) + 3 * g;
                 r.f0 = ap[0]; r.f1 = ap[1]; r.f2 = ap[2];
@@ -667,7 +668,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     struct DecIn { int act; double a0, a1, a2, uu; };    // a call's inputs, decoded
     auto decode = [&](const RawIn& r) {
         DecIn d = {-1, 0.0, 0.0, 0.0, 0.0};
-        if (act_) {                                      // uniform branch
+        if (has_act) {                                   // uniform branch
             if (!CONT) {
                 if constexpr (!LG) d.act = r.ai;
                 else {   // np.argmax: first maximum; a NaN compares as the maximum
@@ -1673,6 +1674,7 @@ int launch_step(void* state, int64_t E, int n, const void* actions, int action_k
     StepArgs a;
     a.st = state_ptrs(state, E, n);
     a.E = E; a.n = n; a.actions = actions; a.action_kind = action_kind; a.u = u;
+    if (!actions) { a.actions = state; a.action_kind = -1; }   // empty call: the kernel reads (and ignores) one mapped word instead of selecting a pointer
     a.obs = obs; a.rew = rew; a.done = done; a.env_done = env_done; a.winner = winner; a.env_done_t = env_done_t;
     a.cfg = *cfg; a.flags = flags; a.seed = seed; a.env_offset = env_offset; a.tie_tick = bsx_tie_tick(n);
     const int64_t EA = E * 2 * n;
