@@ -57,6 +57,9 @@ __global__ __launch_bounds__(TPB) void bsx_actor_kernel(const ActorArgs p) {
         reinterpret_cast<float4*>(s_small)[i] = reinterpret_cast<const float4*>(W + off_small(D))[i];
 
     const int64_t row0 = (int64_t(blockIdx.x) * (TPB / 64) + wave) * ROWS_PER_WAVE;   // first env of this wave
+    // the replay counter is a device word behind a kernel argument: requested here, with the first weight loads, not where the noise
+    // needs it (the compiler's choice -- a scalar miss with nothing left to hide it at the end of the kernel)
+    uint64_t seq_add = p.seq_base ? *p.seq_base : 0ull;
     float4 o[2];
     if constexpr (PREC != BSX_ACTOR_F32) {
         __syncthreads();
@@ -105,6 +108,7 @@ __global__ __launch_bounds__(TPB) void bsx_actor_kernel(const ActorArgs p) {
                 for (int vq = 0; vq < 4; ++vq)
                     w2[mo][mt][vq] = reinterpret_cast<const float4*>(W + off_w2(D))[((mo * 2 + mt) * 4 + vq) * 64 + lane];
 
+        asm volatile("" : "+s"(seq_add));                // (waited for here, under the 64 x 64 layer's weight loads)
         ln_relu_tile(acc1[0][0], acc1[1][0], sm + 1 * H, sm + 2 * H);
         ln_relu_tile(acc1[0][1], acc1[1][1], sm + 1 * H, sm + 2 * H);
 
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(TPB) void bsx_actor_kernel(const ActorArgs p) {
     const float4 b3 = *reinterpret_cast<const float4*>(s_small + 6 * H + H * NA);
     const int64_t e = row0 + 32 * hh + c;
     const size_t row = size_t(e < p.E ? e : p.E - 1) * p.A + a;
-    const uint64_t seq = p.seq + (p.seq_base ? *p.seq_base : 0ull);   // seq_base: device word, so graph replays re-key
+    const uint64_t seq = p.seq + seq_add;                // seq_base: device word, so graph replays re-key
     const bool game_over = p.nz.ou_scale > 0.f && p.nz.env_done && p.nz.env_done[e < p.E ? e : p.E - 1];
     r4 = finish_row(r4, b3, p.nz, p.seed, seq, row, uint64_t(p.env_offset) * uint64_t(p.A) + row, game_over, e < p.E);
     if (e < p.E) reinterpret_cast<float4*>(p.scores)[row] = r4;
