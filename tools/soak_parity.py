@@ -16,11 +16,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--envs", type=int, default=65536); ap.add_argument("--n-agents", type=int, default=1)
 ap.add_argument("--steps", type=int, default=1500); ap.add_argument("--check", type=int, default=250)
 ap.add_argument("--policy", choices=("random", "instinct"), default="random"); ap.add_argument("--seed", type=int, default=2024)
+ap.add_argument("--wide", action="store_true", help="take the 64-bit-offset kernels (BSX_F_WIDE_OFFSETS)")
 ap.add_argument("--many", type=int, default=0, help="K > 0: the HIP side runs K ticks per launch (bsx_step_many_discrete); random policy only")
 args = ap.parse_args()
 E, n, T = args.envs, args.n_agents, args.steps
 A = 2 * n
-env = bsx.parallel_env(n_agents=n, n_envs=E, seed=args.seed, auto_reset=True)
+env = bsx.parallel_env(n_agents=n, n_envs=E, seed=args.seed, auto_reset=True, wide_offsets=args.wide)
 c = cref.CRefBatch(E, n_agents=n, seed=args.seed, auto_reset=True)
 env.reset(); c.reset()
 g = torch.Generator(device="cuda"); g.manual_seed(args.seed)
