@@ -180,6 +180,33 @@ def test_one_launch_continuous_rollout_equals_two_kernel_rollout(noise, n):
         PolicyRollout(a.env, actor, T, one_launch=True, opponent=instinct.Team(a.env.possible_blue, a.env.possible_red, a.env))
 
 
+@pytest.mark.parametrize("n,cont", [(1, False), (3, False), (2, True)])
+def test_one_launch_rollout_is_the_same_through_narrow_and_wide_offset_kernels(n, cont):
+    """The fused rollout kernels exist in both offset widths as well (32-bit offsets while the job's arrays stay below 4 GB, 64-bit
+    above or with wide_offsets=True): same observations, scores, rewards, dones and final state."""
+    from deep_rl_battlespace_amd.rollout import PolicyRollout, StackedActor
+    E, T = 2100, 24
+    torch.manual_seed(3)
+    actor = StackedActor(2 * n, 3 * n + 2, 3 if cont else 4, device="cuda")
+    with torch.no_grad():
+        actor.w3.mul_(40.0)
+    ros = []
+    for wide in (False, True):
+        env = _env(n_agents=n, n_envs=E, seed=11, auto_reset=True, continuous_actions=cont, wide_offsets=wide); env.reset()
+        ro = PolicyRollout(env, actor, T, seed=5, noise_std=0.4, one_launch=True); ro.start(); ro.capture()
+        ros.append(ro)
+    a, b = ros
+    for rep in range(8):                                        # 192 ticks: past the time limit of every team size here
+        a.run(); b.run()
+        torch.cuda.synchronize()
+        assert torch.equal(a.obs, b.obs) and torch.equal(a.scores, b.scores) and torch.equal(a.rew, b.rew), rep
+        assert torch.equal(a.done, b.done) and torch.equal(a.env_done, b.env_done), rep
+    sa, sb = a.env.export_state(), b.env.export_state()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert int(a.env.counters()[:, 0].sum()) >= E
+
+
 @pytest.mark.parametrize("one_launch", [False, True])
 def test_exploration_noise_does_not_depend_on_the_sharding(one_launch):
     """A job split over ranks (sharding.make_shard: env_offset) explores exactly as the unsplit job: the actor's Philox draws are
