@@ -53,6 +53,10 @@ def draw_spawn(n_agents, randint=None):
     return out
 
 
+_current_device = getattr(torch._C, "_cuda_getDevice", torch.cuda.current_device)   # the raw binding: no Python frames per call
+_NULL_CONTEXT = contextlib.nullcontext()
+
+
 class _TeamCounters:
     """`env.team[colour]['wins']` (reference battle_env.py:102-103,492) backed by the device counters."""
 
@@ -91,6 +95,9 @@ class parallel_env:
             raise RuntimeError("parallel_env needs an MI355X visible to torch (torch.cuda.is_available() is False); "
                                "the step() path has no CPU implementation")
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if self.device.type == "cuda" and self.device.index is None:           # "cuda" -> the current device, by number
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self._dev_index = self.device.index
         if self.device.type != "cuda":
             raise ValueError(f"device must be a cuda (HIP) device, got {self.device}")
         self._compat = n_envs is None
@@ -183,7 +190,7 @@ class parallel_env:
     # ------------------------------------------------------------------ helpers
     def _stream(self):
         if self._raw_stream is not None:
-            return self._raw_stream(self.device.index)
+            return self._raw_stream(self._dev_index)
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def _sync(self):
@@ -193,8 +200,8 @@ class parallel_env:
     def _guard(self):
         """HIP launches go to the calling thread's current device: make that the env's device for the duration of a call
         (a no-op context when it already is, which is the normal one-process-per-GPU case)."""
-        if torch.cuda.current_device() == self.device.index:
-            return contextlib.nullcontext()
+        if _current_device() == self._dev_index:
+            return _NULL_CONTEXT
         return torch.cuda.device(self.device)
 
     def _draw_spawn(self):
@@ -364,10 +371,15 @@ class parallel_env:
         caller copies the last one back into `self._env_done`)."""
         flags = self._base_flags | (_lib.F_EMPTY_CALL if empty else 0)
         fn = self._lib.bsx_step_continuous if self.continuous_actions else self._lib.bsx_step_discrete
-        with self._guard():
+        if _current_device() == self._dev_index:           # the normal one-process-per-GPU case: no context object at all on the per-call path
             rc = fn(self._p_state, self.n_envs, self.n_agents, act_ptr, kind, u_ptr, obs_ptr, rew_ptr, done_ptr,
                     env_done_ptr if env_done_ptr is not None else self._p_env_done, self._p_winner,
                     self._cfg_ref, flags, self.seed, self.env_offset, self._stream())
+        else:
+            with torch.cuda.device(self.device):
+                rc = fn(self._p_state, self.n_envs, self.n_agents, act_ptr, kind, u_ptr, obs_ptr, rew_ptr, done_ptr,
+                        env_done_ptr if env_done_ptr is not None else self._p_env_done, self._p_winner,
+                        self._cfg_ref, flags, self.seed, self.env_offset, self._stream())
         if rc:
             _lib.check(rc, "bsx_step")
 
