@@ -36,75 +36,36 @@
 #include "battlespace_hip.h"
 #include "bsx_actor_core.h"
 
+// Diagnostic builds (tools/build_variant.py compiles this file with -DBSX_VARIANT): timing-only ablations (DIAG bits; results are
+// WRONG with any bit set) and in-kernel phase stamps live in bsx_diag.h.  The product build sees the constants below: no
+// ablation, stamps compile to nothing, bsx_build_flags() == 0.
+#ifdef BSX_VARIANT
+#include "bsx_diag.h"
+#else
+constexpr unsigned DIAG = 0;
+constexpr int BUILD_FLAGS = 0;
+constexpr bool PACK_BULLETS = true;
+#define STAMP(i) do { } while (0)
+#define FSTAMP(i) do { } while (0)
+#define PSTAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int K = BSX_BULLET_SLOTS;
 constexpr int TPB = 256;   // reset / export kernels
 constexpr int SPB = 64;    // step kernel: a game never spans a wavefront, so the waves of a workgroup share nothing and no block barrier is needed
-// wavefronts per workgroup of the per-step / multi-tick kernels (the fused rollout has its own: 32 games per workgroup)
-#ifndef BSX_X_WPB
-#define BSX_X_WPB 1
-#endif
-constexpr int WPB = BSX_X_WPB;
-
-// Timing-only ablation mask for profiling builds (hipcc -DBSX_DIAG=<bits>; results are WRONG with any bit set):
-// 1 = skip observation math, 2 = skip the bullet loop, 4 = skip the ordered resolve, 8 = no Philox draw for the shot's jitter,
-// 16 = fast float sincos for the shot.  The product build has 0.
-#ifndef BSX_DIAG
-#define BSX_DIAG 0
-#endif
-constexpr unsigned DIAG = BSX_DIAG;
-
-// In-kernel phase stamps (hipcc -DBSX_STAMPS): lane 0 of every wave stores s_memtime at 8 points into a debug buffer
-// that nothing else reads.  Never defined in the product build; a stamped build is for reading SHARES, not run time.
-#ifdef BSX_STAMPS
-__device__ unsigned long long* g_stamps = nullptr;
-#define STAMP(i)                                                                                   \
-    do {                                                                                           \
-        unsigned long long t_;                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        if (g_stamps && (threadIdx.x & 63) == 0) g_stamps[size_t(blockIdx.x) * 10 + (i)] = t_; \
-    } while (0)
-#else
-#define STAMP(i) do { } while (0)
-#endif
-// -DBSX_STAMPS -DBSX_STAMPS_FINE: stamps 3..6 move INSIDE the shot phase (after the slot table / the Philox draw / sincos / the
-// first slot fetch); FSTAMP stores from every active lane (it sits in divergent code), the phase stamps 3..6 are off.
-#if defined(BSX_STAMPS) && defined(BSX_STAMPS_FINE)
-#define FSTAMP(i)                                                                                  \
-    do {                                                                                           \
-        unsigned long long t_;                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        if (g_stamps) g_stamps[size_t(blockIdx.x) * 10 + (i)] = t_;                                \
-    } while (0)
-#define PSTAMP(i) do { if ((i) < 3 || (i) > 6) STAMP(i); } while (0)
-#else
-#define FSTAMP(i) do { } while (0)
-#define PSTAMP(i) STAMP(i)
-#endif
+constexpr int WPB = 1;     // wavefronts per workgroup of the per-step / multi-tick kernels (the fused rollout has its own: 32 games per workgroup;
+                           // 2 / 4 waves measured slower: 8.54 / 8.39 us against 8.20)
 
 // obs / rew / done leave with the non-temporal hint: nothing on the step path reads them back, so they need not sit dirty in
-// the L2 until the end-of-kernel write-back (C2: 8.21 -> 8.02 us per step; -DBSX_X_PLAINSTORE builds ordinary stores for A/B).
+// the L2 until the end-of-kernel write-back (C2: 8.21 -> 8.02 us per step against ordinary stores).
 typedef float v4f_t __attribute__((ext_vector_type(4)));
-template <class T> __device__ inline void out_store(T* p, T v) {
-#ifdef BSX_X_PLAINSTORE
-    *p = v;
-#else
-    __builtin_nontemporal_store(v, p);
-#endif
-}
+template <class T> __device__ inline void out_store(T* p, T v) { __builtin_nontemporal_store(v, p); }
 
 // Bullets are updated in WORK SLOTS packed across the wavefront (see "wave-packed bullet pass" in the step kernel) for the
-// compile-time team sizes 1..4; -DBSX_X_NOPACK builds the per-lane item walk instead (kept for the runtime-n kernel and for A/B).
-#ifdef BSX_X_NOPACK
-constexpr bool PACK_BULLETS = false;
-#else
-constexpr bool PACK_BULLETS = true;
-#endif
+// compile-time team sizes 1..4 (PACK_BULLETS; the runtime-n kernel keeps the per-lane item walk, which a variant build can select
+// for every team size).
 #define BSX_LDS(T, arr) ((__attribute__((address_space(3))) T*)(uintptr_t)(arr))
 
 // The per-step kernel's STATE stores (plane / game records, bullet entries) can leave non-temporal as well -- the next launch
@@ -178,17 +139,7 @@ inline StatePtrs state_ptrs(void* base, int64_t E, int n) {
 }
 
 // ---------------------------------------------------------------------------------------------- Philox4x32-10
-__device__ inline uint4 philox4x32_10(uint4 ctr, uint2 key) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a mul_hi + mul_lo pair: both are quarter rate
-        const uint64_t p0 = uint64_t(0xD2511F53u) * ctr.x, p1 = uint64_t(0xCD9E8D57u) * ctr.z;
-        const uint32_t hi0 = uint32_t(p0 >> 32), lo0 = uint32_t(p0), hi1 = uint32_t(p1 >> 32), lo1 = uint32_t(p1);
-        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
-        key.x += 0x9E3779B9u; key.y += 0xBB67AE85u;
-    }
-    return ctr;
-}
+using bsx_actor::philox4x32_10;   // one definition, shared with the actor's exploration noise (bsx_actor_core.h)
 enum : uint32_t { STREAM_RESET = 0, STREAM_AUTORESET = 1, STREAM_JITTER = 2 };
 __device__ inline uint4 draw4(uint64_t seed, int64_t genv, uint32_t stream, uint32_t seq, uint32_t who) {
     return philox4x32_10(make_uint4(uint32_t(genv), uint32_t(uint64_t(genv) >> 32) ^ (stream << 28), seq, who),
@@ -230,7 +181,7 @@ __device__ inline double fma_k(double a, double b, double c) {
 // correction), q + q * t * P(t) with t = q * q and its 20-coefficient odd minimax polynomial, then the octant / quadrant selects
 // and the sign of y -- minus what integers in this range never need (the quotient's range scaling and fix-up, infinities, NaNs),
 // and with the polynomial's coefficients in SGPRs (fma_k): 47 vector instructions instead of 88, the same bits (a device test
-// compares it with the library on every argument pair; -DBSX_X_LIBATAN builds the library call).
+// compares it with the library on every argument pair).
 // K independent evaluations in lockstep: with two waves per SIMD nothing else fills the ~8 cycles a dependent float64 operation
 // waits for its predecessor, so K chains advance together, stage by stage, and every coefficient is materialised once for all K.
 __constant__ double ATAN2_COEF[20] = {
@@ -240,10 +191,6 @@ __constant__ double ATAN2_COEF[20] = {
     -0x1.745d119378e4fp-4, 0x1.c71c717e1913cp-4, -0x1.2492492376b7dp-3, 0x1.99999999952ccp-3, -0x1.5555555555523p-2};
 template <int K>
 __device__ inline void atan2_pixels_n(const int (&iy)[K], const int (&ix)[K], double (&out)[K]) {
-#ifdef BSX_X_LIBATAN
-#pragma unroll
-    for (int k = 0; k < K; ++k) out[k] = atan2(double(iy[k]), double(ix[k]));
-#else
     double ax[K], ay[K], u[K], v[K], y[K], e[K], q[K], r[K], t[K], p[K];
 #define BSX_EACH _Pragma("unroll") for (int k = 0; k < K; ++k)
     BSX_EACH { ax[k] = fabs(double(ix[k])); ay[k] = fabs(double(iy[k])); }
@@ -257,11 +204,7 @@ __device__ inline void atan2_pixels_n(const int (&iy)[K], const int (&ix)[K], do
     BSX_EACH r[k] = __builtin_fma(-u[k], q[k], v[k]);
     BSX_EACH q[k] = __builtin_fma(r[k], y[k], q[k]);
     BSX_EACH t[k] = q[k] * q[k];
-#ifdef BSX_X_ATAN_LITERALS
-    constexpr bool TABLE = false;
-#else
     constexpr bool TABLE = K <= 2;                       // measured: 1v1 (K = 2) 7.40 -> 7.34 us; 4v4 (K = 3) 24.0 -> 24.4, so literals there
-#endif
     if constexpr (TABLE) {
         // The 20 coefficients come from constant memory: three scalar loads (8 + 8 + 4 doubles) instead of forty s_mov.  With two
         // waves per SIMD the step is bound by the SIMD's issue port -- one instruction of ANY class per ~4 cycles
@@ -290,7 +233,6 @@ __device__ inline void atan2_pixels_n(const int (&iy)[K], const int (&ix)[K], do
         out[k] = iy[k] < 0 ? -a : a;                                 //  q = 0 gives here anyway); copysign(a, y): a >= 0, and iy = 0 keeps +a
     }
 #undef BSX_EACH
-#endif
 }
 __device__ inline double atan2_pixels(int iy, int ix) {
     const int ys[1] = {iy}, xs[1] = {ix};
@@ -325,11 +267,8 @@ __device__ inline double pair_rads(int x0, int y0, int x1, int y1) {   // rel_an
 // sqrt of a squared pixel distance q = dx*dx + dy*dy (an integer below 2^22): the correctly rounded binary64 root, as math.sqrt
 // gives it (battle_env.py:57).  Same iteration as the library sqrt -- reciprocal-root estimate, two coupled Newton steps on
 // (g ~ sqrt x, h ~ 1 / (2 sqrt x)), two residual corrections with exact fma residuals -- without its range scaling and class tests,
-// which an integer in [0, 2^22) never needs; q = 0 is returned as is.  -DBSX_X_LIBSQRT builds the library call for A/B.
+// which an integer in [0, 2^22) never needs; q = 0 is returned as is (-0.9 % of the step against the library call).
 __device__ inline double sqrt_pixels(int q) {
-#ifdef BSX_X_LIBSQRT
-    return sqrt(double(q));
-#else
     const double x = double(q);
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y, h = y * 0.5;
@@ -341,7 +280,6 @@ __device__ inline double sqrt_pixels(int q) {
     d = __builtin_fma(-g, g, x);
     g = __builtin_fma(d, h, g);
     return q == 0 ? 0.0 : g;
-#endif
 }
 __device__ inline float obs_dist(int x0, int y0, int x1, int y1) {
     const int dx = x0 - x1, dy = y0 - y1;
@@ -353,10 +291,6 @@ __device__ inline void geometry_n(int x, int y, const int (&tx)[K], const int (&
     int dx[K], dy[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) { dx[k] = x - tx[k]; dy[k] = y - ty[k]; }
-#ifdef BSX_X_LIBSQRT
-#pragma unroll
-    for (int k = 0; k < K; ++k) d[k] = obs_dist(x, y, tx[k], ty[k]);
-#else
     double q[K], w[K], g[K], h[K], r[K], c[K];
 #define BSX_EACH _Pragma("unroll") for (int k = 0; k < K; ++k)
     BSX_EACH q[k] = double(__mul24(dx[k], dx[k]) + __mul24(dy[k], dy[k]));           // |dx|, |dy| < 2^11
@@ -370,7 +304,6 @@ __device__ inline void geometry_n(int x, int y, const int (&tx)[K], const int (&
     BSX_EACH g[k] = __builtin_fma(c[k], h[k], g[k]);
     BSX_EACH d[k] = float((q[k] == 0.0 ? 0.0 : g[k]) * (2.0 / FIELD_DIAG) - 1.0);
 #undef BSX_EACH
-#endif
     double a[K];
     atan2_pixels_n<K>(dy, dx, a);
 #pragma unroll
@@ -908,11 +841,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         // The first UNR list indices straight-line: a loop iteration here is a chain of vector compare -> scalar test -> branch
         // (~230 cycles each in the stamps, 5 to 6 of them under uniform play); without the branches an index costs ~10
         // instructions -- a lane without an entry k writes the scratch entry behind the table instead of being masked off.
-#ifdef BSX_X_SLOTLOOP
-        constexpr int UNR = 0;
-#else
         constexpr int UNR = 6;
-#endif
 #pragma unroll
         for (int k = 0; k < UNR; ++k) {
             const bool h = k < ci;
@@ -938,12 +867,10 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     FSTAMP(5);
-#ifndef BSX_X_LATEFETCH
     // the first round's entries are requested as soon as the slot table exists -- BEFORE the shot: the ~150 cycles of the table's
     // LDS round trip are exposed here, and the loads leave ~1.5k cycles (Philox + sincos) earlier; they are what the bullet
     // rounds wait for, and the move + observation geometry alone are shorter than a round trip to the MALL / HBM
     if constexpr (PACK) cur = fetch_slot(0);
-#endif
     double2 nd = make_double2(0.0, 0.0);
     if (spawn) {
         double uu = uu_in;
@@ -961,9 +888,6 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     if constexpr (PACK) {                                // this call's shot as the work slot will read it: list word (age 0) + step
         s_nw[tid] = pack_bullet(x, y, 0);
         s_nd[2 * tid] = nd.x; s_nd[2 * tid + 1] = nd.y;
-#ifdef BSX_X_LATEFETCH
-        cur = fetch_slot(0);                             // (round 2's first placement: behind the shot, which covered the table's LDS round trip)
-#endif
         if (MULTI && !ACTOR && tk + 1 < p.T) load_inputs(tk + 1, rin_next);   // behind this tick's own loads
     }
     FSTAMP(6);
@@ -1229,14 +1153,10 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
                 }
             }
         };
-#ifdef BSX_X_NOPEEL
-        for (int rd = 0; rd * SPB < slots; ++rd) do_round(rd);
-#else
         // the first round stands alone (under sparse play it is the only one in 85 % of the waves): straight-line code, no loop-carried
         // copies of the prefetch registers
         if (slots > 0) do_round(0);
         for (int rd = 1; rd * SPB < slots; ++rd) do_round(rd);
-#endif
         if (slots > 0) flush_stores();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1646,11 +1566,7 @@ void launch_for_n_w(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs&
 // 32-bit offsets when every array of the job stays below 4 GB: the widest rows are the bullets' step vectors (12 x 16 bytes per agent)
 // and an observation row is at most 4 (3 * 16 + 2) = 200 bytes per agent.
 inline bool narrow_offsets_ok(int64_t E, int n, uint32_t flags) {
-#ifdef BSX_X_OFF64
-    return false;
-#else
     return !(flags & BSX_F_WIDE_OFFSETS) && uint64_t(E) * uint64_t(2 * n) * 200ull <= 0xFFFFFFFFull;
-#endif
 }
 template <bool CONT, bool MULTI, bool LG>
 void launch_for_n(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs& a) {
@@ -1704,13 +1620,7 @@ extern "C" {
 
 int bsx_abi_version(void) { return BSX_ABI_VERSION; }
 
-int bsx_build_flags(void) {
-#ifdef BSX_STAMPS
-    return int(DIAG & 0xFFu) | 0x100;
-#else
-    return int(DIAG & 0xFFu);
-#endif
-}
+int bsx_build_flags(void) { return BUILD_FLAGS; }
 
 int bsx_stream_synchronize(void* stream) { return int(hipStreamSynchronize(static_cast<hipStream_t>(stream))); }
 
@@ -1925,13 +1835,5 @@ int bsx_instinct_continuous(const float* obs, double* actions, const double* rnd
     hipLaunchKernelGGL(bsx_instinct_kernel, dim3(unsigned((EA + TPB - 1) / TPB)), dim3(TPB), 0, static_cast<hipStream_t>(stream), a);
     return int(hipGetLastError());
 }
-
-#ifdef BSX_STAMPS
-// diagnostic builds only: where the stamps go (device buffer of 8 * waves uint64)
-int bsx_debug_set_stamps(void* buf) {
-    unsigned long long* p = static_cast<unsigned long long*>(buf);
-    return int(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)));
-}
-#endif
 
 }  // extern "C"

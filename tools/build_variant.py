@@ -7,7 +7,7 @@
     BSX_LIB_PATH=deep-rl-battlespace_amd/csrc/variants/lib_<name>.so [BSX_ALLOW_DIAG=1] python bench.py ...
 
 Same sources and base flags as deep-rl-battlespace_amd/build.py; the extra flags select what differs (-DBSX_DIAG=<bits>,
--DBSX_STAMPS, -DBSX_X_<experiment>, -mllvm ...).  A variant whose results are not the reference's reports that through
+-DBSX_STAMPS, -DBSX_X_NOPACK -- see csrc/bsx_diag.h, which only these builds include --, -mllvm ...).  A variant whose results are not the reference's reports that through
 bsx_build_flags() and the binding refuses it without BSX_ALLOW_DIAG=1.  hipcc cross-compiles without a GPU, so variants
 are built in the build container and travel to the GPU box with the snapshot (csrc/variants/*.so is git-ignored)."""
 import importlib.util
@@ -29,7 +29,8 @@ def build_variant(name, extra, drop=()):
     for src, flags in B.SOURCES:
         obj = os.path.join(out_dir, f"{name}_{os.path.basename(src)}.o")
         fl = [f for f in flags if f not in drop]
-        more = extra if src.endswith("bsx_kernels.hip") else [f for f in extra if f.startswith("-DBSX_X_ACTOR")]
+        # -DBSX_VARIANT: bsx_kernels.hip takes its diagnostic switches from csrc/bsx_diag.h instead of the product constants
+        more = ["-DBSX_VARIANT", *extra] if src.endswith("bsx_kernels.hip") else [f for f in extra if f.startswith("-DBSX_X_ACTOR")]
         subprocess.run([hipcc, *B.COMMON, *fl, *more, "-I", B.INCLUDE, "-c", src, "-o", obj], check=True)
         objs.append(obj)
     lib = os.path.join(out_dir, f"lib_{name}.so")
