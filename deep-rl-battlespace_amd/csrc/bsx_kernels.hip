@@ -14,10 +14,12 @@
 //     independent loads go out in one batch as raw 16-byte words (clamped indices, no per-lane branches); the dependent loads
 //     (heading-table entry, bullet entries) are covered by the shot's Philox + sincos and the fp64 observation math; predicates
 //     are integer sign masks, not SGPR lane masks.
-//   * an agent's bullets are a dense creation-ordered list (row j = j-th bullet of every agent).  For team sizes 1 .. 4 the
-//     bullets of ALL lanes of a wave are updated in WORK SLOTS packed across the wavefront (entry-major, so a round's lanes read
-//     and write along rows): under sparse play one round of 64 slots instead of ~7 mostly-empty per-lane rounds; the outcome
-//     returns to the owner through one LDS add per slot, survivors are stored straight to their compacted position.
+//   * an agent's bullets are a dense creation-ordered list (row j = j-th bullet of every agent) of 8-byte entries: position and
+//     age in one word, the per-update step as an INTEGER code in the other (written once by the shot; exactly the reference's
+//     float64 add-then-truncate, see step_code).  For team sizes 1 .. 4 the bullets of ALL lanes of a wave are updated in WORK
+//     SLOTS packed across the wavefront (entry-major, so a round's lanes read and write along rows): under sparse play one
+//     round of 64 slots instead of ~7 mostly-empty per-lane rounds; the outcome returns to the owner through one LDS add per
+//     slot, survivors are stored straight to their compacted position (4 bytes in place, 8 when the entry moves).
 //   * post-move plane poses and hit points are handed to the other planes of the game by cross-lane moves (1v1) or wave-private
 //     LDS (larger teams); the all-pairs range / angle-off geometry of a team pair is computed once per pair; observation rows
 //     leave straight from registers with the non-temporal hint (the fused rollout keeps them in LDS for the actor's MFMAs).
@@ -73,7 +75,6 @@ template <class T> __device__ inline void out_store(T* p, T v) { __builtin_nonte
 // 1 M x 1v1 73.4 -> 74.5: used for team sizes >= 2 only (NT_STATE below), never inside a multi-tick launch (the same wave reads
 // its bullet rows back one tick later).
 typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
-typedef double v2d_t __attribute__((ext_vector_type(2)));
 template <bool NT, class T> __device__ inline void st_store(T* p, T v) {
     if (NT) __builtin_nontemporal_store(v, p);
     else *p = v;
@@ -95,7 +96,7 @@ struct __align__(16) PlaneRec {   // 16 B per agent
     int16_t x, y;                 // sprite centre (pygame Rect ints)
     uint16_t live;                // number of entries (0..12) in this agent's bullet list
     int8_t hp;                    // alive <=> hp > 0 (sprites.py:143-153)
-    uint8_t pad;
+    uint8_t xf;                   // 1 = some bullet of this agent's list carries the exact-path flag (step_code); cleared when the list runs empty
     double dir;                   // degrees, [0, 360]
 };
 struct __align__(16) EnvRec {     // 16 B per env
@@ -105,7 +106,7 @@ struct __align__(16) EnvRec {     // 16 B per env
     uint8_t done;                 // env_done
     uint8_t winner;               // BSX_WINNER_*
 };
-struct Layout { size_t lut, env, cnt, plane, bxy, bd, bdir, total; };
+struct Layout { size_t lut, env, cnt, plane, bent, bdir, bd, total; };
 
 __host__ __device__ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
@@ -118,24 +119,26 @@ __host__ __device__ inline Layout make_layout(int64_t E, int n) {
     L.cnt = o;   o = align256(o + size_t(E) * sizeof(int4));
     L.plane = o; o = align256(o + EA * sizeof(PlaneRec));
     // Bullets of an agent are a DENSE list in creation order (entry j of every agent is row j: lanes read the same row
-    // -> coalesced however sparse the bullets are); an entry = packed word x(12) | y(12) | age(4) | 0(4) plus its step.
-    L.bxy = o;   o = align256(o + size_t(K) * EA * sizeof(uint32_t)); // [K][EA] words; age 1..11 = updates so far, 15 = tombstone
-    L.bd = o;    o = align256(o + size_t(K) * EA * sizeof(double2));  // [K][EA]: per-update displacement (45cos, 45sin), same index
+    // -> coalesced however sparse the bullets are); an entry = two words: .x = x(11) | y(10) | age(4), rewritten by every
+    // update; .y = the step code (step_code below), written by the shot and carried along when compaction moves the entry.
+    L.bent = o;  o = align256(o + size_t(K) * EA * sizeof(uint2));    // [K][EA] entries; age 1..11 = updates so far, 15 = tombstone
     L.bdir = o;  o = align256(o + size_t(K) * EA * sizeof(double));   // [K][EA]: heading, RING by birth tick % 12 (export only)
+    L.bd = o;    o = align256(o + size_t(K) * EA * sizeof(double2));  // [K][EA]: float64 step (45cos, 45sin), RING by birth tick % 12, of the RARE shots whose
+                                                                      //          step code carries the exact-path flag; never read or written otherwise
     L.total = o;
     return L;
 }
 
 struct StatePtrs {
-    const double2* lut; EnvRec* env; int4* cnt; PlaneRec* plane; uint32_t* bxy; double2* bd; double* bdir;
+    const double2* lut; EnvRec* env; int4* cnt; PlaneRec* plane; uint2* bent; double* bdir; double2* bd;
 };
 inline StatePtrs state_ptrs(void* base, int64_t E, int n) {
     Layout L = make_layout(E, n);
     char* b = static_cast<char*>(base);
     return StatePtrs{reinterpret_cast<const double2*>(b + L.lut), reinterpret_cast<EnvRec*>(b + L.env),
                      reinterpret_cast<int4*>(b + L.cnt), reinterpret_cast<PlaneRec*>(b + L.plane),
-                     reinterpret_cast<uint32_t*>(b + L.bxy), reinterpret_cast<double2*>(b + L.bd),
-                     reinterpret_cast<double*>(b + L.bdir)};
+                     reinterpret_cast<uint2*>(b + L.bent), reinterpret_cast<double*>(b + L.bdir),
+                     reinterpret_cast<double2*>(b + L.bd)};
 }
 
 // ---------------------------------------------------------------------------------------------- Philox4x32-10
@@ -318,12 +321,48 @@ __device__ inline uint32_t rotl12(uint32_t v, int s) {  // rotate a 12-bit mask 
 __device__ inline int sx16(uint32_t w) { return int(int16_t(w & 0xFFFFu)); }
 __device__ inline int sy16(uint32_t w) { return int(int16_t(w >> 16)); }
 __device__ inline uint32_t pack_xy(int x, int y) { return (uint32_t(x) & 0xFFFFu) | (uint32_t(y) << 16); }
-// bullet list entry: a stored bullet is inside the field (0..1200, 0..800), so 12 unsigned bits per coordinate
+// Bullet list entry, two words.  .x = x (11 bits) | age << 11 (4 bits: updates so far, 15 = tombstone) | exact-path flag << 15 |
+// y << 16: a stored bullet is inside the field (0..1200, 0..800), and the two coordinates sit in the two 16-bit halves so that the
+// move and every rectangle test below work on both at once (v_pk_*_i16).  .y = the per-update step as two signed 16-bit halves.
 constexpr uint32_t TOMBSTONE_AGE = 15;
-__device__ inline uint32_t pack_bullet(int x, int y, int age) { return uint32_t(x) | (uint32_t(y) << 12) | (uint32_t(age) << 24); }
-__device__ inline int bullet_x(uint32_t w) { return int(w & 0xFFFu); }
-__device__ inline int bullet_y(uint32_t w) { return int((w >> 12) & 0xFFFu); }
-__device__ inline int bullet_age(uint32_t w) { return int((w >> 24) & 0xFu); }
+constexpr uint32_t ENT_XY = 0x03FF07FFu, ENT_AGE = 0x7800u, ENT_EXACT = 0x8000u;
+__device__ inline uint32_t pack_bullet(int x, int y, int age) { return uint32_t(x) | (uint32_t(age) << 11) | (uint32_t(y) << 16); }
+__device__ inline int bullet_x(uint32_t w) { return int(w & 0x7FFu); }
+__device__ inline int bullet_y(uint32_t w) { return int((w >> 16) & 0x3FFu); }
+__device__ inline int bullet_age(uint32_t w) { return int((w >> 11) & 0xFu); }
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ inline s16x2 as_pk(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ inline uint32_t pk_bits(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+constexpr uint32_t pk_const(int lo, int hi) { return (uint32_t(lo) & 0xFFFFu) | (uint32_t(hi) << 16); }
+constexpr int PK_BIAS = 64;                        // > 46: a moved bullet's biased coordinates are positive
+// 0 / -1: is the sign bit of either half set?
+__device__ inline int pk_any_negative(uint32_t t) { return int(t | (t << 16)) >> 31; }
+// The step.  Bullet.update's move (sprites.py:330-333) is rect.center = (x + 45 cos, y + 45 sin) in binary64 from the INTEGER centre,
+// the store truncating toward zero.  For d = 45 cos with f = floor(d) and r = d - f: the exact sum s = x + d lies at distance
+// min(r, 1 - r) from an integer and the binary64 sum fl(x + d) is at most 2^-43 away from s (|s| < 2048), so whenever r stays
+// 2^-40 away from 0 and 1 the rounded sum lies strictly between the same two integers n = x + f and n + 1 as s, and int() of it
+// is n for n >= 0 and n + 1 for n < 0 (truncation toward zero: x = 3, d = -3.5 -> 0) -- integer arithmetic, exactly the
+// reference's result.  So the list carries f for both axes (|d| <= 45) and, for the other case, a flag: such a shot also stores its
+// float64 step (ring `bd`) and its updates take the float64 sum, as every bullet did before round 3.
+// The shot decides in float32, with a wider guard: |float(d) - d| <= 2^-19 for |d| < 64, so a float32 fraction in
+// [2^-17, 1 - 2^-17] puts d itself at least 2^-18 from every integer -- floor(float(d)) is floor(d) and r is far inside the band.
+// The flag is then set for one shot in ~30 000 (and for headings on an axis: scripted tests); the float64 path it selects is a
+// 16-byte load and two adds behind a branch that a wave takes only if one of its agents says it owns such a bullet (PlaneRec.xf).
+constexpr float STEP_GUARD = 0x1p-17f;
+__device__ inline uint32_t step_code(double dx, double dy, bool& exact) {
+    const float dxf = float(dx), dyf = float(dy);
+    const float fx = floorf(dxf), fy = floorf(dyf);
+    const float rx = dxf - fx, ry = dyf - fy;                       // exact
+    exact = !(fminf(rx, ry) >= STEP_GUARD && fmaxf(rx, ry) <= 1.0f - STEP_GUARD);
+    return pk_bits(__builtin_amdgcn_cvt_pk_i16(int(fx), int(fy)));
+}
+// (x, y) + (fx, fy) with the truncation toward zero of a negative sum, both halves at once
+__device__ inline uint32_t step_pk(uint32_t xy, uint32_t code) {
+    const s16x2 b = as_pk(xy) + as_pk(code);
+    return pk_bits(b - (b >> 15));
+}
+__device__ inline int ring_pos(int ks, int back) { const int q = ks - back; return q + ((q >> 31) & BSX_BULLET_SLOTS); }   // (ks - back) mod 12, 0 <= back < 12
 
 __host__ __device__ constexpr int group_width(int n) {
     int g = 2;
@@ -431,12 +470,12 @@ __device__ inline float4 one_hot_scores(int act) {               // what the sco
 
 // ---------------------------------------------------------------------------------------------- the step kernel
 // Record (un)packing on raw 16-byte words: keeps the loads as single dwordx4 instructions with no byte shuffling.
-__device__ inline void unpack_plane(const uint4 w, int& x, int& y, uint32_t& live, int& hp, double& dir) {
-    x = sx16(w.x); y = sy16(w.x); live = w.y & 0xFFFFu; hp = int(int8_t((w.y >> 16) & 0xFFu));
+__device__ inline void unpack_plane(const uint4 w, int& x, int& y, uint32_t& live, int& hp, uint32_t& xf, double& dir) {
+    x = sx16(w.x); y = sy16(w.x); live = w.y & 0xFFFFu; hp = int(int8_t((w.y >> 16) & 0xFFu)); xf = w.y >> 24;
     dir = __hiloint2double(int(w.w), int(w.z));
 }
-__device__ inline uint4 pack_plane(int x, int y, uint32_t live, int hp, double dir) {
-    return make_uint4(pack_xy(x, y), (live & 0xFFFFu) | ((uint32_t(hp) & 0xFFu) << 16), uint32_t(__double2loint(dir)),
+__device__ inline uint4 pack_plane(int x, int y, uint32_t live, int hp, uint32_t xf, double dir) {
+    return make_uint4(pack_xy(x, y), (live & 0xFFFFu) | ((uint32_t(hp) & 0xFFu) << 16) | (xf << 24), uint32_t(__double2loint(dir)),
                       uint32_t(__double2hiint(dir)));
 }
 struct EnvU {   // EnvRec fields in registers
@@ -474,7 +513,7 @@ __device__ inline void obs_pair(int x, int y, double dir, int tx, int ty, float&
 // that each encoding's kernel issues exactly its own action load in the first batch (an unconditional load of the unused encoding's
 // dummy line cost 1.6 % of the step; a load under a branch costs a second round trip, see load_inputs).
 // Row and byte offsets of the step kernel come in two widths (template parameter OFF32).  A job whose largest array stays below
-// 4 GB -- every measured configuration; 192 bytes of step vectors per agent are the largest rows, so up to 22 M agents -- addresses
+// 4 GB -- every measured configuration; 200 bytes per agent (the widest observation rows) are the bound, so up to 21 M agents -- addresses
 // memory as SGPR base + 32-bit VGPR byte offset: one shift or 24-bit multiply-add per dependent access where 64-bit offsets take two
 // 64 x 32 multiply-adds, two moves and a 64-bit shift-add (C2 7.33 -> 7.22 us, bullet-heavy 14.96 -> 14.73).  Larger jobs (2^30 games
 // are allowed) and BSX_F_WIDE_OFFSETS take the 64-bit kernels.
@@ -534,16 +573,39 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     constexpr int OWN_CAP = SPB * (K + 1) + 2;             // every lane with a full list plus this call's shot (+ one scratch entry, see part 1)
     __shared__ uint16_t s_own_all[PACK ? WAVES * OWN_CAP : 1];   // slot -> owner lane | item index << 8 | "this call's shot" << 15
     __shared__ uint32_t s_agg_all[PACK ? WAVES * SPB : 1];       // per owner: survivor bit per entry | misses << 16 | base hits << 24
-    __shared__ uint32_t s_eb_all[PACK ? WAVES * SPB : 1];        // per owner: enemy base x | y << 16
-    __shared__ uint32_t s_pq_all[PACK ? WAVES * SPB : 1];        // per plane: post-move x | y << 11 | alive << 21
-    __shared__ uint32_t s_nw_all[PACK ? WAVES * SPB : 1];        // per owner: this call's shot as a list word (age 0)
-    __shared__ __attribute__((aligned(16))) double s_nd_all[PACK ? WAVES * SPB * 2 : 2];   // ... and its per-update step
+    // The rectangles a bullet is tested against (enemy base, enemy planes' sprites), staged per owner / per plane for the work slots.
+    // 1v1: as (lower corner, upper corner) pairs of packed (x, y) halves BIASED by +64, so that no half is ever negative and the
+    // corners are plain 32-bit adds of packed literals: a bullet at b overlaps <=> no half of (b - lower) | (upper - b) is negative
+    // (C2 7.33 -> 7.20 us against the centre form: ~15 instructions fewer per round where the instruction count is the bound).
+    // Larger teams: the centre (x | alive << 15 | y << 16) and the margins as constants in the slot -- measured faster there
+    // (4v4 23.1 us against 24.7 with corners; the same launches, four runs each).
+    constexpr bool CORNERS = N == 1;
+    typedef typename std::conditional<CORNERS, u32x2, uint32_t>::type rect_t;
+    __shared__ __attribute__((aligned(8))) rect_t s_eb_all[PACK ? WAVES * SPB : 1];        // per owner: the enemy base, dx in [-33, 33], dy in [-32, 31]
+    __shared__ __attribute__((aligned(8))) rect_t s_pq_all[PACK ? WAVES * SPB : 1];        // per plane: its post-move sprite, dx in [-27, 27], dy in [-25, 24]; dead: never hit
+    // rect(centre, alive, margins below / above): what the owner side stages
+    auto make_rect = [](uint32_t c, bool alive, int xl, int yl, int xh, int yh) {
+        if constexpr (CORNERS) return alive ? u32x2{c + pk_const(PK_BIAS - xl, PK_BIAS - yl), c + pk_const(PK_BIAS + xh, PK_BIAS + yh)} : u32x2{0x7F007F00u, 0u};
+        else return c | (alive ? 0x8000u : 0u);
+    };
+    // 0 / -1: does the bullet at b (CORNERS: biased) overlap the rectangle?
+    auto hits_rect = [](s16x2 b, rect_t r, int xl, int yl, int xh, int yh) {
+        if constexpr (CORNERS) return ~pk_any_negative(pk_bits(b - as_pk(r.x)) | pk_bits(as_pk(r.y) - b));
+        else {
+            const s16x2 d = b - as_pk(r & ENT_XY);
+            return ~pk_any_negative(pk_bits(d + as_pk(pk_const(xl, yl))) | pk_bits(as_pk(pk_const(xh, yh)) - d)) & (int(r << 16) >> 31);
+        }
+    };
+    __shared__ uint32_t s_nw_all[PACK ? WAVES * SPB : 1];        // per owner: this call's shot as an entry word (age 0) | the owner's tick % 12 << 26
+    __shared__ uint32_t s_ns_all[PACK ? WAVES * SPB : 1];        // ... its step code
+    __shared__ __attribute__((aligned(16))) double s_nd_all[PACK ? WAVES * SPB * 2 : 2];   // ... and its float64 step (written and read on the exact path only)
     __shared__ unsigned long long s_ov_all[PACK ? WAVES * SPB : 1], s_pm_all[PACK ? WAVES * SPB : 1];   // per owner: overlap fields / positions by age
     auto* const s_own = BSX_LDS(uint16_t, s_own_all) + (PACK ? wave * OWN_CAP : 0);
     auto* const s_agg = BSX_LDS(uint32_t, s_agg_all) + (PACK ? wave * SPB : 0);
-    auto* const s_eb = BSX_LDS(uint32_t, s_eb_all) + (PACK ? wave * SPB : 0);
-    auto* const s_pq = BSX_LDS(uint32_t, s_pq_all) + (PACK ? wave * SPB : 0);
+    auto* const s_eb = BSX_LDS(rect_t, s_eb_all) + (PACK ? wave * SPB : 0);
+    auto* const s_pq = BSX_LDS(rect_t, s_pq_all) + (PACK ? wave * SPB : 0);
     auto* const s_nw = BSX_LDS(uint32_t, s_nw_all) + (PACK ? wave * SPB : 0);
+    auto* const s_ns = BSX_LDS(uint32_t, s_ns_all) + (PACK ? wave * SPB : 0);
     auto* const s_nd = BSX_LDS(double, s_nd_all) + (PACK ? wave * SPB * 2 : 0);
     auto* const s_ov = BSX_LDS(unsigned long long, s_ov_all) + (PACK ? wave * SPB : 0);
     auto* const s_pm = BSX_LDS(unsigned long long, s_pm_all) + (PACK ? wave * SPB : 0);
@@ -594,7 +656,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // tick, the plane and game records once, after the last one.
     int x = 0, y = 0, hp = 0, games = 0;
     int4 cnt4 = make_int4(0, 0, 0, 0);                   // my game's counters (games, ties, red wins, blue wins): loaded with the other T0 words
-    uint32_t live = 0;
+    uint32_t live = 0, xf = 0;
     double dir = 0.0;
     EnvU er = {};
     RawIn rin = {}, rin_next = {};
@@ -677,7 +739,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
             asm volatile("" : "+s"(seed_t), "+s"(env_offset_t));
             if (N == 0) asm volatile("" : "+s"(tie_tick));
         }
-        unpack_plane(prw, x, y, live, hp, dir);
+        unpack_plane(prw, x, y, live, hp, xf, dir);
         er = unpack_env(erw);
     }
     const DecIn din = MULTI ? din_next : decode(rin);
@@ -758,7 +820,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     const uint32_t live0 = live;
     // Bullets are sparse (uniform random play: 0.6 per agent, 12 at most), and each agent's bullets are a dense list in
     // creation order: entry j of every agent lives in row j, so the lanes of a wave that own a j-th bullet read ONE
-    // contiguous row.  The first four entries are statically indexed "items", their eight loads issued here in one
+    // contiguous row.  The first four entries are statically indexed "items", their four loads issued here in one
     // batch; longer lists are finished by a wave-uniform loop further down.  A missing item reads the heading
     // table's first entry (one shared cache line, no DRAM traffic).
     // The heading table (361 x 16 B, read by every wave of every launch) stays hot in each CU's L1: the entry for the
@@ -769,13 +831,12 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     if (!CONT) dl = p.st.lut[min(max(int(dir_rot), 0), 360)];   // 21.5*cos(-radians(d)), 21.5*sin(-radians(d)) from host libm
     constexpr int NI = 4;
     const int cnt0 = (DIAG & 2u) ? 0 : int(live0 & 15u);
-    uint32_t iw[NI]; double2 idd[NI];
+    uint2 ien[NI];
     if constexpr (!PACK) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const bool has = j < cnt0;
-            iw[j] = *(has ? &p.st.bxy[size_t(j) * EAt + gt] : reinterpret_cast<const uint32_t*>(p.st.lut));
-            idd[j] = *(has ? &p.st.bd[size_t(j) * EAt + gt] : p.st.lut);
+            ien[j] = *(has ? &p.st.bent[size_t(j) * EAt + gt] : reinterpret_cast<const uint2*>(p.st.lut));
         }
         if (MULTI && !ACTOR && tk + 1 < p.T) load_inputs(tk + 1, rin_next);   // behind this tick's own loads: nothing waits for it before the tick ends
     }
@@ -819,8 +880,8 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // below l that have an entry k: one ballot per k.
     FSTAMP(3);
     int slots = 0;                                       // wave total
-    struct Slot { int o, k; bool isnew, on; uint32_t wd; double2 dd; ix_t go; };   // owner lane, list index, "this call's shot", in use; entry; owner's row
-    Slot cur = {0, 0, false, false, 0u, make_double2(0.0, 0.0), 0};
+    struct Slot { int o, k; bool isnew, on; uint2 en; ix_t go; };   // owner lane, list index, "this call's shot", in use; entry; owner's row
+    Slot cur = {0, 0, false, false, make_uint2(0u, 0u), 0};
     ix_t gbt = ix_t(wblk * EPB) * ix_t(A);         // row of lane 0's agent; owner lane o sits (o / G) * A + (o % G) rows on
     if (MULTI) asm volatile("" : "+v"(gbt));
     auto fetch_slot = [&](int rd) {                      // slot rd * 64 + lane: who owns it, and its list entry (loads in flight on return)
@@ -831,9 +892,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         f.o = int(v & 63u); f.k = int((v >> 8) & 15u); f.isnew = (v >> 15) != 0u;
         f.go = gbt + ix_t(f.o / G) * ix_t(A) + ix_t(f.o & (G - 1));
         const bool ld = f.on && !f.isnew;
-        const ix_t off = ix_t(f.k) * EAt + f.go;         // one multiply for both arrays
-        f.wd = *elem(p.st.bxy, ld ? off : ix_t(0));       // (a slot that loads nothing reads element 0: one shared line, any mapped address will do)
-        f.dd = *elem(p.st.bd, ld ? off : ix_t(0));
+        f.en = *elem(p.st.bent, ld ? ix_t(f.k) * EAt + f.go : ix_t(0));   // (a slot that loads nothing reads element 0: one shared line, any mapped address will do)
         return f;
     };
     if constexpr (PACK) {
@@ -861,7 +920,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         }
         FSTAMP(4);
         s_agg[tid] = 0u;
-        s_eb[tid] = pack_xy(team == 0 ? er.bbx : er.brx, team == 0 ? er.bby : er.bry);
+        s_eb[tid] = make_rect(pack_xy(team == 0 ? er.bbx : er.brx, team == 0 ? er.bby : er.bry), true, 33, 32, 33, 31);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -871,7 +930,9 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // LDS round trip are exposed here, and the loads leave ~1.5k cycles (Philox + sincos) earlier; they are what the bullet
     // rounds wait for, and the move + observation geometry alone are shorter than a round trip to the MALL / HBM
     if constexpr (PACK) cur = fetch_slot(0);
-    double2 nd = make_double2(0.0, 0.0);
+    double2 nd = make_double2(0.0, 0.0);                 // this call's shot: float64 step, step code
+    uint32_t ncode = 0u;
+    bool nexact = false;
     if (spawn) {
         double uu = uu_in;
         if (!u_t && !(DIAG & 8u)) {
@@ -883,11 +944,15 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         if (DIAG & 16u) { float sf, cf; __sincosf(float(-(bdir * DEG2RAD)), &sf, &cf); sn = double(sf); cs = double(cf); }   // timing ablation: a few-instruction float sincos (directions right to ~1e-6, so the same bullet population)
         else sincos(-(bdir * DEG2RAD), &sn, &cs);
         nd = make_double2(BULLET_STEP * cs, BULLET_STEP * sn);
+        ncode = step_code(nd.x, nd.y, nexact);
         st_store<NT_STATE>(elem(p.st.bdir, ix_t(ks) * EAt + gt), bdir);       // ring by birth tick: never moves, read only by bsx_export_state
+        xf |= nexact ? 1u : 0u;                          // rare (step_code): this bullet moves by the float64 sum
     }
-    if constexpr (PACK) {                                // this call's shot as the work slot will read it: list word (age 0) + step
-        s_nw[tid] = pack_bullet(x, y, 0);
-        s_nd[2 * tid] = nd.x; s_nd[2 * tid + 1] = nd.y;
+    // does any bullet this wave is about to update take the float64 path?  Asked once, here, long before anything branches on it
+    const bool wave_exact = __any(phys && xf != 0u);
+    if constexpr (PACK) {                                // this call's shot as the work slot will read it: entry (age 0, the PRE-move pose; the owner's tick % 12 rides in the spare bits)
+        s_nw[tid] = pack_bullet(x, y, 0) | (nexact ? ENT_EXACT : 0u) | (uint32_t(ks) << 26);
+        s_ns[tid] = ncode;
         if (MULTI && !ACTOR && tk + 1 < p.T) load_inputs(tk + 1, rin_next);   // behind this tick's own loads
     }
     FSTAMP(6);
@@ -902,7 +967,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         er.tick = 0; er.done = 0; er.winner = BSX_WINNER_NONE;
         tick = 0;
         spawn_plane(seed_t, genv, STREAM_AUTORESET, uint32_t(games), a < A ? a : A - 1, n, x, y, dir);
-        hp = PLANE_HP; live = 0;
+        hp = PLANE_HP; live = 0; xf = 0;
     } else if (mode == M_PHYS && alive0) {
         // ---- process_action (battle_env.py:383-424)
         if (!CONT) {
@@ -928,7 +993,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // ---- hand the post-move pose and hit points to the other planes of the game.  1v1: the only other plane is the lane
     //      next door, three cross-lane moves (DPP) instead of LDS round trips; larger teams stage the block in LDS.
     int nx_ = 0, ny_ = 0, nhp_ = 0;                      // 1v1: the enemy's x, y, hit points
-    if constexpr (PACK) s_pq[tid] = uint32_t(x) | (uint32_t(y) << 11) | ((valid && hp > 0) ? (1u << 21) : 0u);
+    if constexpr (PACK) s_pq[tid] = make_rect(pack_xy(x, y), valid && hp > 0, 27, 25, 27, 24);
     if constexpr (N == 1) {
         nx_ = __shfl_xor(x, 1); ny_ = __shfl_xor(y, 1); nhp_ = __shfl_xor(valid ? hp : 0, 1);
     } else {
@@ -941,6 +1006,13 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     PSTAMP(3);
     // ---- observation geometry (battle_env.py:202-244) from the staged block, BEFORE the bullets: poses are final after
     //      the move, only the alive flags can still change; this fp64 math runs while the bullet-step loads are in flight.
+    if (wave_exact) {                                    // wave-uniform and rare: a flagged shot leaves its float64 step in the ring (and in LDS for its first update)
+        if constexpr (N == 1) asm volatile("");          // (keeps this a scalar branch; see the bullet rounds)
+        if (spawn && nexact) {
+            *elem(p.st.bd, ix_t(ks) * EAt + gt) = nd;
+            if constexpr (PACK) { s_nd[2 * tid] = nd.x; s_nd[2 * tid + 1] = nd.y; }
+        }
+    }
     const int obx = team == 0 ? er.bbx : er.brx, oby = team == 0 ? er.bby : er.bry;   // enemy base
     float ob_d = -1.0f, ob_a = -1.0f;
     float oe_d[NE], oe_a[NE];
@@ -1021,10 +1093,23 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
 #pragma unroll
         for (int j = 0; j < NE; ++j) eam[j] = ((N == 1 ? nhp_ : s_hp[eb + j]) > 0) ? -1 : 0;
     }
-    // one bullet: pre-update position, step `dd`, updates so far `age0`, list index `j` it was read from (-1: this call's shot)
-    auto update_item = [&](int j, int bx0, int by0, int age0, double2 dd, int lvm) {
-        const int bx = int(double(bx0) + dd.x);                                     // truncation toward zero
-        const int by = int(double(by0) + dd.y);
+    // the float64 move of the rare entries that carry the exact-path flag (exact_step() fetches the step the shot left in the ring)
+    auto move_exact = [&](uint32_t ew, auto exact_step) {
+        const double2 dd = exact_step();
+        const int ebx = int(double(bullet_x(ew)) + dd.x);    // truncation toward zero
+        const int eby = int(double(bullet_y(ew)) + dd.y);
+        return (uint32_t(ebx) & 0xFFFFu) | (uint32_t(eby) << 16);
+    };
+    // one bullet of MINE (per-lane walk): entry `en` (updates so far = its age field), list index `j` it was read from (-1: this call's shot)
+    auto update_item = [&](int j, uint2 en, int lvm) {
+        const int age0 = bullet_age(en.x);
+        uint32_t bpk = step_pk(en.x & ENT_XY, en.y);
+        if (wave_exact) {                                // wave-uniform, decided before the bullets
+            asm volatile("");
+            if (lvm != 0 && (en.x & ENT_EXACT) != 0u)
+                bpk = move_exact(en.x, [&]() { return j < 0 ? nd : *elem(p.st.bd, ix_t(ring_pos(ks, age0 > 11 ? 0 : age0)) * EAt + gt); });
+        }
+        const int bx = sx16(bpk), by = sy16(bpk);
         const int age = age0 + 1;
         // miss: dist_travelled >= 500 <=> 12th update (45*12 >= 500 > 45*11); else off the field (x>1200|x<0|y>800|y<0)
         const int missm = ((bx | (FIELD_W - bx) | by | (FIELD_H - by) | (11 - age)) >> 31);
@@ -1059,8 +1144,9 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
             ovl[0] |= (ag >> 2) == 0 ? f : 0ull; ovl[OW > 1 ? 1 : 0] |= (ag >> 2) == 1 ? f : 0ull; ovl[OW > 2 ? 2 : 0] |= (ag >> 2) == 2 ? f : 0ull;
         }
         if (keepm) {
-            p.st.bxy[size_t(pos) * EAt + gt] = pack_bullet(bx, by, age);
-            if (pos != j) p.st.bd[size_t(pos) * EAt + gt] = dd;           // the entry moved down (or is new): its step moves with it
+            const uint32_t nw_ = pack_bullet(bx, by, age) | (en.x & ENT_EXACT);
+            if (pos != j) p.st.bent[size_t(pos) * EAt + gt] = make_uint2(nw_, en.y);   // the entry moved down (or is new): its step moves with it
+            else p.st.bent[size_t(pos) * EAt + gt].x = nw_;
             posmap |= uint64_t(pos) << (4 * ag);
             pos += 1;
         }
@@ -1080,57 +1166,64 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         // a round's survivor stores are issued at the START of the next round (after the loop for the last one), i.e. BEFORE the
         // loads of the round after: loads and stores share the in-order vmcnt, so a wait for loads issued ahead of stores would
         // also sit out the stores' acknowledgement; issued behind them, both are long done when the entries are needed
-        bool st_on = false, st_dd = false; ix_t st_go = 0; int st_ps = 0; uint32_t st_w = 0u; double2 st_d = make_double2(0.0, 0.0);
+        bool st_on = false, st_mv = false; ix_t st_go = 0; int st_ps = 0; uint32_t st_w = 0u, st_c = 0u;
         auto flush_stores = [&]() {
             if (st_on) {
-                const ix_t off = ix_t(st_ps) * EAt + st_go;
-                st_store<NT_STATE>(elem(p.st.bxy, off), st_w);
-                if (st_dd) st_store<NT_STATE>(reinterpret_cast<v2d_t*>(elem(p.st.bd, off)), v2d_t{st_d.x, st_d.y});   // the entry moved down (or is new): its step moves with it
+                uint2* const q = elem(p.st.bent, ix_t(st_ps) * EAt + st_go);
+                st_store<NT_STATE>(&q->x, st_w);
+                if (st_mv) st_store<NT_STATE>(&q->y, st_c);  // the entry moved down (or is new): its step code moves with it
             }
         };
         // what a slot needs from its owner's side of the game, read from the wave's LDS block: enemy base, enemy planes (post-move
         // pose + alive flag), this call's shot
-        struct Ctx { uint32_t ebw, pq[NE], nw; double ndx, ndy; };
+        struct Ctx { rect_t ebw, pq[NE]; uint32_t nw, ns; };
         auto fetch_ctx = [&](int o) {
             Ctx c;
             c.ebw = s_eb[o];
             const int ebl = (o & ~(G - 1)) + (((o & (G - 1)) < N) ? N : 0);     // first lane of the owner's enemy team
 #pragma unroll
             for (int q = 0; q < NE; ++q) c.pq[q] = s_pq[ebl + q];
-            c.nw = s_nw[o]; c.ndx = s_nd[2 * o]; c.ndy = s_nd[2 * o + 1];
+            c.nw = s_nw[o]; c.ns = s_ns[o];
             return c;
         };
         Ctx cx = fetch_ctx(cur.o);
         auto do_round = [&](const int rd) {
             const int o = cur.o, k = cur.k; const bool isnew = cur.isnew, on = cur.on;
-            uint32_t wd = cur.wd; double2 dd = cur.dd;
+            uint2 en = cur.en;
             const ix_t go = cur.go;
             const Ctx c = cx;
             if (rd > 0) flush_stores();
             // more than 64 bullets in the wave: the next round's entries and context are fetched while this one is worked on
             if ((rd + 1) * SPB < slots) { cur = fetch_slot(rd + 1); cx = fetch_ctx(cur.o); }
-            const int obx_o = sx16(c.ebw), oby_o = sy16(c.ebw);
-            int qx[NE], qy[NE], qa[NE];
-#pragma unroll
-            for (int q = 0; q < NE; ++q) {
-                qx[q] = int(c.pq[q] & 0x7FFu); qy[q] = int((c.pq[q] >> 11) & 0x3FFu); qa[q] = -int((c.pq[q] >> 21) & 1u);
+            if (isnew) en = make_uint2(c.nw, c.ns);
+            const uint32_t age0f = en.x & ENT_AGE;                              // updates so far, << 11
+            const int lvm = (on && age0f != (TOMBSTONE_AGE << 11)) ? -1 : 0;     // a tombstone (plane hit last call) is dropped
+            // Everything from here to the outcome works on (x, y) PAIRS in the two 16-bit halves of a register: the move, and every
+            // rectangle test as "some lower or upper margin is negative" = a sign bit in either half.
+            uint32_t bpk = step_pk(en.x & ENT_XY, en.y);
+            if (wave_exact) {                            // wave-uniform, decided before the rounds: the float64 move of flagged entries
+                if constexpr (CORNERS) asm volatile("");   // (1v1: keeps this a scalar branch -- merged with the per-lane test below it is a masked block on the common
+                                                           //  path; larger teams measured faster with the merged form: 4v4 22.9 us against 23.7)
+                if (lvm != 0 && (en.x & ENT_EXACT) != 0u)                       // (this call's shot left its step in LDS, older ones in the ring by birth tick)
+                    bpk = move_exact(en.x, [&]() {
+                        return isnew ? make_double2(s_nd[2 * o], s_nd[2 * o + 1])
+                                     : *elem(p.st.bd, ix_t(ring_pos(int((c.nw >> 26) & 15u), int(age0f >> 11))) * EAt + go);
+                    });
             }
-            if (isnew) { wd = c.nw; dd = make_double2(c.ndx, c.ndy); }
-            const int age0 = bullet_age(wd);
-            const int lvm = (on && age0 != int(TOMBSTONE_AGE)) ? -1 : 0;         // a tombstone (plane hit last call) is dropped
-            const int bx = int(double(bullet_x(wd)) + dd.x);                    // truncation toward zero
-            const int by = int(double(bullet_y(wd)) + dd.y);
-            const int age = age0 + 1;
-            const int missm = ((bx | (FIELD_W - bx) | by | (FIELD_H - by) | (11 - age)) >> 31);
-            const int dxb = bx - obx_o, dyb = by - oby_o;
-            const int basem = ~(((dxb + 33) | (33 - dxb) | (dyb + 32) | (31 - dyb)) >> 31) & ~missm;
+            // miss: off the field (x > 1200 | x < 0 | y > 800 | y < 0), or dist_travelled >= 500 <=> this is the 12th update.  Plain
+            // 32-bit arithmetic with literals on the packed pair: a half that borrows from (or carries into) its neighbour does so
+            // only when a coordinate is negative or beyond the limit -- the bullet is a miss then, whatever the other half says, and
+            // the base / plane results below are discarded for a miss.
+            const uint32_t over = CORNERS ? pk_const(FIELD_W, FIELD_H) - bpk : pk_bits(as_pk(pk_const(FIELD_W, FIELD_H)) - as_pk(bpk));
+            const int missm = pk_any_negative(bpk | over | (0x5000u - age0f));
+            const s16x2 b2 = as_pk(bpk + (CORNERS ? pk_const(PK_BIAS, PK_BIAS) : 0u));
+            // base: 6x3 bullet rect vs 62x62 base rect, strict overlap <=> dx in [-33, 33] and dy in [-32, 31]
+            const int basem = hits_rect(b2, c.ebw, 33, 32, 33, 31) & ~missm;
+            // planes: vs the un-rotated 50x48 rect at the post-move pose <=> dx in [-27, 27] and dy in [-25, 24]
             uint32_t m = 0;
 #pragma unroll
-            for (int q = 0; q < NE; ++q) {
-                const int dxp = bx - qx[q], dyp = by - qy[q];
-                const int pm = ~(((dxp + 27) | (27 - dxp) | (dyp + 25) | (24 - dyp)) >> 31) & qa[q];
-                m |= uint32_t(pm) & (1u << q);
-            }
+            for (int q = 0; q < NE; ++q) m |= uint32_t(hits_rect(b2, c.pq[q], 27, 25, 27, 24)) & (1u << q);
+            const int age = int(age0f >> 11) + 1;
             const int gonem = (missm | basem) & lvm;
             const int keepm = lvm & ~gonem;
             m &= uint32_t(keepm);
@@ -1144,7 +1237,8 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const int ps = __popc(s_agg[o] & ((1u << k) - 1u));
-            st_on = keepm != 0; st_dd = isnew || ps != k; st_go = go; st_ps = ps; st_w = pack_bullet(bx, by, age); st_d = dd;
+            st_on = keepm != 0; st_mv = isnew || ps != k; st_go = go; st_ps = ps; st_c = en.y;
+            st_w = ((en.x & (ENT_AGE | ENT_EXACT)) | bpk) + 0x800u;             // the new position, age + 1, the flag as it was
             if (__any(m != 0u)) {                        // wave-uniform and rare: a bullet overlaps a live enemy plane
                 any_hit = true;
                 if (m != 0u) {
@@ -1168,7 +1262,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
             s_ov[tid] = 0ull; s_pm[tid] = 0ull;
         }
         if (N != 1 && nbase) __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)(&s_bhit[gl + team]), nbase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (phys) live = uint32_t(pos);
+        if (phys) { live = uint32_t(pos); xf = pos ? xf : 0u; }
     } else
     {
         const int physm = phys ? -1 : 0;
@@ -1177,30 +1271,24 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         // waiting for the survivor STORES of earlier items to be acknowledged before a later item may start.
         __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0); expcnt / lgkmcnt untouched
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int age0 = bullet_age(iw[j]);                                     // a tombstone (plane hit last call) is dropped
-            update_item(j, bullet_x(iw[j]), bullet_y(iw[j]), age0, idd[j], ((j < cnt0 && age0 != int(TOMBSTONE_AGE)) ? -1 : 0) & physm);
-        }
+        for (int j = 0; j < NI; ++j)                                                // a tombstone (plane hit last call) is dropped
+            update_item(j, ien[j], ((j < cnt0 && bullet_age(ien[j].x) != int(TOMBSTONE_AGE)) ? -1 : 0) & physm);
         // lists longer than NI: two more rounds when every agent fires every tick
         for (int base = NI; __any(cnt0 > base); base += NI) {
-            uint32_t rw[NI]; double2 rd[NI];
+            uint2 re[NI];
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 const bool has = base + j < cnt0;
-                rw[j] = *(has ? &p.st.bxy[size_t(base + j) * EAt + gt] : reinterpret_cast<const uint32_t*>(p.st.lut));
-                rd[j] = *(has ? &p.st.bd[size_t(base + j) * EAt + gt] : p.st.lut);
+                re[j] = *(has ? &p.st.bent[size_t(base + j) * EAt + gt] : reinterpret_cast<const uint2*>(p.st.lut));
             }
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int age0 = bullet_age(rw[j]);
-                update_item(base + j, bullet_x(rw[j]), bullet_y(rw[j]), age0, rd[j],
-                            ((base + j < cnt0 && age0 != int(TOMBSTONE_AGE)) ? -1 : 0) & physm);
-            }
+            for (int j = 0; j < NI; ++j)
+                update_item(base + j, re[j], ((base + j < cnt0 && bullet_age(re[j].x) != int(TOMBSTONE_AGE)) ? -1 : 0) & physm);
         }
         // this call's shot is the newest bullet: appended last
-        update_item(-1, x0, y0, 0, nd, (spawn ? -1 : 0) & physm);
+        update_item(-1, make_uint2(pack_bullet(x0, y0, 0) | (nexact ? ENT_EXACT : 0u), ncode), (spawn ? -1 : 0) & physm);
         if (N != 1 && nbase) __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)(&s_bhit[gl + team]), nbase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (phys) live = uint32_t(pos);
+        if (phys) { live = uint32_t(pos); xf = pos ? xf : 0u; }
     }
     PSTAMP(5);
     // ---- ordered plane-hit resolve (battle_env.py:332-360 with sprites.py:348-350): creation order = oldest age
@@ -1243,7 +1331,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         while (consumed) {
             const int ag = __builtin_ctz(consumed);
             consumed &= consumed - 1u;
-            *elem(p.st.bxy, ix_t((posmap >> (4 * ag)) & 15u) * EAt + gt) = pack_bullet(0, 0, int(TOMBSTONE_AGE));
+            elem(p.st.bent, ix_t((posmap >> (4 * ag)) & 15u) * EAt + gt)->x = pack_bullet(0, 0, int(TOMBSTONE_AGE));
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1287,7 +1375,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     const bool last_tick = !MULTI || tk == p.T - 1;
     if (valid) {
         if (MULTI ? last_tick : (mode == M_PHYS || mode == M_RESET))
-            st_store<NT_STATE>(elem(reinterpret_cast<v4u_t*>(p.st.plane), gt), as_v4u(pack_plane(x, y, live, hp, dir)));
+            st_store<NT_STATE>(elem(reinterpret_cast<v4u_t*>(p.st.plane), gt), as_v4u(pack_plane(x, y, live, hp, xf, dir)));
         out_store(elem(rew_t, gt), float(rew));
         out_store(elem(done_t, gt), er.done ? uint8_t(1) : uint8_t(alive ? 0 : 1));
     }
@@ -1430,7 +1518,7 @@ __global__ __launch_bounds__(TPB) void bsx_reset_kernel(const ResetArgs p) {
         }
         er.bhp_r = er.bhp_b = int16_t(5 * n);
         er.tick = 0; er.done = 0; er.winner = BSX_WINNER_NONE;
-        pr.hp = PLANE_HP; pr.live = 0;
+        pr.hp = PLANE_HP; pr.live = 0; pr.xf = 0;
         if (valid) p.st.plane[g] = pr;
         if (valid && a == 0) p.st.env[e] = er;
     }
@@ -1477,7 +1565,7 @@ __global__ __launch_bounds__(TPB) void bsx_export_kernel(const ExportArgs p) {
     }
     const int cnt = int(pr.live & 15u);
     for (int j2 = 0; j2 < cnt; ++j2) {
-        const uint32_t w = p.st.bxy[size_t(j2) * EA + g];
+        const uint32_t w = p.st.bent[size_t(j2) * EA + g].x;
         const int age = bullet_age(w);
         if (age == int(TOMBSTONE_AGE)) continue;
         int slot = (ptick - age + 1) % K;
@@ -1563,8 +1651,8 @@ void launch_for_n_w(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs&
         default: hipLaunchKernelGGL((bsx_step_kernel<0, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
     }
 }
-// 32-bit offsets when every array of the job stays below 4 GB: the widest rows are the bullets' step vectors (12 x 16 bytes per agent)
-// and an observation row is at most 4 (3 * 16 + 2) = 200 bytes per agent.
+// 32-bit offsets when every array of the job stays below 4 GB: an observation row is at most 4 (3 * 16 + 2) = 200 bytes per agent,
+// the widest state rows are the exact-path step ring's (12 x 16 bytes per agent, allocated but all but never touched).
 inline bool narrow_offsets_ok(int64_t E, int n, uint32_t flags) {
     return !(flags & BSX_F_WIDE_OFFSETS) && uint64_t(E) * uint64_t(2 * n) * 200ull <= 0xFFFFFFFFull;
 }
