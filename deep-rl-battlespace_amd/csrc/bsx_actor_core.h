@@ -154,7 +154,12 @@ __device__ inline float4 finish_row(float4 r4, const float4 b3, const BsxActorNo
 // 2^-16 -- wh*xh, wh*xm, wm*xh, wh*xl, wm*xm, wl*xh, added smallest first; what is dropped is below 2^-24 relative, the size of a
 // float32 rounding -- 48 matrix instructions of 32 cycles: float32-class accuracy (not the fmaf chain's bits) at 2.7x the f32 MFMA rate.
 // Layer 1 (K = 6) and everything else stay f32 in every mode.
-template <int PREC, class XB>
+// ROLL: the 64 x 64 layer's operands as a ROLLING window instead of all at once -- the first groups are requested behind layer 1's
+// loads, group g + AHEAD right before group g is multiplied (f32: a group = the eight registers of four K steps, 8 MFMAs = 512
+// cycles, AHEAD = 3; bf16: a group = one K step's terms for both output tiles, AHEAD = 2), so that at most AHEAD + 1 groups are
+// live: 32 / 48 weight registers instead of 64.  Same loads in the same (K) order, same arithmetic; it is what lets the fused
+// 2v2 ... 4v4 rollout kernels (bsx_kernels.hip), which carry a game's state across the actor, fit 256 registers without scratch.
+template <int PREC, bool ROLL = false, class XB>
 __device__ inline float4 tile_forward(const float* __restrict__ W, const float* __restrict__ sm_agent, int D, int lane, XB xb) {
 #pragma clang fp contract(fast)
     constexpr bool BF = PREC != BSX_ACTOR_F32;
@@ -175,24 +180,26 @@ __device__ inline float4 tile_forward(const float* __restrict__ W, const float* 
     }
     // The 64 x 64 layer's operands are fetched HERE, behind layer 1's own loads: vmcnt counts in order, so any load issued
     // after these would have to wait for all 16 KB of them; the LayerNorm below (~1 k cycles of VALU) covers their latency.
-    float4 w2[2][2][4];                        // f32: [mo][mt][vq] x 4 k-steps
-    float4 wb[2][4][NT];                       // bf16 modes: [mo][s][term] x 8 bf16
+    constexpr int W2AHEAD = ROLL ? 3 : 8, WBAHEAD = ROLL ? 2 : 4;
+    float4 w2[8][2];                           // f32: [group g = mt * 4 + vq][mo] x 4 k-steps
+    float4 wb[4][2][NT];                       // bf16 modes: [s][mo][term] x 8 bf16
+    auto load_w2 = [&](int g) {
+        w2[g][0] = reinterpret_cast<const float4*>(W + off_w2(D))[((0 * 2 + (g >> 2)) * 4 + (g & 3)) * 64 + lane];
+        w2[g][1] = reinterpret_cast<const float4*>(W + off_w2(D))[((1 * 2 + (g >> 2)) * 4 + (g & 3)) * 64 + lane];
+    };
+    auto load_wb = [&](int s) {
+#pragma unroll
+        for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                wb[s][mo][t] = reinterpret_cast<const float4*>(W + off_w2b(D))[((mo * 4 + s) * 3 + t) * 64 + lane];
+    };
     if constexpr (!BF) {
 #pragma unroll
-        for (int mo = 0; mo < 2; ++mo)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int vq = 0; vq < 4; ++vq)
-                    w2[mo][mt][vq] = reinterpret_cast<const float4*>(W + off_w2(D))[((mo * 2 + mt) * 4 + vq) * 64 + lane];
+        for (int g = 0; g < (W2AHEAD < 8 ? W2AHEAD : 8); ++g) load_w2(g);
     } else {
 #pragma unroll
-        for (int mo = 0; mo < 2; ++mo)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    wb[mo][s][t] = reinterpret_cast<const float4*>(W + off_w2b(D))[((mo * 4 + s) * 3 + t) * 64 + lane];
+        for (int s = 0; s < (WBAHEAD < 4 ? WBAHEAD : 4); ++s) load_wb(s);
     }
     ln_relu_tile(acc1[0], acc1[1], sm + 1 * H, sm + 2 * H);
     f32x16 acc2[2];
@@ -203,6 +210,9 @@ __device__ inline float4 tile_forward(const float* __restrict__ W, const float* 
     if constexpr (BF) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {          // K step s = accumulator registers 8*(s&1) .. +7 of layer-1 tile s>>1
+            if constexpr (ROLL) {
+                if (s + WBAHEAD < 4) load_wb(s + WBAHEAD);
+            }
             bf16x8 xh, xm, xl;                 // two-term mode: xm is the low term, xl unused
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -215,10 +225,10 @@ __device__ inline float4 tile_forward(const float* __restrict__ W, const float* 
             }
 #pragma unroll
             for (int mo = 0; mo < 2; ++mo) {
-                const bf16x8 wh = __builtin_bit_cast(bf16x8, wb[mo][s][0]);
-                const bf16x8 wm = __builtin_bit_cast(bf16x8, wb[mo][s][1]);
+                const bf16x8 wh = __builtin_bit_cast(bf16x8, wb[s][mo][0]);
+                const bf16x8 wm = __builtin_bit_cast(bf16x8, wb[s][mo][1]);
                 if constexpr (PREC == BSX_ACTOR_BF16X6) {
-                    const bf16x8 wl = __builtin_bit_cast(bf16x8, wb[mo][s][NT - 1]);
+                    const bf16x8 wl = __builtin_bit_cast(bf16x8, wb[s][mo][NT - 1]);
                     acc2[mo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc2[mo], 0, 0, 0);
                     acc2[mo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xm, acc2[mo], 0, 0, 0);
                     acc2[mo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc2[mo], 0, 0, 0);
@@ -230,15 +240,21 @@ __device__ inline float4 tile_forward(const float* __restrict__ W, const float* 
         }
     } else {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int g = 0; g < 8; ++g) {          // K order: mt = g >> 2, accumulator registers 4 (g & 3) .. + 3 of layer 1's tile mt
+            if constexpr (ROLL) {
+                if (g + W2AHEAD < 8) load_w2(g + W2AHEAD);
+                __builtin_amdgcn_sched_barrier(0);   // (the window is the point: the scheduler must not pull the later loads up to the first)
+            }
+            const float4 q0 = w2[g][0], q1 = w2[g][1];
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const float4 q0 = w2[0][mt][v >> 2], q1 = w2[1][mt][v >> 2];
-                const float wa0 = (v & 3) == 0 ? q0.x : ((v & 3) == 1 ? q0.y : ((v & 3) == 2 ? q0.z : q0.w));
-                const float wa1 = (v & 3) == 0 ? q1.x : ((v & 3) == 1 ? q1.y : ((v & 3) == 2 ? q1.z : q1.w));
+            for (int t = 0; t < 4; ++t) {
+                const int mt = g >> 2, v = 4 * (g & 3) + t;
+                const float wa0 = t == 0 ? q0.x : (t == 1 ? q0.y : (t == 2 ? q0.z : q0.w));
+                const float wa1 = t == 0 ? q1.x : (t == 1 ? q1.y : (t == 2 ? q1.z : q1.w));
                 acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa0, acc1[mt][v], acc2[0], 0, 0, 0);
                 acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa1, acc1[mt][v], acc2[1], 0, 0, 0);
             }
+        }
     }
     ln_relu_tile(acc2[0], acc2[1], sm + 4 * H, sm + 5 * H);
     const float4* w3 = reinterpret_cast<const float4*>(sm_agent + 6 * H) + hh * 32;   // [hh][mt][v] float4

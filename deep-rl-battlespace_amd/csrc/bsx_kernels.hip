@@ -370,6 +370,18 @@ __host__ __device__ constexpr int group_width(int n) {
     return g;
 }
 
+// np.argmax over four scores (battle_env.py:327-328): the first maximum; a NaN compares as the maximum.  The running maximum is a
+// register, not v[arg]: a dynamically indexed local array lives in scratch memory.
+__device__ inline int argmax4(float a, float b, float c, float d) {
+    int am = 0;
+    float best = a;
+    const float v[3] = {b, c, d};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (!(best != best) && (v[i] > best || v[i] != v[i])) { am = i + 1; best = v[i]; }
+    return am;
+}
+
 struct StepArgs {
     StatePtrs st;
     int64_t E; int n;
@@ -542,7 +554,6 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     const int tid = (WAVES > 1) ? int(threadIdx.x & 63) : int(threadIdx.x);   // position in my wave = LDS index in its private arrays
     const ixs_t wblk = (WAVES > 1) ? ixs_t(blockIdx.x) * WAVES + wave : ixs_t(blockIdx.x);   // which 64 lanes of the job I am
     const int a = tid & (G - 1);
-    const int gl = tid & ~(G - 1);                       // first thread of my env's group
     const ixs_t e = wblk * EPB + (tid / G);
     const bool env_ok = e < ixs_t(E_);
     const bool valid = env_ok && a < A;
@@ -550,9 +561,6 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // out-of-range lanes read a valid row (the last one) and never store: loads stay unconditional
     const ixs_t ec = env_ok ? e : ixs_t(E_ - 1);
     const ix_t g = ix_t(ec) * A + (a < A ? a : A - 1);
-    const int lane = tid;
-    const int team = (a < n) ? 0 : 1;                    // 0 red, 1 blue
-    const int eb = gl + (team == 0 ? n : 0);             // first enemy lane (thread index)
     constexpr int NE = (N > 0) ? N : 1;                  // compile-time enemy count (runtime-n build reads LDS in loops)
 
     // LDS is private to this wavefront: accesses are volatile (program order) and the hardware runs one wave's LDS
@@ -666,13 +674,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         if (has_act) {                                   // uniform branch
             if (!CONT) {
                 if constexpr (!LG) d.act = r.ai;
-                else {   // np.argmax: first maximum; a NaN compares as the maximum
-                    const float v[4] = {r.lg.x, r.lg.y, r.lg.z, r.lg.w};
-                    d.act = 0;
-#pragma unroll
-                    for (int i = 1; i < 4; ++i)
-                        if (!(v[d.act] != v[d.act]) && (v[i] > v[d.act] || v[i] != v[i])) d.act = i;
-                }
+                else d.act = argmax4(r.lg.x, r.lg.y, r.lg.z, r.lg.w);
             } else if (kind_ == BSX_ACT_F32 || kind_ == BSX_ACT_F32X4) {
                 d.a0 = double(r.f0); d.a1 = double(r.f1); d.a2 = double(r.f2);
             } else {
@@ -720,6 +722,15 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         asm volatile("" : "+s"(EAt));
         asm volatile("" : "+s"(seed_t));
     }
+    // The fused rollout of teams >= 2 runs at 256 registers: there the lane's indices pass through an empty asm per tick as well, so
+    // that the ~35 LDS / row addresses derived from them (pair slots, enemy lanes, staging rows) are per-tick work next to their use
+    // instead of registers held across the actor's matrix products -- with them hoisted the kernels spilled to scratch memory.
+    int tid_k = tid;
+    if constexpr (ACTOR && N > 1) asm volatile("" : "+v"(tid_k));
+    const int tid = tid_k, lane = tid, a = tid & (G - 1);
+    const int gl = tid & ~(G - 1);                       // first thread of my env's group
+    const int team = (a < n) ? 0 : 1;                    // 0 red, 1 blue
+    const int eb = gl + (team == 0 ? n : 0);             // first enemy lane (thread index)
     const double* const u_t = (MULTI && p.u) ? p.u + int64_t(tk) * p.u_ts : p.u;
     float* const obs_t = MULTI ? p.obs + int64_t(tk) * p.obs_ts : p.obs;
     float* const rew_t = MULTI ? p.rew + int64_t(tk) * p.rew_ts : p.rew;
@@ -765,9 +776,10 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
             const float* const smn = s_small + ag * bsx_actor::SMALL;
             auto xb = [&](int k) { return k < D ? s_obs_all[(c * G_ + ag) * D + k] : 0.f; };
             float4 o;                                    // uniform branches
-            if (p.aprec == BSX_ACTOR_BF16X3) o = bsx_actor::tile_forward<BSX_ACTOR_BF16X3>(Wn, smn, D, lane, xb);
-            else if (N == 1 && p.aprec == BSX_ACTOR_BF16X6) o = bsx_actor::tile_forward<(N == 1 ? BSX_ACTOR_BF16X6 : BSX_ACTOR_F32)>(Wn, smn, D, lane, xb);   // 1v1 only: 96 weight registers
-            else o = bsx_actor::tile_forward<BSX_ACTOR_F32>(Wn, smn, D, lane, xb);
+            constexpr bool ROLL = N > 1;             // teams >= 2 carry more state across the actor: the 64 x 64 layer's weights as a rolling window
+            if (p.aprec == BSX_ACTOR_BF16X3) o = bsx_actor::tile_forward<BSX_ACTOR_BF16X3, ROLL>(Wn, smn, D, lane, xb);
+            else if (N == 1 && p.aprec == BSX_ACTOR_BF16X6) o = bsx_actor::tile_forward<(N == 1 ? BSX_ACTOR_BF16X6 : BSX_ACTOR_F32), ROLL>(Wn, smn, D, lane, xb);   // 1v1 only: 96 weight registers
+            else o = bsx_actor::tile_forward<BSX_ACTOR_F32, ROLL>(Wn, smn, D, lane, xb);
             if (hh == ti) r4 = o;                        // lower half finishes the wave's first tile, upper half the second
         }
         const float4 b3 = *reinterpret_cast<const float4*>(s_small + mine_c * bsx_actor::SMALL + 6 * bsx_actor::H + bsx_actor::H * bsx_actor::NA);
@@ -788,11 +800,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         }
         if (row_ok) reinterpret_cast<float4*>(p.scores + int64_t(tk) * p.scores_ts)[row] = r4;
         if constexpr (!CONT) {
-            const float v[4] = {r4.x, r4.y, r4.z, r4.w};
-            int am = 0;
-#pragma unroll
-            for (int i = 1; i < 4; ++i)
-                if (!(v[am] != v[am]) && (v[i] > v[am] || v[i] != v[i])) am = i;
+            const int am = argmax4(r4.x, r4.y, r4.z, r4.w);
             if (WAVES > 1) {                             // plane (game, id) sits in lane game*G + id of the workgroup
                 if (has_row) s_act_all[c * G_ + mine] = am;
                 __syncthreads();
