@@ -716,8 +716,45 @@ def rollout_lines(dev, E, K):
         except Exception as exc:                            # a variant this build does not offer is reported, not hidden
             out[tag] = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
         torch.cuda.empty_cache()
+    try:
+        out["reference evaluation workload (evaluate.py:32-76): 2v2, shipped checkpoints vs scripted instinct team"] = evaluation_line(dev, E)
+    except Exception as exc:
+        out["reference evaluation workload (evaluate.py:32-76): 2v2, shipped checkpoints vs scripted instinct team"] = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
     return {"workload": f"BASELINE.json configs[4]: {E} games x 1v1 + on-device actor per plane (obs 5 -> 64 -> LayerNorm -> 64 -> LayerNorm -> 4, "
                         "maddpg/networks.py:54-85), end to end", "variants": out}
+
+
+def evaluation_line(dev, E):
+    """The reference's own evaluation workload on this path: 2v2, reward config models/completed_model/cf.json, red = the shipped
+    checkpoints actor_plane0 / actor_plane1 (weights recorded in tests/golden/g12_evaluation.npz: data, not code) with
+    Ornstein-Uhlenbeck noise 0.1 that is never restarted, blue = the scripted instinct team in-kernel, one launch per 32 ticks;
+    the red win rate beside the tally the unmodified evaluate.main() produced in the build container and README.md:30's figure."""
+    import numpy as np
+    import torch
+    import deep_rl_battlespace_amd as bsx
+    from deep_rl_battlespace_amd.rollout import play_reference_evaluation, reference_checkpoint_actor
+    g12 = np.load(os.path.join(ROOT, "tests", "golden", "g12_evaluation.npz"))
+    cf = dict(zip(("hit_base_reward", "hit_plane_reward", "miss_punishment", "die_punishment", "lose_punishment"), (float(v) for v in g12["cf"])))
+    n = int(g12["n_agents"])
+    actor = reference_checkpoint_actor(g12, n, device=dev)
+    env = bsx.parallel_env(n_agents=n, n_envs=E, auto_reset=True, seed=1234, device=dev, **cf)
+    res = play_reference_evaluation(env, actor, games=3 * E, T=32, one_launch=True, seed=12)      # ~3 games per slot: past the start-up transient
+    ro = res.pop("rollout")
+    torch.cuda.synchronize(dev)
+    samples = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(8):
+            ro.run()
+        torch.cuda.synchronize(dev)
+        samples.append((time.perf_counter() - t0) / (8 * 32))
+    dt = statistics.median(samples)
+    ref = {k: int(g12[k]) for k in ("games", "ties", "red_wins", "blue_wins")}
+    return {**res, "agent_steps_per_s": round(E * 2 * n / dt, 1), "us_per_tick": round(dt * 1e6, 3), "games_per_s": round(res["games"] / (res["ticks"] * dt), 1),
+            "envs": E, "n_agents_per_team": n, "ticks_per_launch": 32,
+            "reference_tally_evaluate_py": {**ref, "win_rate_red": round(ref["red_wins"] / ref["games"], 4),
+                                            "source": "tests/golden/g12_evaluation.npz: evaluate.main() unmodified, run in the build container"},
+            "published_win_rate": "~80% (README.md:30)"}
 
 
 if __name__ == "__main__":

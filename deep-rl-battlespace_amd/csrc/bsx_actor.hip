@@ -183,7 +183,7 @@ int bsx_actor_forward(const float* weights, const float* obs, float* scores, int
     if (!weights || !obs || !scores || E <= 0 || E > BSX_MAX_E || n < 1 || n > BSX_MAX_N) return BSX_E_ARG;
     if (precision != BSX_ACTOR_F32 && precision != BSX_ACTOR_BF16X3 && precision != BSX_ACTOR_BF16X6) return BSX_E_ARG;
     if (!aligned(weights, 16) || !aligned(scores, 16) || !aligned(obs, 4)) return BSX_E_ALIGN;
-    BsxActorNoise nz = {0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr};
+    BsxActorNoise nz = {0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr, 0};
     if (noise) nz = *noise;
     if (nz.ou_scale > 0.f && (!nz.ou_state || !aligned(nz.ou_state, 16))) return nz.ou_state ? BSX_E_ALIGN : BSX_E_ARG;
     if (nz.z_inject && !aligned(nz.z_inject, 16)) return BSX_E_ALIGN;

@@ -790,6 +790,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         bool game_over;
         if (WAVES > 1) game_over = s_gdone_all[c] != 0;
         else game_over = __shfl(er.done, 2 * c) != 0;
+        if (p.nz.ou_keep) game_over = false;             // the evaluation loop never restarts its noise process (evaluate.py:52-76)
         bool scripted_row = false;
         if constexpr (!CONT) scripted_row = p.scripted_team == (mine_c >= N ? 1 : 0);
         if (scripted_row) {                              // instinct/team.py:13-15 for this team's rows, as one-hot score rows
@@ -1690,7 +1691,7 @@ int launch_step(void* state, int64_t E, int n, const void* actions, int action_k
     a.obs = obs; a.rew = rew; a.done = done; a.env_done = env_done; a.winner = winner; a.env_done_t = env_done_t;
     a.cfg = *cfg; a.flags = flags; a.seed = seed; a.env_offset = env_offset; a.tie_tick = bsx_tie_tick(n);
     const int64_t EA = E * 2 * n;
-    a.aw = nullptr; a.aprec = 0; a.scripted_team = -1; a.obs0 = nullptr; a.scores = nullptr; a.scores_ts = 0; a.nz = BsxActorNoise{0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr};
+    a.aw = nullptr; a.aprec = 0; a.scripted_team = -1; a.obs0 = nullptr; a.scores = nullptr; a.scores_ts = 0; a.nz = BsxActorNoise{0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr, 0};
     a.aseed = 0; a.aseq = 0; a.aseq_base = nullptr;
     a.T = T;
     a.act_tb = EA * (CONT ? (action_kind == BSX_ACT_F32 ? 12 : (action_kind == BSX_ACT_F64 ? 24 : 16)) : (action_kind == BSX_ACT_I32 ? 4 : 16));
@@ -1824,7 +1825,7 @@ int launch_rollout(void* state, int64_t E, int n, int T, const float* weights, i
         scripted_team < -1 || scripted_team > 1) return BSX_E_ARG;
     if (CONT && scripted_team != -1) return BSX_E_ARG;
     if (!aligned(state, 256) || !aligned(weights, 16) || !aligned(scores, 16) || !aligned(obs, 4) || !aligned(rew, 4)) return BSX_E_ALIGN;
-    BsxActorNoise nz = {0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr};
+    BsxActorNoise nz = {0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr, 0};
     if (noise) nz = *noise;
     if (nz.ou_scale > 0.f && (!nz.ou_state || !aligned(nz.ou_state, 16))) return nz.ou_state ? BSX_E_ALIGN : BSX_E_ARG;
     if (nz.z_inject) return BSX_E_ARG;                   // injected normals are per call: bsx_actor_forward only

@@ -156,7 +156,7 @@ class FusedActor:
         normals to use instead of the in-kernel draws (parity runs against the reference's np.random.randn values)."""
         if not (noise_std > 0.0 or ou is not None):
             return None
-        nz = _lib.BsxActorNoise(float(noise_std), 0.0, 0.15, 0.2, 0.0, None, None, None)
+        nz = _lib.BsxActorNoise(float(noise_std), 0.0, 0.15, 0.2, 0.0, None, None, None, 0)
         if z is not None:
             if z.dtype != torch.float32 or tuple(z.shape) != (E, 2 * self.n, 4) or not z.is_contiguous():
                 raise ValueError("z must be a contiguous float32 [E, A, 4] tensor")
@@ -169,6 +169,7 @@ class FusedActor:
             nz.ou_sigma, nz.ou_mu = float(ou.get("sigma", 0.2)), float(ou.get("mu", 0.0))
             nz.ou_state = st.data_ptr()
             nz.env_done = ou["env_done"].data_ptr() if ou.get("env_done") is not None else None
+            nz.ou_keep = 0 if ou.get("restart", True) else 1
         return nz
 
     def forward_into(self, obs, scores, noise_std=0.0, seq=None, seq_base=None, ou=None, z=None):
@@ -210,7 +211,7 @@ class PolicyRollout:
     kernel and restarted per game; then clamp(-1, 1) as maddpg/agent.py:31 does."""
 
     def __init__(self, env, actor, T, noise_std=0.0, fused=True, seed=0, opponent=None, ou_scale=0.0, one_launch=False,
-                 precision="f32"):
+                 precision="f32", ou_restart=True):
         """actor: a StackedActor.  fused=True evaluates it with the hand-written HIP kernel (FusedActor), False with
         torch ops (the fp32 reference of the same op).  opponent: an `instinct.Team` that plays its team's planes
         instead of the actor (the reference's training setup, main.py:119-122: learned red vs scripted blue): its
@@ -231,7 +232,9 @@ class PolicyRollout:
         if ou_scale > 0.0:
             if not fused:
                 raise ValueError("ou_scale needs the fused actor")
-            self.ou = dict(scale=float(ou_scale),
+            # ou_restart=False: the process is never restarted -- the reference's evaluation loop (evaluate.py:52-76) never calls
+            # reset_noise, whereas training restarts it at every game start (main.py:155)
+            self.ou = dict(scale=float(ou_scale), restart=bool(ou_restart),
                            state=torch.zeros((env.n_envs, env._A, 4), dtype=torch.float32, device=env.device))
         # one_launch: all T ticks (actor -> step) in ONE kernel (bsx_rollout_discrete / _continuous) instead of 2T launches in a
         # graph: observation rows stay in LDS between the step and the actor, game state in registers / L2.  Up to 4v4; discrete: a
@@ -264,7 +267,7 @@ class PolicyRollout:
         if self.fused is not None:
             # graph arguments are frozen: the noise key is (seed, seq_base + t, row) with seq_base a device word that the
             # graph advances by T once per replay (_body)
-            ou = dict(self.ou, env_done=self.env_done[t]) if self.ou is not None else None
+            ou = dict(self.ou, env_done=self.env_done[t] if self.ou["restart"] else None) if self.ou is not None else None
             self.fused.forward_into(self.obs[t], self.scores[t], self.noise_std, seq=t, seq_base=self._seq_base, ou=ou)
             if self.opponent is not None:
                 self.opponent.write_actions(out=self.scores[t], obs=self.obs[t])
@@ -323,3 +326,47 @@ class PolicyRollout:
             self._body()
         else:
             self.graph.replay()
+
+
+def reference_checkpoint_actor(fixture, n_agents_per_team=2, device="cuda"):
+    """StackedActor holding the reference's SHIPPED policy (models/completed_model/actor_plane0, actor_plane1: 8 -> 64 -> 64 -> 4,
+    trained for 217 651 games) in its red slots, read from a recorded copy of the two state_dicts (tests/golden/g12_evaluation.npz,
+    written by make_golden.py from the checkpoint files: arrays `plane{i}/fc1.weight` ...).  The blue slots repeat plane 0 / 1: in the
+    evaluation workload blue is the scripted opponent and those slots are never evaluated."""
+    import numpy as np
+    z = np.load(fixture) if isinstance(fixture, str) else fixture
+    n = int(n_agents_per_team)
+    actor = StackedActor(2 * n, 3 * n + 2, 4, device=device)
+    for slot in range(2 * n):
+        src = slot % n
+        sd = {k.split("/", 1)[1]: torch.from_numpy(np.asarray(z[k])).to(device) for k in z.files
+              if k.startswith(f"plane{src}/") and k.split("/", 1)[1] not in ("x", "y")}
+        actor.load_reference_actor(slot, sd)
+    return actor
+
+
+def play_reference_evaluation(env, actor, games, T=32, one_launch=True, precision="f32", seed=0, ou_scale=0.1):
+    """The reference's evaluation workload (evaluate.py:32-76; README.md:30 quotes "~80 %" for it) for every game slot of `env` at
+    once: red = `actor` through maddpg/agent.py:25-33 -- tanh scores + Ornstein-Uhlenbeck noise of scale 0.1 (utils/noise.py's
+    default, which evaluate.py never rescales) that is NEVER restarted (evaluate.py never calls reset_noise) -> clamp -> arg-max --,
+    blue = the scripted instinct.Team, finished games re-spawned in place.  Plays whole rollouts of T ticks until at least `games`
+    games are over and returns the tally from the env's own counters (battle_env.py:102-103,169-170,449-455).
+    One difference to the script is kept out on purpose: evaluate.py resets the env twice per game and feeds the FIRST reset's
+    observations to the first tick (evaluate.py:53-66), i.e. one action in ~100 is chosen on another game's spawn."""
+    from . import instinct
+    if env.n_envs < 1 or not env.auto_reset or env.continuous_actions:
+        raise ValueError("the evaluation workload needs a batched discrete env with auto_reset=True")
+    opp = instinct.Team(env.possible_blue, env.possible_red, env)
+    ro = PolicyRollout(env, actor, T, opponent=opp, ou_scale=ou_scale, ou_restart=False, one_launch=one_launch, precision=precision, seed=seed)
+    c0 = env.counters().sum(0)
+    env.reset()
+    ro.start(); ro.capture()
+    ticks = 0
+    while True:
+        ro.run()
+        ticks += T
+        c = env.counters().sum(0) - c0
+        if c[0] >= games:
+            break
+    return {"games": int(c[0]), "ties": int(c[1]), "red_wins": int(c[2]), "blue_wins": int(c[3]), "win_rate_red": float(c[2]) / float(c[0]),
+            "ticks": ticks, "rollout": ro}

@@ -172,6 +172,9 @@ typedef struct BsxActorNoise {
     const uint8_t* env_done;  /* nullable uint8[E]: rows of finished games restart from ou_mu (main.py:155 reset_noise per game) */
     const float* z_inject;    /* nullable float32[E*A*4], 16-byte aligned: standard normals to use instead of the Philox draws
                                  (bsx_actor_forward only; one set per call, used by the OU and the Gaussian term alike) */
+    int ou_keep;              /* bsx_rollout_*: 0 = the process restarts from ou_mu at every game start, as the training loop does
+                                 (main.py:155 reset_noise per game); 1 = it never restarts -- the reference's evaluation loop
+                                 (evaluate.py:52-76) never calls reset_noise.  bsx_actor_forward restarts exactly where env_done says. */
 } BsxActorNoise;
 /* precision of the 64 x 64 layer: exact float32 (an fmaf chain, bit for bit), or both operands split in two bf16 terms and
  * three bf16 matrix products accumulated in float32 (about 1e-5 on a score; 16x the matrix rate).  All else is float32. */

@@ -697,12 +697,91 @@ def learner_side_fixture():
     print("g11_ou_noise:", np.stack(vals).shape, "last", vals[-1])
 
 
+def evaluation_fixture(games):
+    """G12: the reference's own evaluation workload (evaluate.py:14-109; README.md:30 publishes "~80 %" for it): 2v2 with the shipped
+    reward config models/completed_model/cf.json, red = the shipped checkpoints actor_plane0 / actor_plane1 through
+    maddpg.Team.load_models + NetworkedAgent.choose_action (OU noise, scale 0.1, never restarted), blue = instinct.Team.
+    evaluate.main() is run UNMODIFIED; what is injected are names around it: input() answers the model-name prompt, the module
+    sees a `range` that plays `games` games instead of 10 000 and none of the 10 recorded ones (those need a display), torch.load
+    maps the checkpoints to the CPU, and a subclass of the reference env counts calls -- main() keeps its win tally in a local
+    dict and never prints it, so the tally is read from the env's own counters (battle_env.py:102-103,169-170) afterwards.
+    Recorded: the two actors' weights, their forward outputs on 96 observation rows seen in play, cf.json, and the tally."""
+    import builtins
+    import torch
+    os.chdir(REF)
+    sys.path[:0] = [os.path.join(HERE, "standins"), REF]
+    import evaluate as ev                                   # imports envs.battle_env, instinct.team, maddpg.team as they lie
+    import maddpg.networks as nets
+    random.seed(12); np.random.seed(12); torch.manual_seed(12)
+    created, seen_obs, lens = [], [], []
+
+    class CountingEnv(ev.battle_env.parallel_env):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.calls_this_game, created[:] = 0, [self]
+
+        def reset(self, *a, **k):
+            if self.calls_this_game:
+                lens.append(self.calls_this_game)
+            self.calls_this_game = 0
+            return super().reset(*a, **k)
+
+        def step(self, actions):
+            out = super().step(actions)
+            self.calls_this_game += 1
+            if len(seen_obs) < 96 and self.calls_this_game % 7 == 3:
+                seen_obs.append(np.stack([out[0][a] for a in self.possible_red]))
+            return out
+
+    real_input, real_load, real_cls = builtins.input, torch.load, ev.battle_env.parallel_env
+    builtins.input = lambda prompt="": "completed_model"
+    torch.load = lambda f, *a, **k: real_load(f, *a, **{**k, "map_location": "cpu"})
+    ev.battle_env.parallel_env = CountingEnv
+    ev.range = lambda n: builtins.range(games if n == 10000 else 0)
+    try:
+        try:
+            ev.main()
+        except AttributeError as exc:                     # evaluate.py:109 calls env.stop_recording(), which the env does not have
+            assert "stop_recording" in str(exc), exc
+    finally:
+        builtins.input, torch.load, ev.battle_env.parallel_env = real_input, real_load, real_cls
+        del ev.range
+    env = created[0]
+    lens.append(env.calls_this_game)
+    cf = json.load(open(os.path.join(REF, "models/completed_model/cf.json")))
+    out = {"games": np.int64(env.total_games), "ties": np.int64(env.ties), "red_wins": np.int64(env.team["red"]["wins"]),
+           "blue_wins": np.int64(env.team["blue"]["wins"]), "calls_per_game": np.asarray(lens[-games:], np.int32),
+           "cf": np.asarray([cf[k] for k in ("hit_base_reward", "hit_plane_reward", "miss_punishment", "die_punishment", "lose_punishment")], np.float64),
+           "n_agents": np.int64(cf["n_agents"])}
+    x = torch.tensor(np.stack(seen_obs)[:96])              # [rows, 2, 8]: red plane0 / plane1 observations met in play
+    for i in range(2):
+        net = nets.ActorNetwork(8, 4, 64, 64, 0.001, os.path.join(REF, "models/completed_model"), f"actor_plane{i}").to("cpu")
+        net.load_checkpoint()
+        net.eval()
+        with torch.no_grad():
+            y = net.forward(x[:, i])
+        for k, v in net.state_dict().items():
+            out[f"plane{i}/{k}"] = v.numpy()
+        out[f"plane{i}/x"], out[f"plane{i}/y"] = x[:, i].numpy(), y.numpy()
+    out["meta"] = np.asarray(json.dumps({"source": "evaluate.py main() unmodified, %d games" % games, "seed": 12,
+                                         "win_rate_red": float(out["red_wins"]) / float(out["games"])}))
+    np.savez_compressed(os.path.join(HERE, "g12_evaluation.npz"), **out)
+    print("g12_evaluation:", {k: int(out[k]) for k in ("games", "ties", "red_wins", "blue_wins")}, "mean calls per game", float(np.mean(lens)))
+
+
 if __name__ == "__main__":
     if "--actor-only" in sys.argv:
         actor_fixture()
         sys.exit(0)
     if "--learner-side-only" in sys.argv:
         learner_side_fixture()
+        sys.exit(0)
+    if "--evaluation-only" in sys.argv:                    # python tests/golden/make_golden.py --evaluation-only [games]
+        cwd = os.getcwd()
+        try:
+            evaluation_fixture(int(sys.argv[sys.argv.index("--evaluation-only") + 1]) if sys.argv[-1].isdigit() else 2000)
+        finally:
+            os.chdir(cwd)
         sys.exit(0)
     cwd = os.getcwd()
     try:

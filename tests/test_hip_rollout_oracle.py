@@ -91,6 +91,67 @@ def test_closed_loop_reference_actor_rollout_vs_c_oracle(one_launch):
     assert torch.equal(got.argmax(-1)[clear], want.argmax(-1)[clear])
 
 
+@pytest.mark.parametrize("one_launch", [True, False])
+def test_reference_evaluation_workload_vs_c_oracle(one_launch):
+    """The reference's OWN evaluation workload (evaluate.py:32-76; README.md:30: the trained team wins "~80 %") on this path,
+    closed against the oracle: 2v2, the shipped reward config cf.json (float rewards), red = the shipped checkpoints
+    actor_plane0 / actor_plane1 (fixture g12 holds their weights) through the MFMA actor with Ornstein-Uhlenbeck noise of scale 0.1
+    that is never restarted, blue = the scripted instinct opponent played in-kernel (one launch per 32 ticks) or by its own
+    kernel (graph form).  Beside it the C oracle plays the SAME games from the same score vectors' arg-max: rewards, dones, game
+    flags and the full state identical after every run, observations within 1e-5.  Then the tally: the device's red win rate
+    against the one the unmodified evaluate.main() produced here (g12) and against the published figure."""
+    from deep_rl_battlespace_amd.rollout import FusedActor, play_reference_evaluation, reference_checkpoint_actor
+    g12 = np.load(os.path.join(GOLD, "g12_evaluation.npz"))
+    n, E, T = int(g12["n_agents"]), 16384, 32
+    cf = dict(zip(("hit_base_reward", "hit_plane_reward", "miss_punishment", "die_punishment", "lose_punishment"), (float(v) for v in g12["cf"])))
+    actor = reference_checkpoint_actor(g12, n)
+    # the stacked module and the MFMA kernel ARE the reference ActorNetwork.forward of the checkpoints, on rows met in the reference's own play
+    x = torch.stack([torch.from_numpy(g12[f"plane{i % n}/x"]) for i in range(2 * n)], 1).cuda().contiguous()     # [rows, A, 8]
+    want = torch.stack([torch.from_numpy(g12[f"plane{i % n}/y"]) for i in range(2 * n)], 1).cuda()
+    # (float32, different summation orders; the trained weights are larger than g9's fresh ones: 5e-5 on a tanh output)
+    with torch.no_grad():
+        torch.testing.assert_close(actor(x), want, rtol=0, atol=5e-5)
+    torch.testing.assert_close(FusedActor(actor, n)(x), want, rtol=0, atol=5e-5)
+    clear = (want.topk(2, -1).values[..., 0] - want.topk(2, -1).values[..., 1]) > 2e-4
+    assert torch.equal(FusedActor(actor, n)(x).argmax(-1)[clear], want.argmax(-1)[clear]) and float(clear.float().mean()) > 0.8   # (the trained policy saturates: some rows tie at tanh = 1)
+    env = _env(n_agents=n, n_envs=E, seed=212, auto_reset=True, **cf)
+    c = cref.CRefBatch(E, n_agents=n, seed=212, auto_reset=True, **cf)
+    res = play_reference_evaluation(env, actor, games=1, T=T, one_launch=one_launch, seed=12)        # one rollout: sets everything up
+    ro = res["rollout"]
+    o_c = c.reset()
+    np.testing.assert_allclose(ro.obs[0].cpu().numpy(), o_c, rtol=OBS_RTOL, atol=OBS_ATOL)
+    blue = slice(n, 2 * n)
+
+    def check_run(run):
+        torch.cuda.synchronize()
+        obs, sc, rew, done, edone = (v.cpu().numpy() for v in (ro.obs, ro.scores, ro.rew, ro._done, ro.env_done))
+        assert set(np.unique(sc[:, :, blue])) <= {-1.0, 1.0}                # the scripted side's rows are one-hot (instinct/agent.py:56-62)
+        for t in range(T):
+            assert np.array_equal(edone[t], c.env_done), (run, t)
+            co, cr, cd = c.step(sc[t])                                     # arg-max of the score rows (battle_env.py:327-328)
+            assert np.array_equal(done[t].astype(bool), cd), (run, t)
+            np.testing.assert_allclose(rew[t], cr, rtol=1e-6, atol=1e-6, err_msg=f"run {run} tick {t}")
+            np.testing.assert_allclose(obs[t + 1], co, rtol=OBS_RTOL, atol=OBS_ATOL, err_msg=f"run {run} tick {t}")
+        sh = {k: v.cpu().numpy() for k, v in env.export_state().items()}
+        scx = c.export_state()
+        for f in ("px", "py", "pdir", "php", "palive", "base_xy", "bhp", "tick", "env_done", "winner", "bl_live", "counters"):
+            assert np.array_equal(sh[f], scx[f]), (run, f)
+        return scx["counters"].sum(0)
+
+    cn = check_run(0)
+    for run in range(1, 7):                                                 # 224 ticks: every slot finishes a game (time limit: 141) and starts the next
+        ro.run()
+        cn = check_run(run)
+    assert cn[0] >= E and cn[0] == cn[1] + cn[2] + cn[3]
+    rate = cn[2] / cn[0]
+    ref_rate = float(g12["red_wins"]) / float(g12["games"])
+    print(f"evaluation workload: device {cn[0]} games, red wins {rate:.4f}; reference evaluate.main() {int(g12['games'])} games, {ref_rate:.4f}; README ~0.80")
+    # binomial spread of the reference's own sample (a few thousand games) dominates; 4 sigma of it, plus the device's
+    sigma = (ref_rate * (1 - ref_rate) * (1.0 / float(g12["games"]) + 1.0 / float(cn[0]))) ** 0.5
+    assert abs(rate - ref_rate) < 4 * sigma + 0.01, (rate, ref_rate, sigma)
+    assert 0.7 < rate < 0.9                                                 # README.md:30 "~80%"
+
+
 def test_ou_noise_reproduces_the_reference_trajectory():
     """g11: utils/noise.py OUNoise(4) run unmodified -- 40 noise() calls with the np.random.randn values it drew, a reset()
     (main.py:155) and a re-scale (main.py:154) on the way.  The in-kernel process (bsx_actor_forward) is fed the same normals
