@@ -69,6 +69,7 @@ SIGNATURES = {
     "bsx_export_state": (c_int, [c_void_p, c_int64, c_int, ctypes.POINTER(BsxExport), c_void_p]),
     "bsx_tie_tick": (c_int, [c_int]),
     "bsx_stream_synchronize": (c_int, [c_void_p]),
+    "bsx_host_device_pointer": (c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
     "bsx_selftest_atan2": (c_int, [c_int, c_void_p, c_void_p]),
     "bsx_instinct_discrete": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     "bsx_instinct_continuous": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_uint64, c_uint64, c_void_p, c_void_p]),

@@ -1721,6 +1721,11 @@ int bsx_build_flags(void) { return BUILD_FLAGS; }
 
 int bsx_stream_synchronize(void* stream) { return int(hipStreamSynchronize(static_cast<hipStream_t>(stream))); }
 
+int bsx_host_device_pointer(void* host, void** device) {
+    if (!host || !device) return BSX_E_ARG;
+    return int(hipHostGetDevicePointer(device, host, 0));
+}
+
 int bsx_tie_tick(int n) {
     // battle_env.py:168,316-319: total_time += 0.1 (binary64) until >= 10 + 2n
     const double max_time = double(10 + n * 2);

@@ -147,6 +147,10 @@ class parallel_env:
             raise ValueError("rng must be 'python' or 'philox'")
         if self.auto_reset and self.rng == "python":
             raise ValueError("auto_reset draws spawns in-kernel: use rng='philox'")
+        if self.auto_reset and self._compat:
+            # the drop-in surface mirrors `agents`, `dones`, `env_done` on the host by the reference's rules, in which a finished game
+            # stays finished until reset() (battle_env.py:303-306); an in-kernel re-spawn would leave those mirrors stale
+            raise ValueError("auto_reset needs a batched env (n_envs=...): the drop-in surface keeps the reference's reset() contract")
         self.tie_tick = int(self._lib.bsx_tie_tick(n))
 
         # ---- device buffers
@@ -166,6 +170,9 @@ class parallel_env:
         # raw pointers of the env-owned buffers (never re-allocated): one attribute read per call instead of a data_ptr() each
         self._p_state, self._p_obs, self._p_rew, self._p_done = (t.data_ptr() for t in (self._state, self._obs, self._rew, self._done))
         self._p_env_done, self._p_winner = self._env_done.data_ptr(), self._winner.data_ptr()
+        if self._compat:                                  # drop-in mode: the outputs live in pinned host memory; the kernels take its device address
+            cp = self._compat_dev_ptrs
+            self._p_obs, self._p_rew, self._p_done, self._p_env_done, self._p_winner = cp["obs"], cp["rew"], cp["done"], cp["env_done"], cp["winner"]
         self._cfg_ref = ctypes.byref(self._cfg)
         self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)   # the current stream's handle without building a Stream object
         with self._guard():
@@ -254,12 +261,12 @@ class parallel_env:
             _lib.check(self._lib.bsx_reset(self._state.data_ptr(), E, self.n_agents,
                                            mask_t.data_ptr() if mask_t is not None else None,
                                            spawn_t.data_ptr() if spawn_t is not None else None,
-                                           self.seed, self._reset_nonce, self.env_offset, self._obs.data_ptr(),
+                                           self.seed, self._reset_nonce, self.env_offset, self._p_obs,
                                            self._stream()), "bsx_reset")
         if mask_t is None:
             self._env_done.zero_(); self._winner.zero_(); self._done.zero_()
         else:
-            m = mask_t.bool()
+            m = mask_t.bool().to(self._env_done.device)       # (drop-in mode: these rows are views of pinned HOST memory)
             self._env_done[m] = 0; self._winner[m] = 0; self._done[m] = 0
         if self._mirror:
             self._sync_mirror()
@@ -358,7 +365,7 @@ class parallel_env:
                 raise ValueError(f"u must have shape ({self.n_envs}, {self._A})")
             u_ptr = self._u.data_ptr()
         self._launch(act_t.data_ptr() if act_t is not None else None, kind, empty, u_ptr,
-                     self._obs.data_ptr(), self._rew.data_ptr(), self._done.data_ptr())
+                     self._p_obs, self._p_rew, self._p_done)
         if self._mirror:
             self._sync_mirror()
         if copy:
@@ -416,6 +423,8 @@ class parallel_env:
         u:       optional float64 [T, E, A] random() values for the shots (parity runs); needs rng='philox' otherwise
         env_done_out: optional uint8 [T, E] tensor that receives env_done after every tick (row t-1 set = call t found the game
                  finished: the inert / re-spawn call of battle_env.py:303-306, not a transition)"""
+        if self._compat:
+            raise ValueError("step_many needs a batched env (n_envs=...)")
         if self.rng != "philox" and u is None:
             raise ValueError("step_many needs rng='philox' (or injected u)")
         T, kind = self._check_action_series(actions)
@@ -448,7 +457,7 @@ class parallel_env:
         fn = self._lib.bsx_step_many_continuous if self.continuous_actions else self._lib.bsx_step_many_discrete
         with self._guard():
             _lib.check(fn(self._state.data_ptr(), E, self.n_agents, T, actions.data_ptr(), kind, u_ptr, obs.data_ptr(),
-                          rew.data_ptr(), done.data_ptr(), self._env_done.data_ptr(), self._winner.data_ptr(),
+                          rew.data_ptr(), done.data_ptr(), self._p_env_done, self._p_winner,
                           env_done_out.data_ptr() if env_done_out is not None else None,
                           ctypes.byref(self._cfg), flags, 1 if store else 0, self.seed, self.env_offset, self._stream()),
                        "bsx_step_many")
@@ -462,7 +471,7 @@ class parallel_env:
         if self.n_agents > 4:
             raise ValueError("the one-launch rollout is built for 1v1 ... 4v4")
         flags = self._base_flags
-        common = (self._env_done.data_ptr(), self._winner.data_ptr(), env_done_t_ptr, ctypes.byref(self._cfg), flags,
+        common = (self._p_env_done, self._p_winner, env_done_t_ptr, ctypes.byref(self._cfg), flags,
                   ctypes.byref(noise) if noise is not None else None, int(actor_seed), int(seq), seq_base_ptr, self.seed,
                   self.env_offset, self._stream())
         with self._guard():
@@ -487,8 +496,8 @@ class parallel_env:
                  True  = step t writes slice t of new [T, E, A, ...] tensors (a rollout buffer in HBM).
         Returns (graph, outputs): graph.replay() runs the T steps; outputs = (obs, rew, done) tensors.
         Needs rng='philox' (no host draws inside a graph)."""
-        if self.rng != "philox":
-            raise ValueError("capture_steps needs rng='philox'")
+        if self.rng != "philox" or self._compat:
+            raise ValueError("capture_steps needs a batched env with rng='philox'")
         T, kind = self._check_action_series(actions)
         E, A, D = self.n_envs, self._A, self.obs_size
         if store:
@@ -567,8 +576,16 @@ class parallel_env:
             self._hi_act = hi[in_off["act"][0]:][:act_bytes].view(np.float64).reshape(A, 3)
         else:
             self._hi_act = hi[in_off["act"][0]:][:act_bytes].view(np.int32)
-        self._p_in_u = self._in_host.data_ptr() + in_off["u"][0]
-        self._p_in_act = self._in_host.data_ptr() + in_off["act"][0]
+        # The kernels get the DEVICE address of the two staging buffers (hipHostGetDevicePointer): with hipHostMalloc'ed memory it equals
+        # the host address, with registered (hipHostRegister) memory it need not -- never assumed.
+        def device_address(buf):
+            dp = ctypes.c_void_p()
+            _lib.check(self._lib.bsx_host_device_pointer(buf.data_ptr(), ctypes.byref(dp)), "bsx_host_device_pointer (is the staging buffer pinned?)")
+            return dp.value
+        d_in, d_out = device_address(self._in_host), device_address(self._out_host)
+        self._p_in_u = d_in + in_off["u"][0]
+        self._p_in_act = d_in + in_off["act"][0]
+        self._compat_dev_ptrs = {k: d_out + out_off[k][0] for k in ("obs", "rew", "done", "env_done", "winner")}
 
     def _step_compat(self, actions, u):
         ids = self.possible_agents
@@ -637,7 +654,7 @@ class parallel_env:
     # ------------------------------------------------------------------ observe (battle_env.py:202-244)
     def observe(self, agent):
         with self._guard():
-            _lib.check(self._lib.bsx_observe(self._state.data_ptr(), self.n_envs, self.n_agents, self._obs.data_ptr(),
+            _lib.check(self._lib.bsx_observe(self._state.data_ptr(), self.n_envs, self.n_agents, self._p_obs,
                                              self._stream()), "bsx_observe")
         i = self._idx[agent]
         if self._compat:

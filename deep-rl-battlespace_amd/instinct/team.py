@@ -39,6 +39,12 @@ class Team:
             obs = obs.to(env.device)
         E, A = env.n_envs, env._A
         stream = torch.cuda.current_stream(env.device).cuda_stream
+        obs_ptr = obs.data_ptr()
+        if not obs.is_cuda:                                    # pinned host rows: the kernel takes their DEVICE address (never assumed equal)
+            import ctypes
+            dp = ctypes.c_void_p()
+            _lib.check(self._lib.bsx_host_device_pointer(obs_ptr, ctypes.byref(dp)), "bsx_host_device_pointer")
+            obs_ptr = dp.value
         if out is None:
             if self._buf is None:
                 self._buf = (torch.zeros((E, A, 3), dtype=torch.float64, device=env.device) if env.continuous_actions
@@ -51,7 +57,7 @@ class Team:
             if rnd is not None:
                 rnd_t = torch.as_tensor(rnd, dtype=torch.float64, device=env.device).contiguous()
             self.seq += 1
-            _lib.check(self._lib.bsx_instinct_continuous(obs.data_ptr(), out.data_ptr(),
+            _lib.check(self._lib.bsx_instinct_continuous(obs_ptr, out.data_ptr(),
                                                          rnd_t.data_ptr() if rnd_t is not None else None, E, env.n_agents,
                                                          self.team, self.seed, self.seq,
                                                          seq_base.data_ptr() if seq_base is not None else None, stream),
@@ -65,7 +71,7 @@ class Team:
             raise ValueError("discrete instinct actions need an int32 [E, A] or float32 [E, A, 4] tensor")
         if not out.is_contiguous():
             raise ValueError("out must be contiguous")
-        _lib.check(self._lib.bsx_instinct_discrete(obs.data_ptr(), out.data_ptr(), kind, E, env.n_agents, self.team, stream),
+        _lib.check(self._lib.bsx_instinct_discrete(obs_ptr, out.data_ptr(), kind, E, env.n_agents, self.team, stream),
                    "bsx_instinct_discrete")
         return out
 

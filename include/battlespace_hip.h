@@ -237,6 +237,11 @@ int bsx_tie_tick(int n);
  * out[1] = tested (device uint64[2]). */
 int bsx_selftest_atan2(int R, uint64_t* out, void* stream);
 
+/* hipHostGetDevicePointer for a binding that links no HIP runtime of its own: the device address of PINNED host memory
+ * (hipHostMalloc / hipHostRegister) -- what the entry points above must be given for host-resident buffers.  With hipHostMalloc the
+ * two addresses are equal; with registered memory they need not be.  Returns the hipError_t (memory that is not pinned: an error). */
+int bsx_host_device_pointer(void* host, void** device);
+
 /* hipStreamSynchronize(stream) for a binding that links no HIP runtime of its own: the single-game drop-in surface
  * returns host values from step() (battle_env.py:374-381), so it has to wait for the launch it just enqueued. */
 int bsx_stream_synchronize(void* stream);

@@ -133,6 +133,9 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    # the figure to quote is the smaller of the contract fraction and the one on measured traffic; no fraction above 1 anywhere
+    assert r["frac_claimed"] == min(v for v in (r["frac"], r["frac_on_traffic"]) if v is not None) and r["frac_claimed"] <= 1.0
+    assert r["live_aware_bytes_per_launch"] < r["algorithmic_bytes_per_launch"]
     assert d["value"] > 1e9 and abs(d["value"] - 65536 * 2 * 300 / (d["ms_per_step"] * 1e-3 * 300)) / d["value"] < 1e-3
 
 
@@ -153,6 +156,7 @@ def test_bench_measures_the_headline_hbm_traffic_live():
     assert 8e6 < r["traffic"] < r["algorithmic_bytes_per_launch"]          # sparse bullets: less than the 12-slot algorithmic count
     assert abs(r["traffic"] - (2 * r["traffic_detail"]["fetch_size_kib_raw"] + r["traffic_detail"]["write_size_kib_raw"]) * 1024) < 2048
     assert abs(r["frac_on_traffic"] - r["traffic"] / (r["avg_launch_us"] * 1e-6) / 1e9 / r["peak"]) < 1e-3 and r["frac_on_traffic"] < r["frac"]
+    assert r["frac_claimed"] == r["frac_on_traffic"]
 
 
 
@@ -190,3 +194,24 @@ def test_dropin_io_lives_in_pinned_host_memory_and_custom_rows_still_reach_the_d
     o, r, d, _ = env.step(acts)
     assert set(o) == set(env.possible_agents) and all(v.dtype == np.float32 and v.shape == (env.obs_size,) for v in o.values())
     np.testing.assert_array_equal(env.observe("plane0"), o["plane0"])
+
+
+def test_dropin_masked_reset_and_auto_reset_contract():
+    """Drop-in mode keeps its outputs in pinned HOST memory: reset(mask=...) must clear those rows (not index them with a device
+    mask), and auto_reset -- whose in-kernel re-spawn the host mirrors of `agents` / `dones` / `env_done` would never see -- is
+    refused there."""
+    import random as _r
+    _r.seed(3)
+    env = _env(n_agents=1)
+    env.reset()
+    env.step({})                                                    # an empty call ties the game (battle_env.py:309-313)
+    assert env.env_done and env.winner == "tie"
+    obs = env.reset(mask=[True])
+    assert not env.env_done and env.winner == "none" and set(obs) == set(env.possible_agents)
+    assert int(env._env_done[0]) == 0 and int(env._winner[0]) == 0 and not bool(env._done.any())
+    o, r, d, _ = env.step({a: 0 for a in env.possible_agents})
+    assert not any(d.values()) and env.agents == env.possible_agents
+    with pytest.raises(ValueError):
+        _env(n_agents=1, auto_reset=True, rng="philox")
+    with pytest.raises(ValueError):
+        env.step_many(torch.zeros((2, 1, 2), dtype=torch.int32, device="cuda"))

@@ -183,6 +183,46 @@ def test_principal_directions_hit_the_wrap_boundaries_exactly():
     assert set(np.unique(np.abs(got[:, :, [1, 4]]))) >= {0.0, 0.5}                          # the boundaries were exercised
 
 
+@pytest.mark.parametrize("n", [2, 4])
+def test_principal_directions_through_the_pair_shared_bearing_path(n):
+    """Teams of 2 and 4: each red-blue pair's range and bearing are computed ONCE, by one of its two planes, and the other end
+    derives its bearing as r0 +- pi (csrc/bsx_kernels.hip, observation geometry for N >= 2) -- last float64 bits may differ from a
+    direct atan2, and at the +-180 wrap (battle_env.py:50-51), which integer geometry along the principal directions reaches
+    EXACTLY, a last-bit error would flip an observation between +0.5 and -0.5.  Every principal offset x headings in steps of
+    15 degrees (each plane of a team its own heading, so every (red i, blue j) pair -- owner and deriving end -- sees several), against
+    the CPU oracle: angle entries bit-exact."""
+    from oracle import battlespace_ref as ref
+    offs = [(200, 0), (-200, 0), (0, 150), (0, -150), (120, 120), (-120, 120), (120, -120), (-120, -120), (1, 0), (0, -1), (-1, 1)]
+    rows = []
+    for d in range(0, 361, 15):
+        for (dx, dy) in offs:
+            row = [100, 100, 600 + dx, 400 + dy]                             # base red far away; base blue at +off from the red planes
+            row += [v for i in range(n) for v in (600, 400, (d + 15 * i) % 360)]                   # red planes at the centre
+            row += [v for j in range(n) for v in (600 - dx, 400 - dy, (d + 180 + 30 * j) % 360)]   # blue planes at -off
+            rows.append(row)
+    spawn = np.asarray(rows, np.int32)
+    env = _env(n_agents=n, n_envs=len(rows), rng="philox")
+    obs = env.reset(spawn=spawn)
+    got = np.stack([obs[a].cpu().numpy() for a in env.possible_agents], 1)
+    # reset() writes its rows with the reset kernel (direct atan2 per pair); the pair-shared path lives in the STEP kernel, so one
+    # call follows in which nobody moves: action 7 is "no movement" (battle_env.py:399-417) and the step kernel observes the same lattice
+    import torch
+    o = ref.RefEnv(n_agents=n)
+    ang = [1] + [4 + 3 * j for j in range(n)]
+    acts = np.full((len(rows), 2 * n), 7, np.int32)                              # action 7: nobody moves (battle_env.py:399-417), the step kernel still observes
+    obs2, _, _ = env.step_batch(torch.as_tensor(acts))
+    got2 = obs2.cpu().numpy()
+    for i, r in enumerate(rows):
+        exp = o.reset(spawn=r)
+        want = np.stack([exp[a] for a in o.possible_agents])
+        assert np.array_equal(got[i][:, ang], want[:, ang]), (r, got[i], want)
+        exp2, _, _, _ = o.step({a: 7 for a in o.possible_agents})
+        want2 = np.stack([exp2[a] for a in o.possible_agents])
+        assert np.array_equal(got2[i][:, ang], want2[:, ang]), (r, got2[i], want2)             # the step kernel's pair-shared bearings: bit-exact
+        np.testing.assert_allclose(got2[i], want2, rtol=1e-6, atol=1e-7)
+    assert set(np.unique(np.abs(got2[:, :, ang]))) >= {0.0, 0.5}                                 # the boundaries were exercised
+
+
 def test_own_atan2_equals_the_device_library_on_every_pixel_difference():
     """The step path's atan2 (device library algorithm, constants in scalar registers, no range scaling / fix-up) against the
     library call, bit for bit, on every (dy, dx) in [-1300, 1300]^2 -- a superset of every difference of two positions on the

@@ -69,3 +69,20 @@ def test_bench_under_torch_distributed_run_uses_the_ranks_it_is_given():
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak"
     assert abs(d["value"] - 2 * 65536 * 2 * 20 / (d["ms_per_step"] * 1e-3 * 20)) / d["value"] < 1e-3
     assert d["roofline"]["traffic_source"] is None or "profiles/traffic.json" in d["roofline"]["traffic_source"]     # no live PMC passes at N > 1
+
+
+@pytest.mark.skipif(__import__("torch").cuda.device_count() < 2, reason="needs two GPUs: the RCCL leg of bench.py --gpus N on distinct devices")
+def test_two_ranks_on_two_devices_come_up_on_rccl():
+    """`python bench.py --gpus 2` on a node with at least two cards: one rank per GPU, the process group on the nccl backend (= RCCL
+    over xGMI) with device_id and the probe all-reduce -- NOT the gloo fallback that a one-card rehearsal takes.  Skipped on the
+    one-GPU box; the first multi-GPU node that runs the suite proves the happy path of bench.py's process-group setup."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "nccl", "--steps", "100", "--warmup", "20", "--repeats", "2",
+                          "--no-cpu-baseline", "--no-other-workloads", "--no-live-traffic"], capture_output=True, text=True, timeout=900, cwd=root,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["config"]["process_group"] == "nccl" and d["config"]["process_group_note"] is None, d["config"]
+    assert d["config"]["rehearsal_all_ranks_on_device0"] is None
+    assert d["value"] > 1.5 * 65536 * 2 / (d["ms_per_step"] * 1e-3) * 0.5      # two shards' worth of agent-steps in the same wall time
