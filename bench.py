@@ -733,6 +733,8 @@ def rollout_lines(dev, E, K):
                 ("one launch, 64x64 layer as six bf16 matrix products of three-term splits (float32-class accuracy)", dict(one_launch=True, precision="bf16x6"), False, False),
                 ("one launch, 64x64 layer as three bf16 matrix products of two-term splits (~1e-5 on a score)", dict(one_launch=True, precision="bf16x3"), False, False),
                 ("one launch, red = actor vs blue = scripted instinct opponent (main.py:119-122)", dict(one_launch=True), True, False),
+                ("PPO-shaped rollout, one launch: categorical draw from softmax(scores) + log-prob + value head per plane", dict(one_launch=True, sample="categorical", value=True), False, False),
+                ("PPO-shaped rollout, graph of 2 kernels per tick: categorical draw + log-prob + value head", dict(sample="categorical", value=True), False, False),
                 ("continuous actions: graph of 2 kernels per tick", dict(), False, True),
                 ("continuous actions: one launch for all ticks", dict(one_launch=True), False, True)]
     for tag, kw, scripted, cont in variants:
@@ -744,7 +746,13 @@ def rollout_lines(dev, E, K):
             with torch.no_grad():
                 actor.w3.mul_(100.0)                        # random init leaves the head near 0: spread the scores so that play is varied
             opp = instinct.Team(env.possible_blue, env.possible_red, env) if scripted else None
-            ro = PolicyRollout(env, actor, T, noise_std=0.1, opponent=opp, **kw)
+            kw = dict(kw)
+            if kw.pop("value", False):                      # a value head: a second MLP of the actor's shape with one output per plane
+                critic = StackedActor(2, 5, 1, device=dev)
+                with torch.no_grad():
+                    critic.w3.mul_(100.0)
+                kw["value_actor"] = critic
+            ro = PolicyRollout(env, actor, T, noise_std=0.0 if "sample" in kw else 0.1, opponent=opp, **kw)
             ro.start(); ro.capture()
             reps = max(1, K // T)
             for _ in range(3 + 150 // T):                   # past the first time-limit ties

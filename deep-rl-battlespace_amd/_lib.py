@@ -33,7 +33,9 @@ class BsxRewards(ctypes.Structure):
 class BsxActorNoise(ctypes.Structure):
     _fields_ = [("gaussian_std", ctypes.c_float), ("ou_scale", ctypes.c_float), ("ou_theta", ctypes.c_float),
                 ("ou_sigma", ctypes.c_float), ("ou_mu", ctypes.c_float), ("ou_state", ctypes.c_void_p),
-                ("env_done", ctypes.c_void_p), ("z_inject", ctypes.c_void_p), ("ou_keep", ctypes.c_int)]
+                ("env_done", ctypes.c_void_p), ("z_inject", ctypes.c_void_p), ("ou_keep", ctypes.c_int),
+                ("sample_mode", ctypes.c_int), ("temperature", ctypes.c_float), ("logp", ctypes.c_void_p), ("u_inject", ctypes.c_void_p),
+                ("value_weights", ctypes.c_void_p), ("value", ctypes.c_void_p)]
 
 
 EXPORT_FIELDS = ("px", "py", "pdir", "php", "palive", "base_xy", "bhp", "tick", "env_done", "winner",

@@ -161,8 +161,29 @@ __global__ __launch_bounds__(TPB) void bsx_actor_kernel(const ActorArgs p) {
     const size_t row = size_t(e < p.E ? e : p.E - 1) * p.A + a;
     const uint64_t seq = p.seq + seq_add;                // seq_base: device word, so graph replays re-key
     const bool game_over = p.nz.ou_scale > 0.f && p.nz.env_done && p.nz.env_done[e < p.E ? e : p.E - 1];
-    r4 = finish_row(r4, b3, p.nz, p.seed, seq, row, uint64_t(p.env_offset) * uint64_t(p.A) + row, game_over, e < p.E);
+    r4 = finish_row(r4, b3, p.nz, p.seed, seq, row, uint64_t(p.env_offset) * uint64_t(p.A) + row, game_over, e < p.E, row);
     if (e < p.E) reinterpret_cast<float4*>(p.scores)[row] = r4;
+    if (p.nz.value_weights) {
+        // ---- the value head: a second MLP of the same shape on the same rows, exact float32, one 32-row tile at a time; its
+        //      per-neuron vectors and head take the place of the actor's in LDS (every lane is done with them)
+        const float* __restrict__ Wv = p.nz.value_weights + size_t(a) * blob_floats(D);
+        __syncthreads();
+        for (int i = tid; i < SMALL / 4; i += TPB)
+            reinterpret_cast<float4*>(s_small)[i] = reinterpret_cast<const float4*>(Wv + off_small(D))[i];
+        __syncthreads();
+        float4 v[2];
+#pragma nounroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int64_t en = row0 + 32 * nt + c;
+            const float* xr = p.obs + (size_t(en < p.E ? en : p.E - 1) * p.A + a) * D;
+            const float* Wn = Wv;
+            asm volatile("" : "+s"(Wn));
+            const float4 t = tile_forward<BSX_ACTOR_F32>(Wn, s_small, D, lane, [&](int k) { return k < D ? xr[k] : 0.f; });
+            if (nt == 0) v[0] = t; else v[1] = t;
+        }
+        const float vh = hh ? v[1].x : v[0].x;
+        if (e < p.E) p.nz.value[row] = vh + s_small[6 * H + H * NA];
+    }
 }
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
@@ -183,10 +204,13 @@ int bsx_actor_forward(const float* weights, const float* obs, float* scores, int
     if (!weights || !obs || !scores || E <= 0 || E > BSX_MAX_E || n < 1 || n > BSX_MAX_N) return BSX_E_ARG;
     if (precision != BSX_ACTOR_F32 && precision != BSX_ACTOR_BF16X3 && precision != BSX_ACTOR_BF16X6) return BSX_E_ARG;
     if (!aligned(weights, 16) || !aligned(scores, 16) || !aligned(obs, 4)) return BSX_E_ALIGN;
-    BsxActorNoise nz = {0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr, 0};
+    BsxActorNoise nz = {};
     if (noise) nz = *noise;
     if (nz.ou_scale > 0.f && (!nz.ou_state || !aligned(nz.ou_state, 16))) return nz.ou_state ? BSX_E_ALIGN : BSX_E_ARG;
     if (nz.z_inject && !aligned(nz.z_inject, 16)) return BSX_E_ALIGN;
+    if (nz.sample_mode != 0 && (nz.sample_mode != 1 || !(nz.temperature > 0.f))) return BSX_E_ARG;
+    if ((nz.u_inject && !aligned(nz.u_inject, 16)) || (nz.logp && !aligned(nz.logp, 4)) || (nz.value_weights && !aligned(nz.value_weights, 16))) return BSX_E_ALIGN;
+    if (nz.value_weights && (!nz.value || !aligned(nz.value, 4))) return nz.value ? BSX_E_ALIGN : BSX_E_ARG;
     if (env_offset < 0) return BSX_E_ARG;
     const int A = 2 * n, D = 3 * n + 2;
     ActorArgs a{weights, obs, scores, E, A, D, nz, seed, seq, seq_base, env_offset};

@@ -105,13 +105,24 @@ __device__ inline float4 normals4(uint64_t seed, uint64_t seq, uint64_t grow, ui
     return make_float4(m0 * c0, m0 * s0, m1 * c1, m1 * s1);
 }
 
+// Four uniforms in (0, 1) from one Philox4x32-10 block, keyed like normals4 (own salt): the categorical policy's Gumbel draws.
+__device__ inline float4 uniforms4(uint64_t seed, uint64_t seq, uint64_t grow, uint32_t salt) {
+#pragma clang fp contract(fast)
+    const uint4 r = philox4x32_10(make_uint4(uint32_t(grow), uint32_t(grow >> 32), uint32_t(seq), uint32_t(seq >> 32) ^ salt),
+                                  make_uint2(uint32_t(seed), uint32_t(seed >> 32) ^ 0xA5A5A5A5u));
+    const float k = 1.0f / 16777216.0f;
+    return make_float4((float(r.x >> 8) + 0.5f) * k, (float(r.y >> 8) + 0.5f) * k, (float(r.z >> 8) + 0.5f) * k, (float(r.w >> 8) + 0.5f) * k);
+}
+
 // tanh of the head sums + bias, exploration noise, clamp (maddpg/networks.py:85, maddpg/agent.py:30-31) for ONE row.
 // `row` indexes this launch's arrays (OU state, injected normals); `grow` = the job-wide row (env_offset + e)*A + a keys the
 // draws, so the noise a game sees does not depend on the sharding.  Optional Ornstein-Uhlenbeck state at ou_state[row]
 // (utils/noise.py:17-21), restarted from mu when `game_over` (main.py:155); with both processes on, the Gaussian term takes its
 // own draw (salt) -- the OU increment and the white term are independent.  `store`: this lane owns a real row.
+// sample_mode 1 (categorical policy): the row becomes scores / temperature + Gumbel noise -- its arg-max is a draw from
+// softmax(scores / temperature) -- and the drawn action's log-probability goes to nz.logp[orow] (orow: the row in a [T][E*A] record).
 __device__ inline float4 finish_row(float4 r4, const float4 b3, const BsxActorNoise& nz, uint64_t seed, uint64_t seq,
-                                    size_t row, uint64_t grow, bool game_over, bool store) {
+                                    size_t row, uint64_t grow, bool game_over, bool store, size_t orow) {
 #pragma clang fp contract(fast)
     r4.x = tanhf(r4.x + b3.x); r4.y = tanhf(r4.y + b3.y); r4.z = tanhf(r4.z + b3.z); r4.w = tanhf(r4.w + b3.w);
     if (nz.gaussian_std > 0.f || nz.ou_scale > 0.f) {
@@ -135,6 +146,22 @@ __device__ inline float4 finish_row(float4 r4, const float4 b3, const BsxActorNo
         }
         r4.x = fminf(fmaxf(r4.x, -1.f), 1.f); r4.y = fminf(fmaxf(r4.y, -1.f), 1.f);
         r4.z = fminf(fmaxf(r4.z, -1.f), 1.f); r4.w = fminf(fmaxf(r4.w, -1.f), 1.f);
+    }
+    if (nz.sample_mode == 1) {
+        const float it = 1.0f / nz.temperature;
+        const float4 z = make_float4(r4.x * it, r4.y * it, r4.z * it, r4.w * it);
+        const float4 u = nz.u_inject ? reinterpret_cast<const float4*>(nz.u_inject)[row] : uniforms4(seed, seq, grow, 0x40000000u);
+        const float4 pr = make_float4(z.x - __logf(-__logf(u.x)), z.y - __logf(-__logf(u.y)), z.z - __logf(-__logf(u.z)), z.w - __logf(-__logf(u.w)));
+        // the draw = the first maximum of the perturbed row, as the step's arg-max will find it; its log-probability under softmax(z)
+        int am = 0; float best = pr.x, za = z.x;
+        if (pr.y > best) { am = 1; best = pr.y; za = z.y; }
+        if (pr.z > best) { am = 2; best = pr.z; za = z.z; }
+        if (pr.w > best) { am = 3; best = pr.w; za = z.w; }
+        const float m = fmaxf(fmaxf(z.x, z.y), fmaxf(z.z, z.w));
+        const float lse = m + __logf(__expf(z.x - m) + __expf(z.y - m) + __expf(z.z - m) + __expf(z.w - m));
+        if (store && nz.logp) nz.logp[orow] = za - lse;
+        (void)am;
+        r4 = pr;
     }
     return r4;
 }

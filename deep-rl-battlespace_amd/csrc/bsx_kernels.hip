@@ -569,7 +569,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     __shared__ volatile int s_x_all[WAVES * SPB], s_y_all[WAVES * SPB], s_hp_all[WAVES * SPB];
     __shared__ volatile int s_bhit_all[WAVES * SPB];     // base hits, index gl + shooter team
     __shared__ __attribute__((aligned(16))) float s_obs_all[WAVES * SPB * DROW];   // observation rows, [wave][lane][D]
-    __shared__ __attribute__((aligned(16))) float s_small[ACTOR ? 2 * (N > 0 ? N : 1) * bsx_actor::SMALL : 4];   // per-neuron vectors + heads of the actors
+    __shared__ __attribute__((aligned(16))) float s_small[ACTOR ? (N == 1 ? 4 : 2 * N) * bsx_actor::SMALL : 4];   // per-neuron vectors + heads of the actors (1v1: + the two value heads')
     __shared__ int s_act_all[(ACTOR && !CONT && WAVES > 1) ? WAVES * SPB : 1];       // arg-max per row, ACTOR with several waves
     __shared__ float s_actf_all[(ACTOR && CONT && WAVES > 1) ? WAVES * SPB * 3 : 1];  // continuous: [speed, turn, shoot] per row
     __shared__ int s_gdone_all[(ACTOR && WAVES > 1) ? 32 : 1];                       // game-over flag per game of the workgroup
@@ -695,6 +695,14 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
             reinterpret_cast<float4*>(s_small)[i] =
                 reinterpret_cast<const float4*>(p.aw + size_t(ag) * bsx_actor::blob_floats(D) + bsx_actor::off_small(D))[j];
         }
+        if constexpr (N == 1) {
+            if (p.nz.value_weights)
+                for (int i = int(threadIdx.x); i < 2 * bsx_actor::SMALL / 4; i += SPB * WAVES) {
+                    const int ag = i / (bsx_actor::SMALL / 4), j = i - ag * (bsx_actor::SMALL / 4);
+                    reinterpret_cast<float4*>(s_small + 2 * bsx_actor::SMALL)[i] =
+                        reinterpret_cast<const float4*>(p.nz.value_weights + size_t(ag) * bsx_actor::blob_floats(D) + bsx_actor::off_small(D))[j];
+                }
+        }
         // the observations the rollout starts from (obs[0]): this wave's rows are one contiguous block
         const int64_t e_first = wblk * EPB;
         const int64_t nfl = min(int64_t(SPB), (E_ - e_first) * A) * D;
@@ -797,7 +805,24 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
             double td_, ta_;
             r4 = one_hot_scores(instinct_choose([&](int k) { return s_obs_all[(c * G_ + mine_c) * D + k]; }, N, td_, ta_));
         } else {
-            r4 = bsx_actor::finish_row(r4, b3, p.nz, p.aseed, aseq, row, uint64_t(p.env_offset) * uint64_t(A) + row, game_over, row_ok);
+            r4 = bsx_actor::finish_row(r4, b3, p.nz, p.aseed, aseq, row, uint64_t(p.env_offset) * uint64_t(A) + row, game_over, row_ok,
+                                       size_t(tk) * size_t(E_) * size_t(A) + row);
+        }
+        if constexpr (N == 1) {
+            if (p.nz.value_weights) {
+                // ---- the value head (1v1): a second MLP of the actor's shape on the same LDS rows, exact float32; its per-neuron
+                //      vectors and head sit behind the actors' in LDS
+                float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma nounroll
+                for (int ti = 0; ti < 2; ++ti) {
+                    const float* const Wn = p.nz.value_weights + size_t(ti) * bsx_actor::blob_floats(D);
+                    const float* const smn = s_small + (2 + ti) * bsx_actor::SMALL;
+                    auto xb = [&](int k) { return k < D ? s_obs_all[(c * G_ + ti) * D + k] : 0.f; };
+                    const float4 o = bsx_actor::tile_forward<BSX_ACTOR_F32>(Wn, smn, D, lane, xb);
+                    if (hh == ti) v4 = o;
+                }
+                if (row_ok) p.nz.value[size_t(tk) * size_t(E_) * size_t(A) + row] = v4.x + s_small[(2 + mine_c) * bsx_actor::SMALL + 6 * bsx_actor::H + bsx_actor::H * bsx_actor::NA];
+            }
         }
         if (row_ok) reinterpret_cast<float4*>(p.scores + int64_t(tk) * p.scores_ts)[row] = r4;
         if constexpr (!CONT) {
@@ -1691,7 +1716,7 @@ int launch_step(void* state, int64_t E, int n, const void* actions, int action_k
     a.obs = obs; a.rew = rew; a.done = done; a.env_done = env_done; a.winner = winner; a.env_done_t = env_done_t;
     a.cfg = *cfg; a.flags = flags; a.seed = seed; a.env_offset = env_offset; a.tie_tick = bsx_tie_tick(n);
     const int64_t EA = E * 2 * n;
-    a.aw = nullptr; a.aprec = 0; a.scripted_team = -1; a.obs0 = nullptr; a.scores = nullptr; a.scores_ts = 0; a.nz = BsxActorNoise{0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr, 0};
+    a.aw = nullptr; a.aprec = 0; a.scripted_team = -1; a.obs0 = nullptr; a.scores = nullptr; a.scores_ts = 0; a.nz = BsxActorNoise{};
     a.aseed = 0; a.aseq = 0; a.aseq_base = nullptr;
     a.T = T;
     a.act_tb = EA * (CONT ? (action_kind == BSX_ACT_F32 ? 12 : (action_kind == BSX_ACT_F64 ? 24 : 16)) : (action_kind == BSX_ACT_I32 ? 4 : 16));
@@ -1830,10 +1855,13 @@ int launch_rollout(void* state, int64_t E, int n, int T, const float* weights, i
         scripted_team < -1 || scripted_team > 1) return BSX_E_ARG;
     if (CONT && scripted_team != -1) return BSX_E_ARG;
     if (!aligned(state, 256) || !aligned(weights, 16) || !aligned(scores, 16) || !aligned(obs, 4) || !aligned(rew, 4)) return BSX_E_ALIGN;
-    BsxActorNoise nz = {0.f, 0.f, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr, 0};
+    BsxActorNoise nz = {};
     if (noise) nz = *noise;
     if (nz.ou_scale > 0.f && (!nz.ou_state || !aligned(nz.ou_state, 16))) return nz.ou_state ? BSX_E_ALIGN : BSX_E_ARG;
-    if (nz.z_inject) return BSX_E_ARG;                   // injected normals are per call: bsx_actor_forward only
+    if (nz.z_inject || nz.u_inject) return BSX_E_ARG;    // injected draws are per call: bsx_actor_forward only
+    if (nz.sample_mode != 0 && (nz.sample_mode != 1 || !(nz.temperature > 0.f) || CONT)) return BSX_E_ARG;   // a categorical head belongs to discrete actions
+    if ((nz.logp && !aligned(nz.logp, 4)) || (nz.value_weights && !aligned(nz.value_weights, 16))) return BSX_E_ALIGN;
+    if (nz.value_weights && (n != 1 || !nz.value || !aligned(nz.value, 4))) return BSX_E_ARG;          // the value head rides in the 1v1 kernel only
     const int64_t EA = E * 2 * n, D = 3 * n + 2;
     StepArgs a;
     a.st = state_ptrs(state, E, n);

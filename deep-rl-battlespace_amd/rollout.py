@@ -40,12 +40,15 @@ class StackedActor(nn.Module):
     def _ln(x, g, h, eps=1e-5):
         return torch.nn.functional.layer_norm(x, x.shape[-1:], None, None, eps) * g + h
 
-    def forward(self, obs):
-        """obs [E, A, D] -> scores [E, A, n_actions] (tanh-squashed, as the reference's actor output)."""
+    def forward(self, obs, squash=True):
+        """obs [E, A, D] -> scores [E, A, n_actions] (tanh-squashed, as the reference's actor output; squash=False: the raw head,
+        what a value head returns)."""
         x = obs.transpose(0, 1)                                     # [A, E, D]
         x = torch.relu(self._ln(torch.baddbmm(self.b1, x, self.w1), self.g1, self.h1))
         x = torch.relu(self._ln(torch.baddbmm(self.b2, x, self.w2), self.g2, self.h2))
-        x = torch.tanh(torch.baddbmm(self.b3, x, self.w3))
+        x = torch.baddbmm(self.b3, x, self.w3)
+        if squash:
+            x = torch.tanh(x)
         return x.transpose(0, 1)
 
     @torch.no_grad()
@@ -60,9 +63,9 @@ class StackedActor(nn.Module):
                                                 W2[nid(s>>1, 8 (s&1) + i, lane>>5)][32 mo + (lane&31)]  (precision="bf16x3" / "bf16x6")
         with nid(m, v, hh) = 32 m + (v&3) + 8 (v>>2) + 4 hh, the neuron that accumulator register v of 32-neuron tile m
         holds in lane half hh.  float32, contiguous, [n_actors, floats]."""
-        if self.w1.shape[2] != 64 or self.w2.shape[2] != 64 or self.n_actions not in (3, 4):
-            raise ValueError("the fused actor kernel is built for fc1 = fc2 = 64 (main.py:15-16) and 4 action scores, or 3 "
-                             "continuous actions (padded to 4 rows: the extra output is tanh(0) = 0)")
+        if self.w1.shape[2] != 64 or self.w2.shape[2] != 64 or self.n_actions not in (1, 3, 4):
+            raise ValueError("the fused actor kernel is built for fc1 = fc2 = 64 (main.py:15-16) and 4 action scores, 3 continuous "
+                             "actions or 1 value (padded to 4 head columns: the extra outputs are 0)")
         A, D, dev = self.n_actors, self.obs_len, self.w1.device
         Dp = (D + 1) & ~1
         lane = torch.arange(64, device=dev)
@@ -88,9 +91,10 @@ class StackedActor(nn.Module):
         idx = nid(mo3, v16.view(1, 1, 16), hh3).reshape(-1)                      # [hh][mo][v] -> neuron
         small = [x.float().reshape(A, 64)[:, idx] for x in (self.b1, self.g1, self.h1, self.b2, self.g2, self.h2)]
         w3, b3 = self.w3.float(), self.b3.float()
-        if self.n_actions == 3:                                                    # continuous: [speed, turn, shoot] + a zero column
-            w3 = torch.cat([w3, torch.zeros_like(w3[:, :, :1])], dim=2)
-            b3 = torch.cat([b3, torch.zeros_like(b3[:, :, :1])], dim=2)
+        if self.n_actions < 4:                      # continuous: [speed, turn, shoot] + a zero column; a value head: [V] + three zero columns
+            pad = 4 - self.n_actions
+            w3 = torch.cat([w3, torch.zeros_like(w3[:, :, :1]).expand(-1, -1, pad)], dim=2)
+            b3 = torch.cat([b3, torch.zeros_like(b3[:, :, :1]).expand(-1, -1, pad)], dim=2)
         W3P = w3[:, idx, :].reshape(A, -1)                                         # [hh][mt][v][4]: same index pattern with mt for mo
         # W2B[a, mo, s, term, lane, i]: the 64 x 64 layer split in three bfloat16 terms (precision="bf16x3" reads two, "bf16x6" all)
         mo6 = torch.arange(2, device=dev).view(2, 1, 1, 1); s6 = torch.arange(4, device=dev).view(1, 4, 1, 1)
@@ -151,12 +155,37 @@ class FusedActor:
     def refresh(self):
         self.actor.pack(out=self.weights)
 
-    def noise_struct(self, E, noise_std=0.0, ou=None, z=None):
-        """BsxActorNoise for E games (None = no noise); validates the OU state tensor.  z: optional float32 [E, A, 4] standard
-        normals to use instead of the in-kernel draws (parity runs against the reference's np.random.randn values)."""
-        if not (noise_std > 0.0 or ou is not None):
+    def noise_struct(self, E, noise_std=0.0, ou=None, z=None, sample=None, value=None):
+        """BsxActorNoise for E games (None = nothing to say); validates the OU state tensor.  z: optional float32 [E, A, 4] standard
+        normals to use instead of the in-kernel draws (parity runs against the reference's np.random.randn values).
+        sample: dict(temperature[, logp, u]) -- categorical policy head: the action is drawn from softmax(scores / temperature)
+        (Gumbel-max; the score rows that go out are the perturbed ones), `logp` a float32 tensor ([E, A], or [T, E, A] for a one-launch
+        rollout) that receives the drawn action's log-probability, `u` float32 [E, A, 4] uniforms to use instead of the draws (tests).
+        value: dict(weights, out) -- a value head: `weights` the packed blob of a StackedActor with ONE output per agent, `out` a
+        float32 tensor ([E, A] / [T, E, A]) that receives V(obs)."""
+        if not (noise_std > 0.0 or ou is not None or sample is not None or value is not None):
             return None
-        nz = _lib.BsxActorNoise(float(noise_std), 0.0, 0.15, 0.2, 0.0, None, None, None, 0)
+        nz = _lib.BsxActorNoise(float(noise_std), 0.0, 0.15, 0.2, 0.0, None, None, None, 0, 0, 0.0, None, None, None, None)
+        if sample is not None:
+            nz.sample_mode, nz.temperature = 1, float(sample.get("temperature", 1.0))
+            if not nz.temperature > 0.0:
+                raise ValueError("temperature must be > 0")
+            lp, u = sample.get("logp"), sample.get("u")
+            if lp is not None:
+                if lp.dtype != torch.float32 or not lp.is_contiguous() or tuple(lp.shape[-2:]) != (E, 2 * self.n):
+                    raise ValueError("sample['logp'] must be a contiguous float32 [.., E, A] tensor")
+                nz.logp = lp.data_ptr()
+            if u is not None:
+                if u.dtype != torch.float32 or tuple(u.shape) != (E, 2 * self.n, 4) or not u.is_contiguous():
+                    raise ValueError("sample['u'] must be a contiguous float32 [E, A, 4] tensor")
+                nz.u_inject = u.data_ptr()
+        if value is not None:
+            w, out = value["weights"], value["out"]
+            if tuple(w.shape) != tuple(self.weights.shape) or w.dtype != torch.float32 or not w.is_contiguous():
+                raise ValueError("value['weights'] must be the packed blob of a StackedActor(n_actors, obs_len, 1)")
+            if out.dtype != torch.float32 or not out.is_contiguous() or tuple(out.shape[-2:]) != (E, 2 * self.n):
+                raise ValueError("value['out'] must be a contiguous float32 [.., E, A] tensor")
+            nz.value_weights, nz.value = w.data_ptr(), out.data_ptr()
         if z is not None:
             if z.dtype != torch.float32 or tuple(z.shape) != (E, 2 * self.n, 4) or not z.is_contiguous():
                 raise ValueError("z must be a contiguous float32 [E, A, 4] tensor")
@@ -172,7 +201,7 @@ class FusedActor:
             nz.ou_keep = 0 if ou.get("restart", True) else 1
         return nz
 
-    def forward_into(self, obs, scores, noise_std=0.0, seq=None, seq_base=None, ou=None, z=None):
+    def forward_into(self, obs, scores, noise_std=0.0, seq=None, seq_base=None, ou=None, z=None, sample=None, value=None):
         """obs f32 [E, A, D] (contiguous) -> scores f32 [E, A, 4] (contiguous, 16-byte aligned), on the current stream.
         noise_std: Gaussian exploration noise.  ou: optional dict(scale, state[, theta, sigma, mu, env_done]) for the
         reference's Ornstein-Uhlenbeck noise (utils/noise.py): `state` is a float32 [E, A, 4] tensor updated in place,
@@ -182,7 +211,7 @@ class FusedActor:
         if seq is None:
             self.seq += 1
             seq = self.seq
-        nz = self.noise_struct(E, noise_std, ou, z)
+        nz = self.noise_struct(E, noise_std, ou, z, sample, value)
         _lib.check(self._lib.bsx_actor_forward(self.weights.data_ptr(), obs.data_ptr(), scores.data_ptr(), E, self.n, self.precision,
                                                _lib.ctypes.byref(nz) if nz is not None else None, self.seed, int(seq),
                                                seq_base.data_ptr() if seq_base is not None else None, self.env_offset,
@@ -211,7 +240,7 @@ class PolicyRollout:
     kernel and restarted per game; then clamp(-1, 1) as maddpg/agent.py:31 does."""
 
     def __init__(self, env, actor, T, noise_std=0.0, fused=True, seed=0, opponent=None, ou_scale=0.0, one_launch=False,
-                 precision="f32", ou_restart=True):
+                 precision="f32", ou_restart=True, sample=None, temperature=1.0, value_actor=None):
         """actor: a StackedActor.  fused=True evaluates it with the hand-written HIP kernel (FusedActor), False with
         torch ops (the fp32 reference of the same op).  opponent: an `instinct.Team` that plays its team's planes
         instead of the actor (the reference's training setup, main.py:119-122: learned red vs scripted blue): its
@@ -246,6 +275,24 @@ class PolicyRollout:
             raise ValueError("one_launch plays a scripted opponent in-kernel: it must be an instinct.Team of one side")
         self._seq_base = torch.zeros(1, dtype=torch.int64, device=env.device)
         E, A, D, dev = env.n_envs, env._A, env.obs_size, env.device
+        # sample="categorical": a stochastic policy head for policy-gradient learners (BASELINE.json configs[4] words C5 as a PPO rollout):
+        # the action is DRAWN from softmax(scores / temperature) in-kernel, `logp[t]` holds its log-probability; value_actor (a
+        # StackedActor with one output per agent) adds `value[t]` = V(obs[t]).  Fused actor only; the one-launch form takes the value
+        # head at 1v1.
+        if sample not in (None, "categorical"):
+            raise ValueError("sample must be None or 'categorical'")
+        if (sample is not None or value_actor is not None) and (not fused or self.continuous):
+            raise ValueError("the categorical / value heads need the fused actor and a discrete env")
+        self.logp = torch.zeros((T, E, A), dtype=torch.float32, device=dev) if sample is not None else None
+        self._sample = dict(temperature=float(temperature)) if sample is not None else None
+        self.value, self._value_w = None, None
+        if value_actor is not None:
+            if value_actor.n_actions != 1 or value_actor.n_actors != A or value_actor.obs_len != D:
+                raise ValueError("value_actor must be a StackedActor(n_actors=A, obs_len=D, n_actions=1)")
+            if self.one_launch and env.n_agents != 1:
+                raise ValueError("the one-launch rollout takes a value head at 1v1 only (use the graph form)")
+            self.value_actor, self._value_w = value_actor, value_actor.pack()
+            self.value = torch.zeros((T, E, A), dtype=torch.float32, device=dev)
         self.obs = torch.empty((T + 1, E, A, D), dtype=torch.float32, device=dev)
         # discrete: 4 action scores, arg-maxed in the step kernel; continuous: [speed, turn, shoot] + one unused column
         self.scores = torch.zeros((T, E, A, 4), dtype=torch.float32, device=dev)
@@ -268,7 +315,9 @@ class PolicyRollout:
             # graph arguments are frozen: the noise key is (seed, seq_base + t, row) with seq_base a device word that the
             # graph advances by T once per replay (_body)
             ou = dict(self.ou, env_done=self.env_done[t] if self.ou["restart"] else None) if self.ou is not None else None
-            self.fused.forward_into(self.obs[t], self.scores[t], self.noise_std, seq=t, seq_base=self._seq_base, ou=ou)
+            sample = dict(self._sample, logp=self.logp[t]) if self._sample is not None else None
+            value = dict(weights=self._value_w, out=self.value[t]) if self._value_w is not None else None
+            self.fused.forward_into(self.obs[t], self.scores[t], self.noise_std, seq=t, seq_base=self._seq_base, ou=ou, sample=sample, value=value)
             if self.opponent is not None:
                 self.opponent.write_actions(out=self.scores[t], obs=self.obs[t])
             self.env._launch(self.scores[t].data_ptr(), self._kind, False, None,
@@ -309,7 +358,9 @@ class PolicyRollout:
         self.obs[0].copy_(self.obs[self.T])            # continue where the previous rollout ended
         self.env_done[0].copy_(self.env_done[self.T])
         if self.one_launch:
-            nz = self.fused.noise_struct(self.env.n_envs, self.noise_std, self.ou)
+            sample = dict(self._sample, logp=self.logp) if self._sample is not None else None
+            value = dict(weights=self._value_w, out=self.value) if self._value_w is not None else None
+            nz = self.fused.noise_struct(self.env.n_envs, self.noise_std, self.ou, sample=sample, value=value)
             self.env._launch_rollout(self.T, self.fused.weights.data_ptr(), self.fused.precision,
                                      -1 if self.opponent is None else self.opponent.team, self.obs.data_ptr(), self.scores.data_ptr(),
                                      self.rew.data_ptr(), self._done.data_ptr(), nz, self.fused.seed, 0, self._seq_base.data_ptr(),

@@ -175,6 +175,21 @@ typedef struct BsxActorNoise {
     int ou_keep;              /* bsx_rollout_*: 0 = the process restarts from ou_mu at every game start, as the training loop does
                                  (main.py:155 reset_noise per game); 1 = it never restarts -- the reference's evaluation loop
                                  (evaluate.py:52-76) never calls reset_noise.  bsx_actor_forward restarts exactly where env_done says. */
+    /* ---- policy-gradient rollouts (BASELINE.json configs[4] words C5 as a "PPO policy rollout"; README.md:13 mentions the PPO runs
+     * that preceded MADDPG, of which the reference keeps no code): a stochastic policy head and a value head next to the
+     * deterministic-plus-noise one of maddpg/agent.py:25-33.  All fields may be zero / null. */
+    int sample_mode;          /* 0: the score rows go out as they are and the step arg-maxes them (the reference);
+                                 1: categorical policy -- the action is DRAWN from softmax(scores / temperature) by the Gumbel-max rule:
+                                    the row written to `scores` is scores / temperature + g, g_i = -log(-log u_i), u_i uniform in (0, 1)
+                                    from Philox keyed like the noise draws (own stream), so the step's arg-max of that row IS the draw */
+    float temperature;        /* > 0 when sample_mode = 1 */
+    float* logp;              /* nullable float32 [E*A] (bsx_rollout_*: [T][E*A]): log softmax(scores / temperature)[drawn action] */
+    const float* u_inject;    /* nullable float32 [E*A*4], 16-byte aligned: the uniforms to use instead of the Philox draws (bsx_actor_forward only: tests) */
+    const float* value_weights; /* nullable: a second MLP per agent of the actor's shape (obs -> 64 -> LayerNorm -> ReLU -> 64 -> LayerNorm -> ReLU -> 1,
+                                 the widths of maddpg/networks.py:14-52's critic on the agent's own observation), packed like `weights`
+                                 (head column 0 = the value, columns 1-3 zero); evaluated in exact float32 on the rows the actor reads */
+    float* value;             /* float32 [E*A] (bsx_rollout_*: [T][E*A]), required with value_weights: V(obs) = head + bias, no tanh.
+                                 bsx_rollout_* take a value head for n = 1 only (the per-tick form for any n). */
 } BsxActorNoise;
 /* precision of the 64 x 64 layer: exact float32 (an fmaf chain, bit for bit), or both operands split in two bf16 terms and
  * three bf16 matrix products accumulated in float32 (about 1e-5 on a score; 16x the matrix rate).  All else is float32. */

@@ -152,6 +152,95 @@ def test_reference_evaluation_workload_vs_c_oracle(one_launch):
     assert 0.7 < rate < 0.9                                                 # README.md:30 "~80%"
 
 
+@pytest.mark.parametrize("n", [1, 2])
+def test_categorical_policy_head_and_value_head_vs_torch(n):
+    """The policy-gradient heads next to the reference's deterministic-plus-noise one (BASELINE.json configs[4] words C5 as a PPO
+    rollout): with injected uniforms the kernel's Gumbel-max row, the drawn action and its log-probability equal a torch fp32
+    restatement (softmax(scores / T), g = -log(-log u)); the value head equals the torch forward of a second MLP of the same shape;
+    and with the kernel's own Philox draws the action frequencies on one observation row follow softmax(scores / T) (chi-square)."""
+    from deep_rl_battlespace_amd.rollout import FusedActor, StackedActor
+    torch.manual_seed(31)
+    E, A, D, tau = 4096, 2 * n, 3 * n + 2, 0.5
+    actor, critic = StackedActor(A, D, 4, device="cuda"), StackedActor(A, D, 1, device="cuda")
+    with torch.no_grad():
+        actor.w3.mul_(60.0); critic.w3.mul_(100.0)                              # spread the fresh heads (0.003-uniform) so that rows differ
+    obs = (torch.rand((E, A, D), device="cuda") * 2 - 1).contiguous()
+    u = (torch.rand((E, A, 4), device="cuda") * 0.998 + 0.001).contiguous()
+    fa = FusedActor(actor, n, seed=9)
+    scores = torch.empty((E, A, 4), device="cuda"); lp = torch.zeros((E, A), device="cuda"); val = torch.zeros((E, A), device="cuda")
+    fa.forward_into(obs, scores, sample=dict(temperature=tau, logp=lp, u=u), value=dict(weights=critic.pack(), out=val))
+    with torch.no_grad():
+        z = actor(obs) / tau
+        want = z - torch.log(-torch.log(u))
+        a = want.argmax(-1)
+        want_lp = torch.log_softmax(z, -1).gather(-1, a[..., None])[..., 0]
+        want_v = critic(obs, squash=False)[..., 0]
+    torch.testing.assert_close(scores, want, rtol=0, atol=2e-4)
+    top = want.topk(2, -1).values
+    clear = (top[..., 0] - top[..., 1]) > 2e-3
+    assert torch.equal(scores.argmax(-1)[clear], a[clear]) and float(clear.float().mean()) > 0.99
+    torch.testing.assert_close(lp[clear], want_lp[clear], rtol=0, atol=2e-4)
+    torch.testing.assert_close(val, want_v, rtol=0, atol=5e-5)
+    # the kernel's own draws: one observation row for every game, 4096 x A draws -> frequencies against softmax(z)
+    obs1 = obs[:1].expand(E, -1, -1).contiguous()
+    fa.forward_into(obs1, scores, sample=dict(temperature=tau, logp=lp))
+    with torch.no_grad():
+        pr = torch.softmax(actor(obs1[:1]) / tau, -1)[0]                        # [A, 4]
+    for i in range(A):
+        cnt = torch.bincount(scores[:, i].argmax(-1), minlength=4).double()
+        exp = pr[i].double() * E
+        keep = exp > 5
+        chi2 = float((((cnt - exp) ** 2) / exp)[keep].sum())
+        assert chi2 < 25.0, (i, cnt.tolist(), exp.tolist(), chi2)               # 3 degrees of freedom: p(chi2 > 25) ~ 1.5e-5
+        got_lp = lp[:, i]
+        want_row = torch.log(pr[i])[scores[:, i].argmax(-1)]
+        torch.testing.assert_close(got_lp, want_row.float(), rtol=0, atol=2e-4)
+    # a second call with another sequence number draws differently
+    s2 = torch.empty_like(scores)
+    fa.forward_into(obs1, s2, sample=dict(temperature=tau))
+    assert float((s2.argmax(-1) != scores.argmax(-1)).float().mean()) > 0.05
+
+
+@pytest.mark.parametrize("n,one_launch", [(1, True), (1, False), (2, False)])
+def test_categorical_rollout_records_logp_and_value_and_one_launch_equals_the_graph(n, one_launch):
+    """PolicyRollout(sample='categorical', value_actor=...): T ticks of (draw an action from softmax(scores / T), V(obs), step) with
+    logp / value records [T, E, A]; the step takes exactly the drawn action (its arg-max of the perturbed row), so the C oracle
+    stepping on the recorded score rows plays the same games; at 1v1 the one-launch form equals the per-tick graph bit for bit."""
+    from deep_rl_battlespace_amd.rollout import PolicyRollout, StackedActor
+    E, T, A, D = 8192, 16, 2 * n, 3 * n + 2
+    torch.manual_seed(5)
+    actor, critic = StackedActor(A, D, 4, device="cuda"), StackedActor(A, D, 1, device="cuda")
+    with torch.no_grad():
+        actor.w3.mul_(60.0); critic.w3.mul_(100.0)
+
+    def play(ol):
+        env = _env(n_agents=n, n_envs=E, seed=41, auto_reset=True)
+        env.reset()
+        ro = PolicyRollout(env, actor, T, seed=3, one_launch=ol, sample="categorical", temperature=0.7, value_actor=critic)
+        ro.start(); ro.capture()
+        ro.run(); ro.run()
+        torch.cuda.synchronize()
+        return env, ro
+    env, ro = play(one_launch)
+    c = cref.CRefBatch(E, n_agents=n, seed=41, auto_reset=True)
+    c.reset()
+    env_b, ro_b = play(False) if one_launch else (env, ro)
+    if one_launch:
+        for f in ("obs", "scores", "rew", "_done", "logp", "value", "env_done"):
+            assert torch.equal(getattr(ro, f), getattr(ro_b, f)), f
+    # the log-probabilities are those of the arg-max of the recorded rows under softmax(actor(obs) / T); values are the critic's
+    with torch.no_grad():
+        z = actor(ro.obs[3]) / 0.7
+        a = ro.scores[3].argmax(-1)
+        want_lp = torch.log_softmax(z, -1).gather(-1, a[..., None])[..., 0]
+        want_v = critic(ro.obs[3], squash=False)[..., 0]
+    torch.testing.assert_close(ro.logp[3], want_lp, rtol=0, atol=3e-4)
+    torch.testing.assert_close(ro.value[3], want_v, rtol=0, atol=5e-5)
+    assert float(ro.logp.max()) <= 0.0 and float(ro.logp.min()) > -20.0
+    acts = torch.bincount(ro.scores.argmax(-1).flatten(), minlength=4)
+    assert int(acts.min()) > 0.02 * int(acts.sum())                              # a stochastic policy: every action is drawn
+
+
 def test_ou_noise_reproduces_the_reference_trajectory():
     """g11: utils/noise.py OUNoise(4) run unmodified -- 40 noise() calls with the np.random.randn values it drew, a reset()
     (main.py:155) and a re-scale (main.py:154) on the way.  The in-kernel process (bsx_actor_forward) is fed the same normals
