@@ -10,6 +10,7 @@
 //   -DBSX_STAMPS -DBSX_STAMPS_FINE   stamps 3..6 move INSIDE the shot phase (after the slot table / the Philox draw / sincos / the
 //                       first slot fetch); FSTAMP stores from every active lane (it sits in divergent code), the phase stamps 3..6 are off
 //   -DBSX_X_NOPACK      the per-lane item walk instead of the wave-packed bullet pass for every team size (same results)
+//   -DBSX_X_OBS=<0|1|2> the store form of the observation rows (below; same results)
 #pragma once
 
 #ifndef BSX_DIAG
@@ -22,6 +23,15 @@ constexpr bool PACK_BULLETS = false;
 #else
 constexpr bool PACK_BULLETS = true;
 #endif
+
+// how the observation rows of the per-step kernels leave (round 3's measurement of the 4v4 write side; same results):
+//   -DBSX_X_OBS=0  straight from registers, 16-byte non-temporal stores per lane + tail (the product)
+//   -DBSX_X_OBS=1  staged in LDS, transposed into fully coalesced 16-byte non-temporal stores
+//   -DBSX_X_OBS=2  staged in LDS; 4v4: lane j of a game writes the j-th 64-byte segment of the game's 448 bytes whole
+#ifndef BSX_X_OBS
+#define BSX_X_OBS 0
+#endif
+constexpr int OBS_FORM = BSX_X_OBS;
 
 #ifdef BSX_STAMPS
 constexpr int BUILD_FLAGS = int(DIAG & 0xFFu) | 0x100;

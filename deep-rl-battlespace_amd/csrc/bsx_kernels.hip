@@ -47,6 +47,7 @@
 constexpr unsigned DIAG = 0;
 constexpr int BUILD_FLAGS = 0;
 constexpr bool PACK_BULLETS = true;
+constexpr int OBS_FORM = 0;
 #define STAMP(i) do { } while (0)
 #define FSTAMP(i) do { } while (0)
 #define PSTAMP(i) do { } while (0)
@@ -1418,11 +1419,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // (rows are 4 (3n + 2) bytes apart, so the stores are only dword-aligned -- fine for global_store_dwordx4).  Round 1 staged
     // rows in LDS to emit fully coalesced 16-byte stores; with non-temporal stores that transpose only costs: C2 8.21 -> 7.92 us,
     // 4v4 28.0 -> 24.9 (-DBSX_X_LDSOBS builds it for A/B).  The fused rollout keeps its rows in LDS (the actor reads them there).
-#ifdef BSX_X_LDSOBS
-    constexpr bool DIRECT_OBS = false;
-#else
-    constexpr bool DIRECT_OBS = !ACTOR && N > 0;
-#endif
+    constexpr bool DIRECT_OBS = !ACTOR && N > 0 && OBS_FORM == 0;
     if constexpr (DIRECT_OBS) {
         constexpr int D = 3 * N + 2;
         float row[D];
@@ -1470,7 +1467,16 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (G == A && (reinterpret_cast<uintptr_t>(obs_t) & 15u) == 0) {
+        if (OBS_FORM == 2 && N == 4 && !ACTOR && (reinterpret_cast<uintptr_t>(obs_t) & 63u) == 0) {
+            // (variant builds, 4v4: a game's 8 rows are 448 contiguous bytes = seven 64-byte segments; lane j < 7 of the game writes
+            //  segment j whole -- four 16-byte stores into ONE aligned 64-byte sector instead of rows that straddle sectors)
+            if (valid && a < 7) {
+                float* gseg = obs_t + (gt - ix_t(a)) * ix_t(D) + 16 * a;
+                const float* sseg = &s_obs[gl * D + 16 * a];
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) out_store(reinterpret_cast<v4f_t*>(gseg + 4 * k4), *reinterpret_cast<const v4f_t*>(sseg + 4 * k4));
+            }
+        } else if (G == A && (reinterpret_cast<uintptr_t>(obs_t) & 15u) == 0) {
             // rows of this wave: global floats [base, base + rows*D); the wave's offset SPB*D*4 bytes is a multiple of 16
             const int64_t e_first = wblk * EPB;
             const int64_t rows = min(int64_t(SPB), (E_ - e_first) * A);
