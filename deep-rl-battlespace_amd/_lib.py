@@ -64,7 +64,7 @@ SIGNATURES = {
     "bsx_rollout_discrete": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, ctypes.POINTER(BsxRewards), c_uint32, ctypes.POINTER(BsxActorNoise), c_uint64,
                                      c_uint64, c_void_p, c_uint64, c_int64, c_void_p]),
-    "bsx_rollout_continuous": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+    "bsx_rollout_continuous": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_int, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, ctypes.POINTER(BsxRewards), c_uint32, ctypes.POINTER(BsxActorNoise), c_uint64,
                                        c_uint64, c_void_p, c_uint64, c_int64, c_void_p]),
     "bsx_observe": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),

@@ -396,6 +396,7 @@ struct StepArgs {
     int T; int64_t act_tb /* bytes */, u_ts, obs_ts, rew_ts, done_ts /* elements */;
     // fused rollout (bsx_rollout_discrete): the actor in front of every tick
     const float* aw; int aprec; int scripted_team /* -1 none, 0 red, 1 blue */; const float* obs0; float* scores; int64_t scores_ts; BsxActorNoise nz; uint64_t aseed, aseq; const uint64_t* aseq_base;
+    uint64_t iseed;                                      // continuous scripted opponent in the fused rollout: its Philox seed (bsx_instinct_continuous's `seed`)
 };
 
 // Observation row for one agent from the LDS-staged block (battle_env.py:202-244).
@@ -476,6 +477,26 @@ __device__ inline int instinct_choose(OB ob, int n, double& td, double& ta) {
         if (sc < best) { best = sc; td = d; ta = an; }
     }
     return (td < 250.0 && fabs(ta) < 20.0) ? 1 : (ta > 0.0 ? 3 : 2);   // agent.py:56-62
+}
+// The scripted opponent's continuous action (instinct/agent.py:41-54) for the chosen target at distance td / angle ta: shoot with
+// probability 0.6 inside 2/3 of the shot distance and 20 degrees, speed from the distance, turn toward the target, uniform(-0.15,
+// 0.15) noise on all three, clip.  Draws: row g of the launch, sequence number seq (bsx_instinct_continuous's keying).
+__device__ inline void instinct_continuous_draws(uint64_t seed, uint64_t seq, uint64_t g, double& r0, double& n0, double& n1, double& n2) {
+    const uint4 r = philox4x32_10(make_uint4(uint32_t(g), uint32_t(g >> 32) ^ 0x10000000u, uint32_t(seq), uint32_t(seq >> 32)),
+                                  make_uint2(uint32_t(seed), uint32_t(seed >> 32)));
+    r0 = double(r.x) * (1.0 / 4294967296.0);
+    n0 = -0.15 + 0.3 * (double(r.y) * (1.0 / 4294967296.0));
+    n1 = -0.15 + 0.3 * (double(r.z) * (1.0 / 4294967296.0));
+    n2 = -0.15 + 0.3 * (double(r.w) * (1.0 / 4294967296.0));
+}
+__device__ inline void instinct_continuous_action(double td, double ta, double r0, double n0, double n1, double n2, double& o0, double& o1, double& o2) {
+    double a2 = 0.0;
+    if (td < 500.0 / 3.0 * 2.0 && fabs(ta) < 20.0) a2 = r0 < 0.6 ? 1.0 : -1.0;
+    const double a0 = td / FIELD_DIAG * 2.0 - 1.0;
+    const double a1 = ta > 0.0 ? fmax(-ta / 35.0, -1.0) : fmin(-ta / 35.0, 1.0);
+    o0 = fmin(fmax(a0 + n0, -1.0), 1.0);
+    o1 = fmin(fmax(a1 + n1, -1.0), 1.0);
+    o2 = fmin(fmax(a2 + n2, -1.0), 1.0);
 }
 __device__ inline float4 one_hot_scores(int act) {               // what the score-vector step path arg-maxes back to `act`
     return make_float4(act == 0 ? 1.f : -1.f, act == 1 ? 1.f : -1.f, act == 2 ? 1.f : -1.f, act == 3 ? 1.f : -1.f);
@@ -573,6 +594,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     __shared__ __attribute__((aligned(16))) float s_small[ACTOR ? (N == 1 ? 4 : 2 * N) * bsx_actor::SMALL : 4];   // per-neuron vectors + heads of the actors (1v1: + the two value heads')
     __shared__ int s_act_all[(ACTOR && !CONT && WAVES > 1) ? WAVES * SPB : 1];       // arg-max per row, ACTOR with several waves
     __shared__ float s_actf_all[(ACTOR && CONT && WAVES > 1) ? WAVES * SPB * 3 : 1];  // continuous: [speed, turn, shoot] per row
+    __shared__ double s_actd_all[(ACTOR && CONT && WAVES > 1) ? WAVES * SPB * 3 : 1]; // ... of a scripted team's rows, binary64
     __shared__ int s_gdone_all[(ACTOR && WAVES > 1) ? 32 : 1];                       // game-over flag per game of the workgroup
     // n >= 2: every plane-to-plane pair is computed ONCE, by one of its two planes, and handed to the other through these
     __shared__ float s_pd_all[(N >= 2) ? WAVES * SPB * N : 1];      // range (symmetric)
@@ -780,7 +802,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
 #pragma nounroll
         for (int ti = 0; ti < 2; ++ti) {                 // one tile at a time: its 64 weight registers are reused by the next
             const int ag = wave + ti * WAVES;            // wave-uniform
-            if (ag >= A_ || (!CONT && p.scripted_team == (ag >= N ? 1 : 0))) continue;   // no such plane / played by the scripted opponent
+            if (ag >= A_ || p.scripted_team == (ag >= N ? 1 : 0)) continue;   // no such plane / played by the scripted opponent
             const float* const Wn = p.aw + size_t(ag) * bsx_actor::blob_floats(D);
             const float* const smn = s_small + ag * bsx_actor::SMALL;
             auto xb = [&](int k) { return k < D ? s_obs_all[(c * G_ + ag) * D + k] : 0.f; };
@@ -800,11 +822,18 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         if (WAVES > 1) game_over = s_gdone_all[c] != 0;
         else game_over = __shfl(er.done, 2 * c) != 0;
         if (p.nz.ou_keep) game_over = false;             // the evaluation loop never restarts its noise process (evaluate.py:52-76)
-        bool scripted_row = false;
-        if constexpr (!CONT) scripted_row = p.scripted_team == (mine_c >= N ? 1 : 0);
-        if (scripted_row) {                              // instinct/team.py:13-15 for this team's rows, as one-hot score rows
+        const bool scripted_row = p.scripted_team == (mine_c >= N ? 1 : 0);
+        double sd0 = 0.0, sd1 = 0.0, sd2 = 0.0;          // continuous: the scripted row's binary64 actions, as bsx_instinct_continuous writes them
+        if (scripted_row) {                              // instinct/team.py:13-15 for this team's rows
             double td_, ta_;
-            r4 = one_hot_scores(instinct_choose([&](int k) { return s_obs_all[(c * G_ + mine_c) * D + k]; }, N, td_, ta_));
+            const int sact = instinct_choose([&](int k) { return s_obs_all[(c * G_ + mine_c) * D + k]; }, N, td_, ta_);
+            if constexpr (!CONT) r4 = one_hot_scores(sact);                     // ... as one-hot score rows
+            else {
+                double r0, n0, n1, n2;
+                instinct_continuous_draws(p.iseed, aseq, uint64_t(row), r0, n0, n1, n2);
+                instinct_continuous_action(td_, ta_, r0, n0, n1, n2, sd0, sd1, sd2);
+                r4 = make_float4(float(sd0), float(sd1), float(sd2), 0.f);      // the record holds them rounded to float32; the step takes the binary64 values
+            }
         } else {
             r4 = bsx_actor::finish_row(r4, b3, p.nz, p.aseed, aseq, row, uint64_t(p.env_offset) * uint64_t(A) + row, game_over, row_ok,
                                        size_t(tk) * size_t(E_) * size_t(A) + row);
@@ -848,6 +877,20 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
                 f0 = __shfl(r4.x, src); f1 = __shfl(r4.y, src); f2 = __shfl(r4.z, src);
             }
             a0 = double(f0); a1 = double(f1); a2 = double(f2);
+            if (p.scripted_team >= 0) {                  // uniform: the scripted planes' binary64 actions travel the same way, unrounded
+                double d0_, d1_, d2_;
+                if (WAVES > 1) {
+                    __syncthreads();
+                    if (has_row) { double* q = &s_actd_all[(c * G_ + mine) * 3]; q[0] = sd0; q[1] = sd1; q[2] = sd2; }
+                    __syncthreads();
+                    const double* q = &s_actd_all[(wave * SPB + tid) * 3];
+                    d0_ = q[0]; d1_ = q[1]; d2_ = q[2];
+                } else {
+                    const int src = ((lane & 1) << 5) | (lane >> 1);
+                    d0_ = __shfl(sd0, src); d1_ = __shfl(sd1, src); d2_ = __shfl(sd2, src);
+                }
+                if (team == p.scripted_team) { a0 = d0_; a1 = d1_; a2 = d2_; }
+            }
         }
     }
 
@@ -1656,23 +1699,9 @@ __global__ __launch_bounds__(TPB) void bsx_instinct_kernel(const InstinctArgs p)
     }
     double r0, n0, n1, n2;                                        // agent.py:41-54
     if (p.rnd) { r0 = p.rnd[4 * g]; n0 = p.rnd[4 * g + 1]; n1 = p.rnd[4 * g + 2]; n2 = p.rnd[4 * g + 3]; }
-    else {
-        const uint64_t seq = p.seq + (p.seq_base ? *p.seq_base : 0ull);
-        const uint4 r = philox4x32_10(make_uint4(uint32_t(g), uint32_t(uint64_t(g) >> 32) ^ 0x10000000u, uint32_t(seq), uint32_t(seq >> 32)),
-                                      make_uint2(uint32_t(p.seed), uint32_t(p.seed >> 32)));
-        r0 = double(r.x) * (1.0 / 4294967296.0);
-        n0 = -0.15 + 0.3 * (double(r.y) * (1.0 / 4294967296.0));
-        n1 = -0.15 + 0.3 * (double(r.z) * (1.0 / 4294967296.0));
-        n2 = -0.15 + 0.3 * (double(r.w) * (1.0 / 4294967296.0));
-    }
-    double a2 = 0.0;
-    if (td < 500.0 / 3.0 * 2.0 && fabs(ta) < 20.0) a2 = r0 < 0.6 ? 1.0 : -1.0;
-    const double a0 = td / FIELD_DIAG * 2.0 - 1.0;
-    const double a1 = ta > 0.0 ? fmax(-ta / 35.0, -1.0) : fmin(-ta / 35.0, 1.0);
+    else instinct_continuous_draws(p.seed, p.seq + (p.seq_base ? *p.seq_base : 0ull), uint64_t(g), r0, n0, n1, n2);
     double* out = static_cast<double*>(p.actions) + 3 * g;
-    out[0] = fmin(fmax(a0 + n0, -1.0), 1.0);
-    out[1] = fmin(fmax(a1 + n1, -1.0), 1.0);
-    out[2] = fmin(fmax(a2 + n2, -1.0), 1.0);
+    instinct_continuous_action(td, ta, r0, n0, n1, n2, out[0], out[1], out[2]);
 }
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
@@ -1722,7 +1751,7 @@ int launch_step(void* state, int64_t E, int n, const void* actions, int action_k
     a.obs = obs; a.rew = rew; a.done = done; a.env_done = env_done; a.winner = winner; a.env_done_t = env_done_t;
     a.cfg = *cfg; a.flags = flags; a.seed = seed; a.env_offset = env_offset; a.tie_tick = bsx_tie_tick(n);
     const int64_t EA = E * 2 * n;
-    a.aw = nullptr; a.aprec = 0; a.scripted_team = -1; a.obs0 = nullptr; a.scores = nullptr; a.scores_ts = 0; a.nz = BsxActorNoise{};
+    a.aw = nullptr; a.aprec = 0; a.scripted_team = -1; a.iseed = 0; a.obs0 = nullptr; a.scores = nullptr; a.scores_ts = 0; a.nz = BsxActorNoise{};
     a.aseed = 0; a.aseq = 0; a.aseq_base = nullptr;
     a.T = T;
     a.act_tb = EA * (CONT ? (action_kind == BSX_ACT_F32 ? 12 : (action_kind == BSX_ACT_F64 ? 24 : 16)) : (action_kind == BSX_ACT_I32 ? 4 : 16));
@@ -1851,7 +1880,7 @@ void launch_rollout_w(int n, dim3 grid, hipStream_t s, const StepArgs& a) {
     }
 }
 template <bool CONT>
-int launch_rollout(void* state, int64_t E, int n, int T, const float* weights, int precision, int scripted_team, float* obs, float* scores, float* rew,
+int launch_rollout(void* state, int64_t E, int n, int T, const float* weights, int precision, int scripted_team, uint64_t scripted_seed, float* obs, float* scores, float* rew,
                    uint8_t* done, uint8_t* env_done, uint8_t* winner, uint8_t* env_done_t, const BsxRewards* cfg, uint32_t flags,
                    const BsxActorNoise* noise, uint64_t actor_seed, uint64_t seq, const uint64_t* seq_base, uint64_t seed,
                    int64_t env_offset, void* stream) {
@@ -1859,7 +1888,6 @@ int launch_rollout(void* state, int64_t E, int n, int T, const float* weights, i
         return BSX_E_ARG;
     if ((flags & BSX_F_EMPTY_CALL) || (precision != BSX_ACTOR_F32 && precision != BSX_ACTOR_BF16X3 && !(precision == BSX_ACTOR_BF16X6 && n == 1)) ||
         scripted_team < -1 || scripted_team > 1) return BSX_E_ARG;
-    if (CONT && scripted_team != -1) return BSX_E_ARG;
     if (!aligned(state, 256) || !aligned(weights, 16) || !aligned(scores, 16) || !aligned(obs, 4) || !aligned(rew, 4)) return BSX_E_ALIGN;
     BsxActorNoise nz = {};
     if (noise) nz = *noise;
@@ -1876,7 +1904,7 @@ int launch_rollout(void* state, int64_t E, int n, int T, const float* weights, i
     a.cfg = *cfg; a.flags = flags; a.seed = seed; a.env_offset = env_offset; a.tie_tick = bsx_tie_tick(n);
     a.T = T; a.act_tb = 0; a.u_ts = 0; a.obs_ts = EA * D; a.rew_ts = EA; a.done_ts = EA;
     a.aw = weights; a.aprec = precision; a.scripted_team = scripted_team; a.obs0 = obs; a.scores = scores; a.scores_ts = EA * 4; a.nz = nz; a.aseed = actor_seed; a.aseq = seq;
-    a.aseq_base = seq_base;
+    a.aseq_base = seq_base; a.iseed = scripted_seed;
     const dim3 grid(unsigned((E + 31) / 32));            // a workgroup = 32 games = G/2 waves
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (narrow_offsets_ok(E, n, flags)) launch_rollout_w<CONT, true>(n, grid, s, a);
@@ -1891,15 +1919,15 @@ int bsx_rollout_discrete(void* state, int64_t E, int n, int T, const float* weig
                          uint8_t* done, uint8_t* env_done, uint8_t* winner, uint8_t* env_done_t, const BsxRewards* cfg, uint32_t flags,
                          const BsxActorNoise* noise, uint64_t actor_seed, uint64_t seq, const uint64_t* seq_base, uint64_t seed,
                          int64_t env_offset, void* stream) {
-    return launch_rollout<false>(state, E, n, T, weights, precision, scripted_team, obs, scores, rew, done, env_done, winner, env_done_t, cfg, flags,
+    return launch_rollout<false>(state, E, n, T, weights, precision, scripted_team, 0, obs, scores, rew, done, env_done, winner, env_done_t, cfg, flags,
                                  noise, actor_seed, seq, seq_base, seed, env_offset, stream);
 }
 
-int bsx_rollout_continuous(void* state, int64_t E, int n, int T, const float* weights, int precision, float* obs, float* scores, float* rew,
+int bsx_rollout_continuous(void* state, int64_t E, int n, int T, const float* weights, int precision, int scripted_team, uint64_t scripted_seed, float* obs, float* scores, float* rew,
                            uint8_t* done, uint8_t* env_done, uint8_t* winner, uint8_t* env_done_t, const BsxRewards* cfg, uint32_t flags,
                            const BsxActorNoise* noise, uint64_t actor_seed, uint64_t seq, const uint64_t* seq_base, uint64_t seed,
                            int64_t env_offset, void* stream) {
-    return launch_rollout<true>(state, E, n, T, weights, precision, -1, obs, scores, rew, done, env_done, winner, env_done_t, cfg, flags,
+    return launch_rollout<true>(state, E, n, T, weights, precision, scripted_team, scripted_seed, obs, scores, rew, done, env_done, winner, env_done_t, cfg, flags,
                                 noise, actor_seed, seq, seq_base, seed, env_offset, stream);
 }
 

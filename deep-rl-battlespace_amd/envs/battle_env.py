@@ -466,7 +466,7 @@ class parallel_env:
         return obs, rew, done.view(torch.bool)
 
     def _launch_rollout(self, T, weights_ptr, precision, scripted_team, obs_ptr, scores_ptr, rew_ptr, done_ptr, noise, actor_seed, seq,
-                        seq_base_ptr, env_done_t_ptr=None):
+                        seq_base_ptr, env_done_t_ptr=None, scripted_seed=0):
         """Enqueue bsx_rollout_discrete / bsx_rollout_continuous: T ticks of (actor -> step) in one launch (rollout.PolicyRollout)."""
         if self.n_agents > 4:
             raise ValueError("the one-launch rollout is built for 1v1 ... 4v4")
@@ -476,10 +476,9 @@ class parallel_env:
                   self.env_offset, self._stream())
         with self._guard():
             if self.continuous_actions:
-                if int(scripted_team) != -1:
-                    raise ValueError("no scripted opponent in the continuous one-launch rollout")
                 _lib.check(self._lib.bsx_rollout_continuous(self._state.data_ptr(), self.n_envs, self.n_agents, int(T), weights_ptr,
-                                                            int(precision), obs_ptr, scores_ptr, rew_ptr, done_ptr, *common),
+                                                            int(precision), int(scripted_team), int(scripted_seed) & 0xFFFFFFFFFFFFFFFF,
+                                                            obs_ptr, scores_ptr, rew_ptr, done_ptr, *common),
                            "bsx_rollout_continuous")
             else:
                 _lib.check(self._lib.bsx_rollout_discrete(self._state.data_ptr(), self.n_envs, self.n_agents, int(T), weights_ptr,

@@ -29,7 +29,7 @@ class Team:
         self._cols = [env._idx[a] for a in self.agent_list]
         self._buf = None
 
-    def write_actions(self, out=None, obs=None, rnd=None, seq_base=None):
+    def write_actions(self, out=None, obs=None, rnd=None, seq_base=None, seq=None):
         """Fill this team's rows of `out` from the observation tensor (default: the env's own, i.e. what the last
         reset()/step() produced).  out: int32 [E, A] or float32 [E, A, 4] (one-hot +-1, for the score-vector step path)
         when discrete; float64 [E, A, 3] when continuous.  Returns `out`."""
@@ -56,10 +56,12 @@ class Team:
             rnd_t = None
             if rnd is not None:
                 rnd_t = torch.as_tensor(rnd, dtype=torch.float64, device=env.device).contiguous()
-            self.seq += 1
+            if seq is None:                                    # (a caller that captures the call into a graph passes its own number + a device word)
+                self.seq += 1
+                seq = self.seq
             _lib.check(self._lib.bsx_instinct_continuous(obs_ptr, out.data_ptr(),
                                                          rnd_t.data_ptr() if rnd_t is not None else None, E, env.n_agents,
-                                                         self.team, self.seed, self.seq,
+                                                         self.team, self.seed, int(seq),
                                                          seq_base.data_ptr() if seq_base is not None else None, stream),
                        "bsx_instinct_continuous")
             return out

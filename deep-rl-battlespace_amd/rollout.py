@@ -250,8 +250,6 @@ class PolicyRollout:
         self.continuous = bool(env.continuous_actions)
         if actor.n_actions != (3 if self.continuous else 4):
             raise ValueError("the actor must have 4 outputs for a discrete env (action scores), 3 for a continuous one")
-        if self.continuous and opponent is not None:
-            raise ValueError("the scripted opponent writes float64 [E, A, 3] actions: not combinable with the actor's rows")
         self.env, self.actor, self.T, self.noise_std = env, actor, int(T), float(noise_std)
         self.fused = FusedActor(actor, env.n_agents, seed=seed, precision=precision, env_offset=env.env_offset) if fused else None
         self.opponent = opponent
@@ -297,6 +295,9 @@ class PolicyRollout:
         # discrete: 4 action scores, arg-maxed in the step kernel; continuous: [speed, turn, shoot] + one unused column
         self.scores = torch.zeros((T, E, A, 4), dtype=torch.float32, device=dev)
         self._kind = _lib.ACT_F32X4 if self.continuous else _lib.ACT_LOGITS_F32
+        # continuous + scripted opponent, per-tick form: the reference hands the env float32 rows from the actors and float64 rows from
+        # instinct/agent.py:41-54 side by side; here the actors' rows are widened (exactly) into one float64 [E, A, 3] array next to them
+        self._act64 = torch.zeros((E, A, 3), dtype=torch.float64, device=dev) if (self.continuous and opponent is not None) else None
         self.rew = torch.empty((T, E, A), dtype=torch.float32, device=dev)
         self._done = torch.empty((T, E, A), dtype=torch.uint8, device=dev)
         self.done = self._done.view(torch.bool)
@@ -318,6 +319,16 @@ class PolicyRollout:
             sample = dict(self._sample, logp=self.logp[t]) if self._sample is not None else None
             value = dict(weights=self._value_w, out=self.value[t]) if self._value_w is not None else None
             self.fused.forward_into(self.obs[t], self.scores[t], self.noise_std, seq=t, seq_base=self._seq_base, ou=ou, sample=sample, value=value)
+            if self._act64 is not None:
+                cols = slice(self.opponent._cols[0], self.opponent._cols[-1] + 1)   # a team's planes are adjacent columns (a slice: nothing is uploaded while capturing)
+                self._act64.copy_(self.scores[t][..., :3])
+                self.opponent.write_actions(out=self._act64, obs=self.obs[t], seq=t, seq_base=self._seq_base)
+                self.scores[t][:, cols, :3] = self._act64[:, cols].float()      # the record: the scripted rows rounded to float32, as the one-launch form writes them
+                self.scores[t][:, cols, 3] = 0.0
+                self.env._launch(self._act64.data_ptr(), _lib.ACT_F64, False, None,
+                                 self.obs[t + 1].data_ptr(), self.rew[t].data_ptr(), self._done[t].data_ptr(),
+                                 env_done_ptr=self.env_done[t + 1].data_ptr())
+                return
             if self.opponent is not None:
                 self.opponent.write_actions(out=self.scores[t], obs=self.obs[t])
             self.env._launch(self.scores[t].data_ptr(), self._kind, False, None,
@@ -364,7 +375,8 @@ class PolicyRollout:
             self.env._launch_rollout(self.T, self.fused.weights.data_ptr(), self.fused.precision,
                                      -1 if self.opponent is None else self.opponent.team, self.obs.data_ptr(), self.scores.data_ptr(),
                                      self.rew.data_ptr(), self._done.data_ptr(), nz, self.fused.seed, 0, self._seq_base.data_ptr(),
-                                     env_done_t_ptr=self.env_done[1].data_ptr())
+                                     env_done_t_ptr=self.env_done[1].data_ptr(),
+                                     scripted_seed=0 if self.opponent is None else self.opponent.seed)
         else:
             for t in range(self.T):
                 self._tick(t)

@@ -225,8 +225,13 @@ int bsx_rollout_discrete(void* state, int64_t E, int n, int T, const float* weig
 /* The same loop for a continuous-action env (battle_env.py:295-297,418-424; the reference's own driver test_env.py:22-43 is
  * continuous): T x (bsx_actor_forward -> bsx_step_continuous with BSX_ACT_F32X4), bit for bit.  The actors have three outputs
  * [speed, turn, shoot] padded to the 4-wide rows (`scores` [T][E*A*4]: what was fed to the step; the fourth value is ignored).
- * No scripted opponent here: the reference's continuous instinct agent draws float64 actions with its own noise. */
-int bsx_rollout_continuous(void* state, int64_t E, int n, int T, const float* weights, int precision, float* obs, float* scores, float* rew,
+ *   scripted_team  -1 / 0 / 1 as above: that team's planes are played by the continuous scripted opponent (instinct/agent.py:41-54),
+ *            exactly as bsx_instinct_continuous computes them with seed = scripted_seed and sequence number seq + *seq_base + t for
+ *            tick t (row = e*A + a of this launch): binary64 actions that go to the step unrounded, as the reference's float64 arrays
+ *            do; their `scores` rows record them rounded to float32.  The per-tick equivalent: the actors' rows widened to binary64
+ *            next to bsx_instinct_continuous' rows in one BSX_ACT_F64 array. */
+int bsx_rollout_continuous(void* state, int64_t E, int n, int T, const float* weights, int precision, int scripted_team, uint64_t scripted_seed,
+                           float* obs, float* scores, float* rew,
                            uint8_t* done, uint8_t* env_done, uint8_t* winner, uint8_t* env_done_t, const BsxRewards* cfg, uint32_t flags,
                            const BsxActorNoise* noise, uint64_t actor_seed, uint64_t seq, const uint64_t* seq_base,
                            uint64_t seed, int64_t env_offset, void* stream);

@@ -325,9 +325,48 @@ def test_one_launch_continuous_rollout_equals_two_kernel_rollout(noise, n):
         assert torch.equal(sa[k], sb[k]), k
     assert int(a.env.counters()[:, 0].sum()) >= E                # the runs crossed game ends
     assert float(b.scores[..., 2].max()) > 0 and float(b.scores[..., 2].min()) < 0      # some planes fire, some do not
-    with pytest.raises(ValueError):                              # no scripted opponent in continuous mode (it writes float64 rows)
-        from deep_rl_battlespace_amd import instinct
-        PolicyRollout(a.env, actor, T, one_launch=True, opponent=instinct.Team(a.env.possible_blue, a.env.possible_red, a.env))
+
+
+@pytest.mark.parametrize("n,scripted", [(1, "blue"), (2, "blue"), (4, "red")])
+def test_one_launch_continuous_rollout_plays_the_scripted_opponent_in_kernel(n, scripted):
+    """The reference's only continuous driver is instinct-vs-instinct (test_env.py:22-43); a learned team against the continuous
+    scripted opponent (instinct/agent.py:41-54) hands the env float32 rows from the actors next to float64 rows from the script.
+    Per-tick form: actor kernel -> the actors' rows widened into one float64 [E, A, 3] array -> bsx_instinct_continuous fills its
+    team's rows (Philox: its seed, sequence number tick + replay counter) -> bsx_step_continuous(BSX_ACT_F64).  One-launch form:
+    bsx_rollout_continuous with scripted_team: that team's actor tiles are skipped, its binary64 actions are computed from the LDS
+    observation rows with the same draws and reach the step unrounded.  Same transitions bit for bit, over runs and auto-resets."""
+    from deep_rl_battlespace_amd import instinct
+    from deep_rl_battlespace_amd.rollout import PolicyRollout, StackedActor
+    E, T = (4100 if n == 1 else 1030), 40
+    torch.manual_seed(17)
+    actor = StackedActor(2 * n, 3 * n + 2, 3, device="cuda")
+    with torch.no_grad():
+        actor.w3.mul_(60.0)
+    ros = []
+    for one in (False, True):
+        env = _env(n_agents=n, n_envs=E, seed=33, auto_reset=True, continuous_actions=True); env.reset()
+        opp = instinct.Team(env.possible_blue, env.possible_red, env, seed=91) if scripted == "blue" else instinct.Team(env.possible_red, env.possible_blue, env, seed=91)
+        ro = PolicyRollout(env, actor, T, seed=7, noise_std=0.2, one_launch=one, opponent=opp); ro.start(); ro.capture()
+        ros.append(ro)
+    a, b = ros
+    cols = a.opponent._cols
+    for rep in range(5):
+        a.run(); b.run()
+        torch.cuda.synchronize()
+        assert torch.equal(a.obs, b.obs), rep
+        assert torch.equal(a.scores, b.scores), rep
+        assert torch.equal(a.rew, b.rew) and torch.equal(a.done, b.done) and torch.equal(a.env_done, b.env_done), rep
+    sa, sb = a.env.export_state(), b.env.export_state()
+    for k in ("px", "py", "pdir", "php", "bhp", "tick", "env_done", "winner", "bl_live", "bl_x", "bl_y", "bl_dir", "counters"):
+        assert torch.equal(sa[k], sb[k]), k
+    c = a.env.counters().sum(0)
+    assert c[0] >= E and (c[2] + c[3]) > 0.2 * c[0]               # the runs crossed game ends, and a share of them were decided by play
+    sc = b.scores[:, :, cols]
+    assert float(sc[..., 3].abs().max()) == 0.0 and float(sc[..., :3].abs().max()) <= 1.0
+    assert 0.02 < float((sc[..., 2] > 0).float().mean()) < 0.9    # the script fires inside its cone with probability 0.6, not otherwise
+    # draws differ from run to run (the replay counter is part of the key): the same tick of two runs is not the same row
+    x1 = b.scores[5][:, cols].clone(); b.run(); torch.cuda.synchronize()
+    assert not torch.equal(x1, b.scores[5][:, cols])
 
 
 @pytest.mark.parametrize("n,cont", [(1, False), (3, False), (2, True)])
