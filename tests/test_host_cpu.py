@@ -57,9 +57,21 @@ def test_bad_arguments_are_rejected_before_any_launch():
     assert lib.bsx_rollout_discrete(ok, 4, 1, 8, ok, 7, -1, ok, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1
     assert lib.bsx_rollout_discrete(ok, 4, 1, 8, ok, 0, 2, ok, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1
     assert lib.bsx_rollout_discrete(ok, 4, 2, 8, ok, 2, -1, ok, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1   # bf16x6 in one launch: 1v1 only
-    assert lib.bsx_rollout_continuous(ok, 4, 5, 8, ok, 0, ok, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1
+    assert lib.bsx_rollout_continuous(ok, 4, 5, 8, ok, 0, -1, 0, ok, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1
+    assert lib.bsx_rollout_continuous(ok, 4, 1, 8, ok, 0, 2, 0, ok, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1   # scripted_team out of range
     nz = L.BsxActorNoise(0.1, 0.0, 0.15, 0.2, 0.0, None, None, ctypes.c_void_p(4096))     # injected normals are per call: not for a T-tick launch
-    assert lib.bsx_rollout_continuous(ok, 4, 1, 8, ok, 0, ok, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, ctypes.byref(nz), 0, 0, None, 0, 0, None) == -1
+    assert lib.bsx_rollout_continuous(ok, 4, 1, 8, ok, 0, -1, 0, ok, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, ctypes.byref(nz), 0, 0, None, 0, 0, None) == -1
+    # the policy-gradient heads: a categorical head needs a temperature and discrete actions; a value head rides in the 1v1 one-launch kernel only
+    nz = L.BsxActorNoise(); nz.sample_mode = 1
+    assert lib.bsx_actor_forward(ok, ok, ok, 4, 1, 0, ctypes.byref(nz), 0, 0, None, 0, None) == -1                  # temperature 0
+    nz.temperature = 1.0
+    assert lib.bsx_rollout_continuous(ok, 4, 1, 8, ok, 0, -1, 0, ok, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, ctypes.byref(nz), 0, 0, None, 0, 0, None) == -1
+    nz = L.BsxActorNoise(); nz.value_weights = 4096
+    assert lib.bsx_actor_forward(ok, ok, ok, 4, 1, 0, ctypes.byref(nz), 0, 0, None, 0, None) == -1                  # value head without an output
+    nz.value = 4096
+    assert lib.bsx_rollout_discrete(ok, 4, 2, 8, ok, 0, -1, ok, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, ctypes.byref(nz), 0, 0, None, 0, 0, None) == -1
+    dp = ctypes.c_void_p()
+    assert lib.bsx_host_device_pointer(None, ctypes.byref(dp)) == -1
     assert lib.bsx_actor_forward(ok, ok, ok, 4, 1, 7, None, 0, 0, None, 0, None) == -1
     assert lib.bsx_actor_forward(ok, ok, ok, 4, 1, 0, None, 0, 0, None, -5, None) == -1   # negative env_offset
     assert lib.bsx_build_flags() == 0                                                      # the in-tree library is the product build

@@ -199,3 +199,56 @@ def test_ou_fixture_is_the_reference_recursion():
         x = x + theta * (mu - x) + sigma * g["z"][t]
         np.testing.assert_allclose(g["state"][t], x, rtol=0, atol=1e-15)
         np.testing.assert_allclose(g["noise"][t], x * scale, rtol=0, atol=1e-15)
+
+
+def test_shipped_checkpoints_forward_and_evaluation_tally_fixture():
+    """Fixture g12 (the reference's evaluation workload, evaluate.py:14-109, run unmodified by make_golden.py): the stacked module
+    loaded with the SHIPPED checkpoints' weights (models/completed_model/actor_plane0, actor_plane1) reproduces the reference
+    ActorNetwork.forward on the observation rows met in the reference's own play; the recorded tally is self-consistent and the
+    reward config is cf.json's."""
+    from deep_rl_battlespace_amd.rollout import reference_checkpoint_actor
+    z = np.load(os.path.join(GOLDEN, "g12_evaluation.npz"))
+    n = int(z["n_agents"])
+    assert n == 2 and z["cf"].tolist() == [1.0, 0.9, -0.02, -0.03, -0.05]
+    actor = reference_checkpoint_actor(z, n, device="cpu")
+    x = torch.stack([torch.from_numpy(z[f"plane{i % n}/x"]) for i in range(2 * n)], 1)
+    with torch.no_grad():
+        out = actor(x)
+    for i in range(2 * n):
+        np.testing.assert_allclose(out[:, i].numpy(), z[f"plane{i % n}/y"], rtol=0, atol=2e-5)      # float32, another summation order
+    games, ties, red, blue = (int(z[k]) for k in ("games", "ties", "red_wins", "blue_wins"))
+    assert games == ties + red + blue and games >= 3000 and 0.75 < red / games < 0.90        # README.md:30: "~80%"
+    assert z["calls_per_game"].min() >= 1 and z["calls_per_game"].max() <= 141               # a 2v2 game ends at the latest on call 141
+
+
+def test_value_head_packs_like_an_actor_with_one_output():
+    """A value head is a StackedActor with ONE output per agent: pack() pads its head to the 4-wide rows the kernels read (columns
+    1-3 and their biases zero), and forward(squash=False) returns the raw head."""
+    from deep_rl_battlespace_amd.rollout import StackedActor
+    torch.manual_seed(2)
+    A, D = 4, 8
+    critic, actor = StackedActor(A, D, 1), StackedActor(A, D, 4)
+    with torch.no_grad():
+        actor.w3[:, :, 0] = critic.w3[:, :, 0]; actor.b3[:, :, 0] = critic.b3[:, :, 0]
+        actor.w3[:, :, 1:] = 0; actor.b3[:, :, 1:] = 0
+        for k in ("w1", "b1", "g1", "h1", "w2", "b2", "g2", "h2"):
+            getattr(actor, k).copy_(getattr(critic, k))
+    assert torch.equal(critic.pack(), actor.pack())
+    obs = torch.rand(16, A, D) * 2 - 1
+    with torch.no_grad():
+        assert torch.allclose(critic(obs, squash=False)[..., 0], actor(obs, squash=False)[..., 0])
+        assert torch.allclose(torch.tanh(critic(obs, squash=False)), critic(obs))
+
+
+def test_roofline_claim_and_live_aware_bytes():
+    """bench.py's roofline bookkeeping: the claimed fraction is the smaller of the contract fraction and the one on measured traffic,
+    a contract fraction above 1 is never printed, and the live-bullet-aware byte count of this layout sits between the API-only bound
+    and the 12-slot contract formula."""
+    import bench
+    assert bench.claim(0.59, 0.29) == (0.29, 0.59) and bench.claim(0.3, 0.5) == (0.3, 0.3)
+    assert bench.claim(1.15, 0.21) == (0.21, None) and bench.claim(0.45, None) == (0.45, 0.45)
+    for n in (1, 4):
+        lo, hi = bench.b_io(n), bench.b_alg(n)
+        assert lo < bench.b_live(n, 0.57, 0.25) < hi
+        assert abs(bench.b_live(n, 1.0, 0.0) - bench.b_live(n, 0.0, 0.0) - 12.0) < 1e-9      # 8 B read + 4 B written per live bullet
+    assert abs(bench.b_alg(1) - 260.0) < 1e-9 and abs(bench.b_alg(4) - 289.25) < 1e-9      # (SURVEY.md section 8d rounds it to 289.3)
