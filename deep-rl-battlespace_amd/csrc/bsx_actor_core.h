@@ -121,9 +121,12 @@ __device__ inline float4 uniforms4(uint64_t seed, uint64_t seq, uint64_t grow, u
 // own draw (salt) -- the OU increment and the white term are independent.  `store`: this lane owns a real row.
 // sample_mode 1 (categorical policy): the row becomes scores / temperature + Gumbel noise -- its arg-max is a draw from
 // softmax(scores / temperature) -- and the drawn action's log-probability goes to nz.logp[orow] (orow: the row in a [T][E*A] record).
-__device__ inline float4 finish_row(float4 r4, const float4 b3, const BsxActorNoise& nz, uint64_t seed, uint64_t seq,
+template <class NZ>   // BsxActorNoise, in whatever address space the caller holds it (the fused kernels read it from the kernarg segment)
+__device__ inline float4 finish_row(float4 r4, const float4 b3, const NZ& nz, uint64_t seed, uint64_t seq,
                                     size_t row, uint64_t grow, bool game_over, bool store, size_t orow) {
-#pragma clang fp contract(fast)
+    // No implicit contraction in here: the stand-alone actor kernel and the fused rollout must produce the same bits, and which
+    // multiply the back end would fuse into which add depends on the code around the call.  Every fused operation is spelled out.
+#pragma clang fp contract(off)
     r4.x = tanhf(r4.x + b3.x); r4.y = tanhf(r4.y + b3.y); r4.z = tanhf(r4.z + b3.z); r4.w = tanhf(r4.w + b3.w);
     if (nz.gaussian_std > 0.f || nz.ou_scale > 0.f) {
         const float4 z = nz.z_inject ? reinterpret_cast<const float4*>(nz.z_inject)[row] : normals4(seed, seq, grow, 0u);
@@ -131,10 +134,10 @@ __device__ inline float4 finish_row(float4 r4, const float4 b3, const BsxActorNo
             float4* xs = reinterpret_cast<float4*>(nz.ou_state) + row;
             float4 x = *xs;
             if (game_over) x = make_float4(nz.ou_mu, nz.ou_mu, nz.ou_mu, nz.ou_mu);
-            x.x += nz.ou_theta * (nz.ou_mu - x.x) + nz.ou_sigma * z.x;
-            x.y += nz.ou_theta * (nz.ou_mu - x.y) + nz.ou_sigma * z.y;
-            x.z += nz.ou_theta * (nz.ou_mu - x.z) + nz.ou_sigma * z.z;
-            x.w += nz.ou_theta * (nz.ou_mu - x.w) + nz.ou_sigma * z.w;
+            x.x += fmaf(nz.ou_theta, nz.ou_mu - x.x, nz.ou_sigma * z.x);
+            x.y += fmaf(nz.ou_theta, nz.ou_mu - x.y, nz.ou_sigma * z.y);
+            x.z += fmaf(nz.ou_theta, nz.ou_mu - x.z, nz.ou_sigma * z.z);
+            x.w += fmaf(nz.ou_theta, nz.ou_mu - x.w, nz.ou_sigma * z.w);
             if (store) *xs = x;
             r4.x = fmaf(nz.ou_scale, x.x, r4.x); r4.y = fmaf(nz.ou_scale, x.y, r4.y);
             r4.z = fmaf(nz.ou_scale, x.z, r4.z); r4.w = fmaf(nz.ou_scale, x.w, r4.w);

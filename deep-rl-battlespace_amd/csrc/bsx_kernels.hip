@@ -559,7 +559,8 @@ template <class T> __device__ inline T* elem(T* base, size_t i) { return base + 
 template <int N, bool CONT, bool MULTI, bool ACTOR = false, bool LG = false, bool OFF32 = false>
 __global__ __launch_bounds__(SPB * (ACTOR ? group_width(N > 0 ? N : 1) / 2 : WPB)) __attribute__((amdgpu_waves_per_eu((ACTOR && N > 1) ? 2 : 1)))
 void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* const cnt_, const PlaneRec* const plane_, const void* const act_,
-                     const int kind_, const StepArgs p) {
+                     const int kind_, const StepArgs p_) {
+    const StepArgs& p = p_;                              // (the tick loop of the multi-tick forms shadows this name: see there)
     // The six leading arguments repeat p.E, p.st.env, p.st.cnt, p.st.plane, p.actions, p.action_kind: eleven dwords that the
     // dispatcher preloads into SGPRs (-amdgpu-kernarg-preload-count), so that a wave's first loads need nothing from the
     // kernarg segment and do not queue behind its cold scalar-cache fetch.
@@ -758,6 +759,17 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // instead of registers held across the actor's matrix products -- with them hoisted the kernels spilled to scratch memory.
     int tid_k = tid;
     if constexpr (ACTOR && N > 1) asm volatile("" : "+v"(tid_k));
+    // The kernel's arguments likewise: ~60 scalar registers of pointers, strides and reward constants were held across the tick
+    // loop, ~40 of them spilled to VGPR lanes before it and read back one v_readlane at a time in every tick (78 of them at
+    // 1v1).  Inside a tick the arguments are read through the kernarg segment's own address, made opaque per tick: scalar loads
+    // of 4 ... 16 dwords next to their use, nothing carried.  (StepArgs follows six leading arguments: 5 x 8 + 4 bytes, padded to 48.)
+    typedef const StepArgs __attribute__((address_space(4))) StepArgsK;
+    static_assert(alignof(StepArgs) == 8, "kernarg offset of StepArgs");
+    const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    if (MULTI) asm volatile("" : "+s"(ka));
+    // (the one-call kernels keep the parameter itself: their argument fetch is placed by hand in the shadow of the first loads, and
+    //  through the segment pointer it measured slower -- C2 7.21 -> 7.37 us, 4v4 23.4 -> 27.3)
+    auto& p = [&]() -> decltype(auto) { if constexpr (MULTI) return (*reinterpret_cast<StepArgsK*>(ka + 48)); else return (p_); }();
     const int tid = tid_k, lane = tid, a = tid & (G - 1);
     const int gl = tid & ~(G - 1);                       // first thread of my env's group
     const int team = (a < n) ? 0 : 1;                    // 0 red, 1 blue
