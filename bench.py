@@ -29,13 +29,15 @@ HIP graphs holding G = min(K, --graph-len) consecutive step() launches (the laun
 eager` times one Python call per step instead); the action table always spans --graph-len ticks and a short block walks
 through it slice by slice, so the workload does not depend on K.  Rank 0 prints ONE JSON line.
 
-roofline: the step kernel is HBM-bound integer/fp64 work.  achieved = ALGORITHMIC bytes per launch (SURVEY.md section 8d:
-260 B per agent-step at 1v1, 289.3 B at 4v4, x E*A agent-steps per launch) / the kernel's average launch duration (B).
-peak = 8 TB/s.  frac = achieved / peak is the contract figure; frac_on_traffic beside it is the same duration against the
-bytes that actually reached HBM: PMC FETCH_SIZE x 2 + WRITE_SIZE, collected by two child runs of this script under
-`rocprofv3 --kernel-trace --pmc` (one counter per pass, as MI355X_MICROARCH.md prescribes) right after the timed region --
-the counters cannot be read from inside this process; `traffic_source` says so, or names the profiles/traffic.json
-series that was used instead (`--no-live-traffic`, no rocprofv3, N > 1; always for `other_workloads`).
+roofline: the step kernel is HBM-bound integer/fp64 work by the contract's accounting.  achieved = ALGORITHMIC bytes per launch
+(260 B per agent-step at 1v1, 289.3 B at 4v4, x E*A agent-steps per launch) / the kernel's average launch
+duration (B); peak = 8 TB/s; frac = achieved / peak is the contract figure (printed as null when it exceeds 1: the 12-slot count is
+then more than the launch moves).  frac_on_traffic is the same duration against the bytes that actually reached HBM: PMC
+FETCH_SIZE x 2 + WRITE_SIZE, collected by two child runs of this script under `rocprofv3 --kernel-trace --pmc` (one counter per
+pass, as MI355X_MICROARCH.md prescribes) right after the timed region -- the counters cannot be read from inside this process;
+`traffic_source` says so, or names the profiles/traffic.json series that was used instead (`--no-live-traffic`, no rocprofv3, a
+profiler already attached, N > 1; always for `other_workloads`).  frac_claimed = min(frac, frac_on_traffic) is the figure to quote;
+live_aware_bytes_per_launch is what this build's layout must move with the measured bullet load (b_live below).
 cpu_baseline: the CPU oracle (oracle/battlespace_ref.py, the scalar Python restatement of the reference's step()) on
 configs[0] -- 1 game of 1v1, the same uniform random actions, reset on done -- timed on one host core of this box.
 """
