@@ -1020,7 +1020,12 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // LDS round trip are exposed here, and the loads leave ~1.5k cycles (Philox + sincos) earlier; they are what the bullet
     // rounds wait for, and the move + observation geometry alone are shorter than a round trip to the MALL / HBM
     if constexpr (PACK) cur = fetch_slot(0);
-    double2 nd = make_double2(0.0, 0.0);                 // this call's shot: float64 step, step code
+    // 1v1 discrete: the shot's step from the heading table by angle addition instead of a float64 sincos (below).  Larger teams keep
+    // the sincos: there the shorter shot measured SLOWER (4v4 23.3 -> 25.3 us, two runs each) -- the table entry it needs arrives
+    // later than the ~110 instructions of the sincos take, and nothing else is left to cover it.
+    constexpr bool CHEAP_SHOT = !CONT && N == 1;
+    double2 nd = make_double2(0.0, 0.0);                 // this call's shot: float64 step (CHEAP_SHOT: to ~1e-8 unless flagged exact), step code, heading
+    double nbdir = 0.0;
     uint32_t ncode = 0u;
     bool nexact = false;
     if (spawn) {
@@ -1029,13 +1034,28 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
             const uint4 r = draw4(seed_t, genv, STREAM_JITTER, uint32_t(games), (uint32_t(tick) << 8) | uint32_t(a));
             uu = uniform53(r.x, r.y);
         }
-        const double bdir = d0 + (uu * 8.0 - 4.0);
-        double sn, cs;
-        if (DIAG & 16u) { float sf, cf; __sincosf(float(-(bdir * DEG2RAD)), &sf, &cf); sn = double(sf); cs = double(cf); }   // timing ablation: a few-instruction float sincos (directions right to ~1e-6, so the same bullet population)
-        else sincos(-(bdir * DEG2RAD), &sn, &cs);
-        nd = make_double2(BULLET_STEP * cs, BULLET_STEP * sn);
+        const double jit = uu * 8.0 - 4.0;
+        nbdir = d0 + jit;
+        if constexpr (CHEAP_SHOT) {
+            // Discrete headings are whole degrees and a shooter does not turn, so (21.5 cos d0, -21.5 sin d0) is the heading-table
+            // entry `dl` this lane gathered for its move; the jitter is at most 4 degrees.  The integer step code only needs the
+            // step to ~2^-18 (step_code's guard is wider than any error here), so the common path takes it from the angle-addition
+            // formulas with two-term series for the jitter -- |error| < 1e-8 on 45 cos -- instead of a float64 sincos of ~110
+            // instructions.  A shot the code flags as not provably exact (one in ~30 000) gets the library sincos below, behind the
+            // wave-uniform branch of the exact path; every other shot's integer moves are those of the exact step (same floor, the
+            // fraction far from 0 and 1), so the results do not change.
+            const double jr = jit * DEG2RAD, t = jr * jr;
+            const double cj = __builtin_fma(t, __builtin_fma(t, 1.0 / 24.0, -0.5), 1.0);
+            const double sj = jr * __builtin_fma(t, __builtin_fma(t, 1.0 / 120.0, -1.0 / 6.0), 1.0);
+            constexpr double K45 = BULLET_STEP / 21.5;
+            nd = make_double2(K45 * __builtin_fma(dl.x, cj, dl.y * sj), K45 * __builtin_fma(dl.y, cj, -(dl.x * sj)));
+        } else {
+            double sn, cs;
+            sincos(-(nbdir * DEG2RAD), &sn, &cs);
+            nd = make_double2(BULLET_STEP * cs, BULLET_STEP * sn);
+        }
         ncode = step_code(nd.x, nd.y, nexact);
-        st_store<NT_STATE>(elem(p.st.bdir, ix_t(ks) * EAt + gt), bdir);       // ring by birth tick: never moves, read only by bsx_export_state
+        st_store<NT_STATE>(elem(p.st.bdir, ix_t(ks) * EAt + gt), nbdir);      // ring by birth tick: never moves, read only by bsx_export_state
         xf |= nexact ? 1u : 0u;                          // rare (step_code): this bullet moves by the float64 sum
     }
     // does any bullet this wave is about to update take the float64 path?  Asked once, here, long before anything branches on it
@@ -1099,6 +1119,11 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     if (wave_exact) {                                    // wave-uniform and rare: a flagged shot leaves its float64 step in the ring (and in LDS for its first update)
         if constexpr (N == 1) asm volatile("");          // (keeps this a scalar branch; see the bullet rounds)
         if (spawn && nexact) {
+            if constexpr (CHEAP_SHOT) {                  // the exact float64 step, as Bullet.update evaluates it (sprites.py:35-42,330-333)
+                double sn, cs;
+                sincos(-(nbdir * DEG2RAD), &sn, &cs);
+                nd = make_double2(BULLET_STEP * cs, BULLET_STEP * sn);
+            }
             *elem(p.st.bd, ix_t(ks) * EAt + gt) = nd;
             if constexpr (PACK) { s_nd[2 * tid] = nd.x; s_nd[2 * tid + 1] = nd.y; }
         }
