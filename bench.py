@@ -737,6 +737,7 @@ def rollout_lines(dev, E, K):
                 ("one launch, red = actor vs blue = scripted instinct opponent (main.py:119-122)", dict(one_launch=True), True, False),
                 ("PPO-shaped rollout, one launch: categorical draw from softmax(scores) + log-prob + value head per plane", dict(one_launch=True, sample="categorical", value=True), False, False),
                 ("PPO-shaped rollout, graph of 2 kernels per tick: categorical draw + log-prob + value head", dict(sample="categorical", value=True), False, False),
+                ("PPO-shaped rollout, one launch, both MLPs' 64x64 layers as three bf16 matrix products of two-term splits", dict(one_launch=True, sample="categorical", value=True, precision="bf16x3"), False, False),
                 ("continuous actions: graph of 2 kernels per tick", dict(), False, True),
                 ("continuous actions: one launch for all ticks", dict(one_launch=True), False, True)]
     for tag, kw, scripted, cont in variants:

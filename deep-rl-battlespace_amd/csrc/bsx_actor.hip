@@ -164,7 +164,8 @@ __global__ __launch_bounds__(TPB) void bsx_actor_kernel(const ActorArgs p) {
     r4 = finish_row(r4, b3, p.nz, p.seed, seq, row, uint64_t(p.env_offset) * uint64_t(p.A) + row, game_over, e < p.E, row);
     if (e < p.E) reinterpret_cast<float4*>(p.scores)[row] = r4;
     if (p.nz.value_weights) {
-        // ---- the value head: a second MLP of the same shape on the same rows, exact float32, one 32-row tile at a time; its
+        // ---- the value head: a second MLP of the same shape on the same rows, in the same precision mode (per-tile code of
+        //      bsx_actor_core.h, which the fused rollout runs as well: same bits), one 32-row tile at a time; its
         //      per-neuron vectors and head take the place of the actor's in LDS (every lane is done with them)
         const float* __restrict__ Wv = p.nz.value_weights + size_t(a) * blob_floats(D);
         __syncthreads();
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(TPB) void bsx_actor_kernel(const ActorArgs p) {
             const float* xr = p.obs + (size_t(en < p.E ? en : p.E - 1) * p.A + a) * D;
             const float* Wn = Wv;
             asm volatile("" : "+s"(Wn));
-            const float4 t = tile_forward<BSX_ACTOR_F32>(Wn, s_small, D, lane, [&](int k) { return k < D ? xr[k] : 0.f; });
+            const float4 t = tile_forward<PREC>(Wn, s_small, D, lane, [&](int k) { return k < D ? xr[k] : 0.f; });
             if (nt == 0) v[0] = t; else v[1] = t;
         }
         const float vh = hh ? v[1].x : v[0].x;

@@ -852,15 +852,18 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         }
         if constexpr (N == 1) {
             if (p.nz.value_weights) {
-                // ---- the value head (1v1): a second MLP of the actor's shape on the same LDS rows, exact float32; its per-neuron
-                //      vectors and head sit behind the actors' in LDS
+                // ---- the value head (1v1): a second MLP of the actor's shape on the same LDS rows, in the actors' precision mode; its
+                //      per-neuron vectors and head sit behind the actors' in LDS
                 float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma nounroll
                 for (int ti = 0; ti < 2; ++ti) {
                     const float* const Wn = p.nz.value_weights + size_t(ti) * bsx_actor::blob_floats(D);
                     const float* const smn = s_small + (2 + ti) * bsx_actor::SMALL;
                     auto xb = [&](int k) { return k < D ? s_obs_all[(c * G_ + ti) * D + k] : 0.f; };
-                    const float4 o = bsx_actor::tile_forward<BSX_ACTOR_F32>(Wn, smn, D, lane, xb);
+                    float4 o;                            // the 64 x 64 layer in the actors' precision mode (uniform branches)
+                    if (p.aprec == BSX_ACTOR_BF16X3) o = bsx_actor::tile_forward<BSX_ACTOR_BF16X3>(Wn, smn, D, lane, xb);
+                    else if (p.aprec == BSX_ACTOR_BF16X6) o = bsx_actor::tile_forward<BSX_ACTOR_BF16X6>(Wn, smn, D, lane, xb);
+                    else o = bsx_actor::tile_forward<BSX_ACTOR_F32>(Wn, smn, D, lane, xb);
                     if (hh == ti) v4 = o;
                 }
                 if (row_ok) p.nz.value[size_t(tk) * size_t(E_) * size_t(A) + row] = v4.x + s_small[(2 + mine_c) * bsx_actor::SMALL + 6 * bsx_actor::H + bsx_actor::H * bsx_actor::NA];

@@ -187,7 +187,7 @@ typedef struct BsxActorNoise {
     const float* u_inject;    /* nullable float32 [E*A*4], 16-byte aligned: the uniforms to use instead of the Philox draws (bsx_actor_forward only: tests) */
     const float* value_weights; /* nullable: a second MLP per agent of the actor's shape (obs -> 64 -> LayerNorm -> ReLU -> 64 -> LayerNorm -> ReLU -> 1,
                                  the widths of maddpg/networks.py:14-52's critic on the agent's own observation), packed like `weights`
-                                 (head column 0 = the value, columns 1-3 zero); evaluated in exact float32 on the rows the actor reads */
+                                 (head column 0 = the value, columns 1-3 zero); evaluated in the call's `precision` mode on the rows the actor reads */
     float* value;             /* float32 [E*A] (bsx_rollout_*: [T][E*A]), required with value_weights: V(obs) = head + bias, no tanh.
                                  bsx_rollout_* take a value head for n = 1 only (the per-tick form for any n). */
 } BsxActorNoise;

@@ -130,7 +130,11 @@ class Recorder:
         mark = len(tap.ints)
         obs = env.reset()
         assert not tap.force_ints
-        draws = tap.ints[mark:]
+        return self.adopt_reset(obs, tap.ints[mark:])
+
+    def adopt_reset(self, obs, draws):
+        """Book an episode start from a reset() that has just happened (draws: the randint values it consumed)."""
+        env = self.env
         assert len(draws) == 4 + 3 * self.A
         # what the env actually holds (dir after the red fold)
         sp = [*env.team["red"]["base"].rect.center, *env.team["blue"]["base"].rect.center]
@@ -154,11 +158,15 @@ class Recorder:
             self.ep_ptr.append(len(self.rows["obs"]))
 
     # -- one step() call
-    def step(self, actions, logits=None, empty=False):
-        """actions: list per agent (ints, or 3-vectors when continuous); logits: optional [A,4]."""
+    def step(self, actions, logits=None, empty=False, call=None, stepper=None):
+        """actions: list per agent (ints, or 3-vectors when continuous); logits: optional [A,4].
+        call / stepper: the dict a foreign driver handed to step() and the bound method to run it with (the evaluation fixture
+        records calls that evaluate.main() makes; `actions` then holds the integers the env reduces that dict to)."""
         env, tap, ids = self.env, self.tap, self.ids
         alive_before = list(env.agents)
-        if empty:
+        if call is not None:
+            pass
+        elif empty:
             call = {}
         elif logits is not None:
             call = {a: np.asarray(logits[i], dtype=np.float64) for i, a in enumerate(ids)}
@@ -169,7 +177,7 @@ class Recorder:
         mark = len(tap.floats)
         bullets_before = len(env.bullets)
         was_done = env.env_done
-        obs, rew, done, info = env.step(call)
+        obs, rew, done, info = (stepper or env.step)(call)
         draws = tap.floats[mark:]
         # attribute each random() draw to the agent whose shot consumed it: alive-agent order
         u = np.full(self.A, np.nan)
@@ -714,20 +722,45 @@ def evaluation_fixture(games):
     import maddpg.networks as nets
     random.seed(12); np.random.seed(12); torch.manual_seed(12)
     created, seen_obs, lens = [], [], []
+    TRACE_GAMES = 40                                        # the first games also as a step trace (g3_2v2_evaluation_games)
+    tap = RngTap(); tap.install()                           # records the stdlib draws (spawns, bullet jitter); does not change them
+    rec = Recorder.__new__(Recorder)
 
     class CountingEnv(ev.battle_env.parallel_env):
         def __init__(self, *a, **k):
             super().__init__(*a, **k)
             self.calls_this_game, created[:] = 0, [self]
+            self.pending, self.recorded, self.recording = None, 0, False
+            rec.be, rec.tap, rec.cfg, rec.env = ev.battle_env, tap, dict(k), self
+            rec.n, rec.A, rec.D, rec.cont, rec.ids = self.n_agents, 2 * self.n_agents, self.obs_size, False, list(self.possible_agents)
+            rec.rows = {key: [] for key in (
+                "actions", "logits", "empty_call", "u", "obs", "rew", "done", "env_done", "winner",
+                "px", "py", "pdir", "php", "palive", "bhp", "tick", "total_time",
+                "bl_live", "bl_x", "bl_y", "bl_dir", "total_games", "ties", "wins_red", "wins_blue")}
+            rec.spawn, rec.obs0, rec.ep_ptr, rec.has_logits = [], [], [0], False
 
         def reset(self, *a, **k):
             if self.calls_this_game:
                 lens.append(self.calls_this_game)
             self.calls_this_game = 0
-            return super().reset(*a, **k)
+            mark = len(tap.ints)
+            obs = super().reset(*a, **k)
+            self.pending = (obs, tap.ints[mark:])           # evaluate.py resets twice per game: the LAST reset before a step starts the episode
+            return obs
 
         def step(self, actions):
-            out = super().step(actions)
+            if self.pending is not None:                    # first call of a game: is it one of the recorded ones?
+                self.recording = self.recorded < TRACE_GAMES
+                if self.recording:
+                    rec.adopt_reset(*self.pending)
+                    self.recorded += 1
+                self.pending = None
+            if self.recording:
+                ints = [int(np.argmax(actions[a])) if isinstance(actions[a], np.ndarray) else int(actions[a]) for a in rec.ids]
+                o, r, d = rec.step(ints, call=actions, stepper=super().step)
+                out = (o, r, d, {a: {} for a in rec.ids})
+            else:
+                out = super().step(actions)
             self.calls_this_game += 1
             if len(seen_obs) < 96 and self.calls_this_game % 7 == 3:
                 seen_obs.append(np.stack([out[0][a] for a in self.possible_red]))
@@ -746,7 +779,10 @@ def evaluation_fixture(games):
     finally:
         builtins.input, torch.load, ev.battle_env.parallel_env = real_input, real_load, real_cls
         del ev.range
+        tap.uninstall()
     env = created[0]
+    rec.save("g3_2v2_evaluation_games", {"policy": "evaluate.py main() unmodified: red = shipped checkpoints + OU noise 0.1 (maddpg.Team.load_models), "
+                                                   "blue = instinct.Team; the first %d games" % TRACE_GAMES, "seed": 12})
     lens.append(env.calls_this_game)
     cf = json.load(open(os.path.join(REF, "models/completed_model/cf.json")))
     out = {"games": np.int64(env.total_games), "ties": np.int64(env.ties), "red_wins": np.int64(env.team["red"]["wins"]),

@@ -201,8 +201,8 @@ def test_categorical_policy_head_and_value_head_vs_torch(n):
     assert float((s2.argmax(-1) != scores.argmax(-1)).float().mean()) > 0.05
 
 
-@pytest.mark.parametrize("n,one_launch", [(1, True), (1, False), (2, False)])
-def test_categorical_rollout_records_logp_and_value_and_one_launch_equals_the_graph(n, one_launch):
+@pytest.mark.parametrize("n,one_launch,precision", [(1, True, "f32"), (1, False, "f32"), (2, False, "f32"), (1, True, "bf16x3")])
+def test_categorical_rollout_records_logp_and_value_and_one_launch_equals_the_graph(n, one_launch, precision):
     """PolicyRollout(sample='categorical', value_actor=...): T ticks of (draw an action from softmax(scores / T), V(obs), step) with
     logp / value records [T, E, A]; the step takes exactly the drawn action (its arg-max of the perturbed row), so the C oracle
     stepping on the recorded score rows plays the same games; at 1v1 the one-launch form equals the per-tick graph bit for bit."""
@@ -216,7 +216,7 @@ def test_categorical_rollout_records_logp_and_value_and_one_launch_equals_the_gr
     def play(ol):
         env = _env(n_agents=n, n_envs=E, seed=41, auto_reset=True)
         env.reset()
-        ro = PolicyRollout(env, actor, T, seed=3, one_launch=ol, sample="categorical", temperature=0.7, value_actor=critic)
+        ro = PolicyRollout(env, actor, T, seed=3, one_launch=ol, sample="categorical", temperature=0.7, value_actor=critic, precision=precision)
         ro.start(); ro.capture()
         ro.run(); ro.run()
         torch.cuda.synchronize()
@@ -234,8 +234,9 @@ def test_categorical_rollout_records_logp_and_value_and_one_launch_equals_the_gr
         a = ro.scores[3].argmax(-1)
         want_lp = torch.log_softmax(z, -1).gather(-1, a[..., None])[..., 0]
         want_v = critic(ro.obs[3], squash=False)[..., 0]
-    torch.testing.assert_close(ro.logp[3], want_lp, rtol=0, atol=3e-4)
-    torch.testing.assert_close(ro.value[3], want_v, rtol=0, atol=5e-5)
+    tol = 1.0 if precision == "f32" else 40.0                                   # bf16x3: ~1e-5 on a tanh score, ~1e-3 on the (unsquashed, x100) value head
+    torch.testing.assert_close(ro.logp[3], want_lp, rtol=0, atol=3e-4 * tol)
+    torch.testing.assert_close(ro.value[3], want_v, rtol=0, atol=5e-5 * tol)
     assert float(ro.logp.max()) <= 0.0 and float(ro.logp.min()) > -20.0
     acts = torch.bincount(ro.scores.argmax(-1).flatten(), minlength=4)
     assert int(acts.min()) > 0.02 * int(acts.sum())                              # a stochastic policy: every action is drawn
