@@ -821,7 +821,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
             float4 o;                                    // uniform branches
             constexpr bool ROLL = N > 1;             // teams >= 2 carry more state across the actor: the 64 x 64 layer's weights as a rolling window
             if (p.aprec == BSX_ACTOR_BF16X3) o = bsx_actor::tile_forward<BSX_ACTOR_BF16X3, ROLL>(Wn, smn, D, lane, xb);
-            else if (N == 1 && p.aprec == BSX_ACTOR_BF16X6) o = bsx_actor::tile_forward<(N == 1 ? BSX_ACTOR_BF16X6 : BSX_ACTOR_F32), ROLL>(Wn, smn, D, lane, xb);   // 1v1 only: 96 weight registers
+            else if (p.aprec == BSX_ACTOR_BF16X6) o = bsx_actor::tile_forward<BSX_ACTOR_BF16X6, ROLL>(Wn, smn, D, lane, xb);   // (teams >= 2: its 96 weight registers fit as a rolling window of 72)
             else o = bsx_actor::tile_forward<BSX_ACTOR_F32, ROLL>(Wn, smn, D, lane, xb);
             if (hh == ti) r4 = o;                        // lower half finishes the wave's first tile, upper half the second
         }
@@ -1926,7 +1926,7 @@ int launch_rollout(void* state, int64_t E, int n, int T, const float* weights, i
                    int64_t env_offset, void* stream) {
     if (!state || E <= 0 || E > BSX_MAX_E || n < 1 || n > 4 || T < 1 || T > BSX_MAX_T || !weights || !obs || !scores || !rew || !done || !cfg)
         return BSX_E_ARG;
-    if ((flags & BSX_F_EMPTY_CALL) || (precision != BSX_ACTOR_F32 && precision != BSX_ACTOR_BF16X3 && !(precision == BSX_ACTOR_BF16X6 && n == 1)) ||
+    if ((flags & BSX_F_EMPTY_CALL) || (precision != BSX_ACTOR_F32 && precision != BSX_ACTOR_BF16X3 && precision != BSX_ACTOR_BF16X6) ||
         scripted_team < -1 || scripted_team > 1) return BSX_E_ARG;
     if (!aligned(state, 256) || !aligned(weights, 16) || !aligned(scores, 16) || !aligned(obs, 4) || !aligned(rew, 4)) return BSX_E_ALIGN;
     BsxActorNoise nz = {};

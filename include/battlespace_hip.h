@@ -196,7 +196,7 @@ typedef struct BsxActorNoise {
 #define BSX_ACTOR_F32 0
 #define BSX_ACTOR_BF16X3 1
 #define BSX_ACTOR_BF16X6 2   /* three bf16 terms per operand, six products: float32-class accuracy (~1e-7), 48 matrix instructions of 32 cycles
-                               instead of 64 of 64; bsx_actor_forward for any n, the one-launch rollouts for n = 1 */
+                               instead of 64 of 64; every actor entry point, every team size */
 int bsx_actor_blob_floats(int obs_len, int* floats_per_agent);
 int bsx_actor_forward(const float* weights, const float* obs, float* scores, int64_t E, int n, int precision,
                       const BsxActorNoise* noise, uint64_t seed, uint64_t seq, const uint64_t* seq_base, int64_t env_offset,

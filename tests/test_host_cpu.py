@@ -56,7 +56,6 @@ def test_bad_arguments_are_rejected_before_any_launch():
     assert lib.bsx_rollout_discrete(ok, 4, 5, 8, ok, 0, -1, ok, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1
     assert lib.bsx_rollout_discrete(ok, 4, 1, 8, ok, 7, -1, ok, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1
     assert lib.bsx_rollout_discrete(ok, 4, 1, 8, ok, 0, 2, ok, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1
-    assert lib.bsx_rollout_discrete(ok, 4, 2, 8, ok, 2, -1, ok, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1   # bf16x6 in one launch: 1v1 only
     assert lib.bsx_rollout_continuous(ok, 4, 5, 8, ok, 0, -1, 0, ok, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1
     assert lib.bsx_rollout_continuous(ok, 4, 1, 8, ok, 0, 2, 0, ok, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1   # scripted_team out of range
     nz = L.BsxActorNoise(0.1, 0.0, 0.15, 0.2, 0.0, None, None, ctypes.c_void_p(4096))     # injected normals are per call: not for a T-tick launch
