@@ -261,6 +261,9 @@ def parse_args(argv=None):
     ap.add_argument("--continuous", action="store_true", help="continuous [speed, turn, shoot] actions (battle_env.py:418-424) instead of discrete")
     ap.add_argument("--mode", choices=("graph", "eager", "many"), default="graph")
     ap.add_argument("--graph-len", type=int, default=100)
+    ap.add_argument("--chains", type=int, default=1,
+                    help="graph mode: the batch as this many game ranges, each its own chain of launches on a branch of the graph "
+                         "(capture_steps(chains=)); 1 = one launch per step over the whole batch (the headline)")
     ap.add_argument("--no-stagger", action="store_true", help="leave all games on the same clock (time-limit ties in lock-step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the extra (non-headline) measurements")
@@ -446,7 +449,7 @@ def main():
         turn = torch.where(hy * (600 - px) - hx * (400 - py) > 0, 2, 3)
         return torch.where(out | near_base, turn, torch.ones_like(turn)).to(torch.int32)
 
-    def measure(n, E, K, W, mode, graph_len, mix="uniform", continuous=False, R=None, do_stagger=True):
+    def measure(n, E, K, W, mode, graph_len, mix="uniform", continuous=False, R=None, do_stagger=True, chains=1):
         """K timed step() calls of E games x n-v-n on this rank, R times -> dict(env, walls, kms, G, live)."""
         A = 2 * n
         R = R or args.repeats
@@ -492,7 +495,7 @@ def main():
         run_b, Kb = None, None
         pos = [0]                                           # which G-tick slice of the table comes next
         if mode == "graph":
-            graphs = [env.capture_steps(actions[i * G:(i + 1) * G])[0] for i in range(NG)]
+            graphs = [env.capture_steps(actions[i * G:(i + 1) * G], chains=chains)[0] for i in range(NG)]
             graph = graphs[0]
 
             def run(steps):
@@ -502,7 +505,7 @@ def main():
                 for t in range(steps % G):
                     env.step_batch(actions[(pos[0] % NG) * G + t])
             if NG > 1:                                      # short blocks: the event bracket holds the whole table as ONE graph (timed_blocks)
-                graph_b, _ = env.capture_steps(actions)
+                graph_b, _ = env.capture_steps(actions, chains=chains)
                 Kb = TT
 
                 def run_b(steps):
@@ -571,7 +574,9 @@ def main():
     n, E = args.n_agents, args.envs_per_gpu
     A = 2 * n
     K, W = args.steps, args.warmup
-    head = measure(n, E, K, W, args.mode, args.graph_len, mix=args.action_mix, continuous=args.continuous)
+    if args.chains != 1 and args.mode != "graph":
+        raise SystemExit("--chains is a property of the captured graph (--mode graph)")
+    head = measure(n, E, K, W, args.mode, args.graph_len, mix=args.action_mix, continuous=args.continuous, chains=args.chains)
     env = head["env"]
     games = sharding.reduce_counters(sharding.local_counter_sums(env).to(red_dev))   # logging only, after the timed region
     if args.digest_dir:
@@ -592,9 +597,9 @@ def main():
 
     # Not the headline: the same kernel on BASELINE.json configs[2], in the streaming regime (working set > Infinity Cache),
     # with many live bullets, with continuous actions, as a multi-tick launch, and with the policy in the loop (configs[4]).
-    others, multi, loop_sampling, rollouts, dropin = {}, None, None, None, None
+    others, multi, loop_sampling, rollouts, dropin, chained = {}, None, None, None, None, None
     extra = world == 1 and not args.no_other_workloads and (n, E) == (1, 65536) and args.mode == "graph" \
-        and args.action_mix == "uniform" and not args.continuous
+        and args.action_mix == "uniform" and not args.continuous and args.chains == 1
     if extra:
         Ko = min(K, 400)
         m = measure(n, E, min(K, 1000), W, "many", 100)
@@ -630,6 +635,22 @@ def main():
             others[tag] = summary(m, n2, E2, K2, continuous=cont2, key=key2)
             del m
             torch.cuda.empty_cache()
+        # The same step() workloads with the graph's launches as independent chains over game ranges (capture_steps(chains=)): per step
+        # the whole batch still advances one tick, as P launches that wait only for their own range's previous launch
+        chained = {"note": "one HIP graph, P branches = P game ranges, each a chain of per-step launches (bsx_step_*_range); same games bit for bit "
+                           "(tests/test_hip_fullsize.py::test_chained_graph_plays_the_same_games); us_per_step = HIP events around the replays / steps"}
+        for tag, (n2, E2, K2, cont2, P2) in {
+                "65536 x 1v1, 2 chains": (1, 65536, Ko, False, 2),
+                "65536 x 4v4, 2 chains": (4, 65536, Ko, False, 2),
+                "65536 x 4v4, 3 chains": (4, 65536, Ko, False, 3),
+                "65536 x 4v4, continuous actions, 2 chains": (4, 65536, Ko, True, 2),
+                "1048576 x 1v1, 2 chains": (1, 1048576, min(K, 200), False, 2)}.items():
+            m = measure(n2, E2, K2, 50, "graph", 100, continuous=cont2, R=3, chains=P2)
+            km2, wall2 = statistics.median(m["kms"]), statistics.median(m["walls"])
+            chained[tag] = {"chains": P2, "us_per_step": round(km2 * 1e3, 3), "agent_steps_per_s": round(E2 * 2 * n2 * K2 / wall2, 1),
+                            "steps": K2, "repeats": len(m["kms"])}
+            del m
+            torch.cuda.empty_cache()
         rollouts = rollout_lines(dev, E, min(K, 320))
         try:
             dropin = dropin_one_game(dev)
@@ -648,7 +669,7 @@ def main():
                 "workload, read side x2 (MI355X_MICROARCH.md); a constant from that profile, not measured by this run") if te else None
         tdetail = None
         cpu_base = cpu_baseline() if (world == 1 and not args.no_cpu_baseline) else None      # before the counter passes: a quiet host
-        if world == 1 and not args.no_live_traffic:
+        if world == 1 and not args.no_live_traffic and args.chains == 1:   # (a chained graph's launches cover a range each: the per-launch counters do not describe a step)
             Gw = 2
             while Gw < A:
                 Gw *= 2
@@ -675,7 +696,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64/i16", "data": "synthetic",
             "config": {"workload": f"{E} games x {n}v{n} per GPU, {mixname} {'continuous' if args.continuous else 'discrete'} actions, fused HIP step(), auto-reset, "
                                    f"staggered game clocks (BASELINE.json configs[{1 if n == 1 else 2}]{' x ' + str(world) + ' shards' if world > 1 else ''})",
-                       "envs_per_gpu": E, "n_agents_per_team": n, "agents_per_env": A, "launch": args.mode,
+                       "envs_per_gpu": E, "n_agents_per_team": n, "agents_per_env": A, "launch": args.mode + (f", {args.chains} chains of launches over game ranges" if args.chains > 1 else ""),
                        "graph_len": head["G"] if args.mode == "graph" else None, "parallelism": f"{world} independent env shards, no collective",
                        "process_group": (args.backend if world > 1 else None), "process_group_note": backend_note,
                        "rehearsal_all_ranks_on_device0": bool(args.rehearse_on_device0) or None},
@@ -709,6 +730,7 @@ def main():
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         out["other_workloads"] = others
+        out["chained_graphs"] = chained
         out["multi_tick_launch"] = multi
         out["loop_incl_action_sampling"] = loop_sampling
         out["policy_rollouts"] = rollouts

@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # bsx_build_flags() is non-zero (results are not the reference's) is refused unless BSX_ALLOW_DIAG=1 is set as well.
 LIB_PATH = os.environ.get("BSX_LIB_PATH") or os.path.join(_HERE, "csrc", "libbattlespace_hip.so")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 BULLET_SLOTS = 12
 MAX_N = 16
 MAX_T = 65535
@@ -57,6 +57,10 @@ SIGNATURES = {
                                   c_void_p, c_void_p, ctypes.POINTER(BsxRewards), c_uint32, c_uint64, c_int64, c_void_p]),
     "bsx_step_continuous": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, ctypes.POINTER(BsxRewards), c_uint32, c_uint64, c_int64, c_void_p]),
+    "bsx_step_discrete_range": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, ctypes.POINTER(BsxRewards), c_uint32, c_uint64, c_int64, c_void_p]),
+    "bsx_step_continuous_range": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, ctypes.POINTER(BsxRewards), c_uint32, c_uint64, c_int64, c_void_p]),
     "bsx_step_many_discrete": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, ctypes.POINTER(BsxRewards), c_uint32, c_int, c_uint64, c_int64, c_void_p]),
     "bsx_step_many_continuous": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -33,6 +33,18 @@ constexpr bool PACK_BULLETS = true;
 #endif
 constexpr int OBS_FORM = BSX_X_OBS;
 
+// round 3's 4v4 experiments (same results): the table shot / the corner-form rectangle tests for every team size
+#ifdef BSX_X_CHEAP_ALL
+constexpr bool X_CHEAP_ALL = true;
+#else
+constexpr bool X_CHEAP_ALL = false;
+#endif
+#ifdef BSX_X_CORNERS_ALL
+constexpr bool X_CORNERS_ALL = true;
+#else
+constexpr bool X_CORNERS_ALL = false;
+#endif
+
 #ifdef BSX_STAMPS
 constexpr int BUILD_FLAGS = int(DIAG & 0xFFu) | 0x100;
 __device__ unsigned long long* g_stamps = nullptr;

@@ -48,6 +48,7 @@ constexpr unsigned DIAG = 0;
 constexpr int BUILD_FLAGS = 0;
 constexpr bool PACK_BULLETS = true;
 constexpr int OBS_FORM = 0;
+constexpr bool X_CHEAP_ALL = false, X_CORNERS_ALL = false;
 #define STAMP(i) do { } while (0)
 #define FSTAMP(i) do { } while (0)
 #define PSTAMP(i) do { } while (0)
@@ -580,7 +581,10 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     const ixs_t e = wblk * EPB + (tid / G);
     const bool env_ok = e < ixs_t(E_);
     const bool valid = env_ok && a < A;
-    const ix_t EA = ix_t(E_) * ix_t(A);
+    // E_ = the games THIS launch steps (rows 0 .. E_ - 1 of every array it was handed); p.E = the games the state was laid out for, i.e.
+    // the row stride of the entry-major bullet arrays.  They differ only for a launch over a sub-range of the games (bsx_step_*_range:
+    // every [E]-major pointer arrives advanced to the range's first game, the entry-major ones by the same rows within their first entry).
+    const ix_t EA = ix_t((MULTI || ACTOR) ? E_ : p.E) * ix_t(A);
     // out-of-range lanes read a valid row (the last one) and never store: loads stay unconditional
     const ixs_t ec = env_ok ? e : ixs_t(E_ - 1);
     const ix_t g = ix_t(ec) * A + (a < A ? a : A - 1);
@@ -611,7 +615,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // (C2 7.33 -> 7.20 us against the centre form: ~15 instructions fewer per round where the instruction count is the bound).
     // Larger teams: the centre (x | alive << 15 | y << 16) and the margins as constants in the slot -- measured faster there
     // (4v4 23.1 us against 24.7 with corners; the same launches, four runs each).
-    constexpr bool CORNERS = N == 1;
+    constexpr bool CORNERS = N == 1 || X_CORNERS_ALL;
     typedef typename std::conditional<CORNERS, u32x2, uint32_t>::type rect_t;
     __shared__ __attribute__((aligned(8))) rect_t s_eb_all[PACK ? WAVES * SPB : 1];        // per owner: the enemy base, dx in [-33, 33], dy in [-32, 31]
     __shared__ __attribute__((aligned(8))) rect_t s_pq_all[PACK ? WAVES * SPB : 1];        // per plane: its post-move sprite, dx in [-27, 27], dy in [-25, 24]; dead: never hit
@@ -1026,7 +1030,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // 1v1 discrete: the shot's step from the heading table by angle addition instead of a float64 sincos (below).  Larger teams keep
     // the sincos: there the shorter shot measured SLOWER (4v4 23.3 -> 25.3 us, two runs each) -- the table entry it needs arrives
     // later than the ~110 instructions of the sincos take, and nothing else is left to cover it.
-    constexpr bool CHEAP_SHOT = !CONT && N == 1;
+    constexpr bool CHEAP_SHOT = !CONT && (N == 1 || (X_CHEAP_ALL && N > 0));
     double2 nd = make_double2(0.0, 0.0);                 // this call's shot: float64 step (CHEAP_SHOT: to ~1e-8 unless flagged exact), step code, heading
     double nbdir = 0.0;
     uint32_t ncode = 0u;
@@ -1320,7 +1324,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
             // rectangle test as "some lower or upper margin is negative" = a sign bit in either half.
             uint32_t bpk = step_pk(en.x & ENT_XY, en.y);
             if (wave_exact) {                            // wave-uniform, decided before the rounds: the float64 move of flagged entries
-                if constexpr (CORNERS) asm volatile("");   // (1v1: keeps this a scalar branch -- merged with the per-lane test below it is a masked block on the common
+                if constexpr (N == 1) asm volatile("");   // (1v1: keeps this a scalar branch -- merged with the per-lane test below it is a masked block on the common
                                                            //  path; larger teams measured faster with the merged form: 4v4 22.9 us against 23.7)
                 if (lvm != 0 && (en.x & ENT_EXACT) != 0u)                       // (this call's shot left its step in LDS, older ones in the ring by birth tick)
                     bpk = move_exact(en.x, [&]() {
@@ -1751,13 +1755,13 @@ inline int grid_for(int64_t E, int n, int tpb = TPB) {
 }
 
 template <bool CONT, bool MULTI, bool LG, bool OFF32>
-void launch_for_n_w(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs& a) {
+void launch_for_n_w(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs& a, int64_t bound) {
     switch (n) {
-        case 1: hipLaunchKernelGGL((bsx_step_kernel<1, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-        case 2: hipLaunchKernelGGL((bsx_step_kernel<2, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-        case 3: hipLaunchKernelGGL((bsx_step_kernel<3, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-        case 4: hipLaunchKernelGGL((bsx_step_kernel<4, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-        default: hipLaunchKernelGGL((bsx_step_kernel<0, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        case 1: hipLaunchKernelGGL((bsx_step_kernel<1, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, bound, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        case 2: hipLaunchKernelGGL((bsx_step_kernel<2, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, bound, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        case 3: hipLaunchKernelGGL((bsx_step_kernel<3, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, bound, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        case 4: hipLaunchKernelGGL((bsx_step_kernel<4, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, bound, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        default: hipLaunchKernelGGL((bsx_step_kernel<0, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, bound, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
     }
 }
 // 32-bit offsets when every array of the job stays below 4 GB: an observation row is at most 4 (3 * 16 + 2) = 200 bytes per agent,
@@ -1766,17 +1770,22 @@ inline bool narrow_offsets_ok(int64_t E, int n, uint32_t flags) {
     return !(flags & BSX_F_WIDE_OFFSETS) && uint64_t(E) * uint64_t(2 * n) * 200ull <= 0xFFFFFFFFull;
 }
 template <bool CONT, bool MULTI, bool LG>
-void launch_for_n(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs& a) {
-    if (narrow_offsets_ok(a.E, n, a.flags)) launch_for_n_w<CONT, MULTI, LG, true>(n, grid, block, s, a);
-    else launch_for_n_w<CONT, MULTI, LG, false>(n, grid, block, s, a);
+void launch_for_n(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs& a, int64_t bound) {
+    if (narrow_offsets_ok(a.E, n, a.flags)) launch_for_n_w<CONT, MULTI, LG, true>(n, grid, block, s, a, bound);
+    else launch_for_n_w<CONT, MULTI, LG, false>(n, grid, block, s, a, bound);
 }
 
 // T == 0: one call (bsx_step_*);  T >= 1: bsx_step_many_* -- T calls in one launch, arrays with a leading T axis
 template <bool CONT>
 int launch_step(void* state, int64_t E, int n, const void* actions, int action_kind, const double* u, float* obs,
                 float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner, const BsxRewards* cfg, uint32_t flags,
-                uint64_t seed, int64_t env_offset, void* stream, int T = 0, int store_all = 0, uint8_t* env_done_t = nullptr) {
+                uint64_t seed, int64_t env_offset, void* stream, int T = 0, int store_all = 0, uint8_t* env_done_t = nullptr,
+                int64_t first = 0, int64_t count = -1) {
     if (T < 0 || T > BSX_MAX_T) return BSX_E_ARG;
+    if (count < 0) count = E - first;
+    // a sub-range of the games (bsx_step_*_range): whole 256-game blocks, so that every array the launch is handed stays aligned as the
+    // full arrays are; the one-call form only (a multi-tick launch strides its per-tick arrays by the games it steps)
+    if (first < 0 || count <= 0 || first > E - count || (first & 255) || ((first || count != E) && T != 0)) return BSX_E_ARG;
     if (!state || E <= 0 || E > BSX_MAX_E || n < 1 || n > BSX_MAX_N || !obs || !rew || !done || !cfg) return BSX_E_ARG;
     if (!actions && !(flags & BSX_F_EMPTY_CALL)) return BSX_E_ARG;
     if (!aligned(state, 256) || !aligned(obs, 4) || !aligned(rew, 4) || (u && !aligned(u, 8))) return BSX_E_ALIGN;
@@ -1797,15 +1806,27 @@ int launch_step(void* state, int64_t E, int n, const void* actions, int action_k
     a.act_tb = EA * (CONT ? (action_kind == BSX_ACT_F32 ? 12 : (action_kind == BSX_ACT_F64 ? 24 : 16)) : (action_kind == BSX_ACT_I32 ? 4 : 16));
     a.u_ts = EA;
     a.obs_ts = store_all ? EA * (3 * n + 2) : 0; a.rew_ts = store_all ? EA : 0; a.done_ts = store_all ? EA : 0;
-    const dim3 grid(grid_for(E, n, SPB * WPB)), block(SPB * WPB);
+    if (first) {
+        // Every array is indexed by game or by agent row (game * 2n + plane), the bullet arrays by entry * (E * 2n) + agent row with the stride
+        // taken from a.E: advancing each pointer to the range's first row turns the kernel's row r into row first + r of the full arrays.
+        const int64_t fa = first * 2 * n;
+        a.st.env += first; a.st.cnt += first; a.st.plane += fa; a.st.bent += fa; a.st.bdir += fa; a.st.bd += fa;
+        if (actions) a.actions = static_cast<const char*>(actions) + fa * (a.act_tb / EA);
+        if (u) a.u += fa;
+        a.obs += fa * (3 * n + 2); a.rew += fa; a.done += fa;
+        if (env_done) a.env_done += first;
+        if (winner) a.winner += first;
+        a.env_offset += first;                             // the draws are keyed by the global game index
+    }
+    const dim3 grid(grid_for(count, n, SPB * WPB)), block(SPB * WPB);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool lg = !CONT && action_kind == BSX_ACT_LOGITS_F32;
     if (T == 0) {
-        if (lg) launch_for_n<CONT, false, !CONT>(n, grid, block, s, a);
-        else launch_for_n<CONT, false, false>(n, grid, block, s, a);
+        if (lg) launch_for_n<CONT, false, !CONT>(n, grid, block, s, a, count);
+        else launch_for_n<CONT, false, false>(n, grid, block, s, a, count);
     } else {
-        if (lg) launch_for_n<CONT, true, !CONT>(n, grid, block, s, a);
-        else launch_for_n<CONT, true, false>(n, grid, block, s, a);
+        if (lg) launch_for_n<CONT, true, !CONT>(n, grid, block, s, a, count);
+        else launch_for_n<CONT, true, false>(n, grid, block, s, a, count);
     }
     return int(hipGetLastError());
 }
@@ -1888,6 +1909,20 @@ int bsx_step_continuous(void* state, int64_t E, int n, const void* actions, int 
                         const BsxRewards* cfg, uint32_t flags, uint64_t seed, int64_t env_offset, void* stream) {
     return launch_step<true>(state, E, n, actions, action_kind, u, obs, rew, done, env_done, winner, cfg, flags, seed,
                              env_offset, stream);
+}
+
+int bsx_step_discrete_range(void* state, int64_t E, int n, int64_t first, int64_t count, const void* actions, int action_kind, const double* u,
+                            float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner, const BsxRewards* cfg,
+                            uint32_t flags, uint64_t seed, int64_t env_offset, void* stream) {
+    return launch_step<false>(state, E, n, actions, action_kind, u, obs, rew, done, env_done, winner, cfg, flags, seed,
+                              env_offset, stream, 0, 0, nullptr, first, count);
+}
+
+int bsx_step_continuous_range(void* state, int64_t E, int n, int64_t first, int64_t count, const void* actions, int action_kind, const double* u,
+                              float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner, const BsxRewards* cfg,
+                              uint32_t flags, uint64_t seed, int64_t env_offset, void* stream) {
+    return launch_step<true>(state, E, n, actions, action_kind, u, obs, rew, done, env_done, winner, cfg, flags, seed,
+                             env_offset, stream, 0, 0, nullptr, first, count);
 }
 
 int bsx_step_many_discrete(void* state, int64_t E, int n, int T, const void* actions, int action_kind, const double* u,

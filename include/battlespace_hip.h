@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BSX_ABI_VERSION 12
+#define BSX_ABI_VERSION 13
 #define BSX_BULLET_SLOTS 12 /* a bullet is removed at the latest on its 12th update (sprites.py:334-337: 12*45 >= 500) */
 #define BSX_MAX_N 16
 #define BSX_MAX_E (INT64_C(1) << 30)   /* games per call: keeps every grid below 2^31 workgroups; 2^30 games of 1v1 is ~0.8 TB of state */
@@ -105,6 +105,20 @@ int bsx_step_discrete(void* state, int64_t E, int n, const void* actions, int ac
 int bsx_step_continuous(void* state, int64_t E, int n, const void* actions, int action_kind, const double* u,
                         float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner,
                         const BsxRewards* cfg, uint32_t flags, uint64_t seed, int64_t env_offset, void* stream);
+
+/* The same call for the games [first, first + count) of the state only (battle_env.py:281-381: the reference's games share nothing,
+ * so any partition of the batch steps to the same results).  Every array argument is the FULL array, exactly as bsx_step_discrete /
+ * bsx_step_continuous take it; rows outside the range are neither read nor written.  What it is for: a caller with all T calls'
+ * actions at hand enqueues the batch as a few independent chains of launches (one per range, each on its own stream, or as parallel
+ * branches of one HIP graph), so that one chain's kernel boundary -- launch, first loads, store drain -- runs under another chain's
+ * arithmetic (`parallel_env.capture_steps(..., chains=)`).  `first` must be a multiple of 256 (BSX_E_ARG otherwise: sub-arrays keep the
+ * alignment of the full ones); count >= 1, first + count <= E.  Launches over disjoint ranges may run concurrently. */
+int bsx_step_discrete_range(void* state, int64_t E, int n, int64_t first, int64_t count, const void* actions, int action_kind,
+                            const double* u, float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner,
+                            const BsxRewards* cfg, uint32_t flags, uint64_t seed, int64_t env_offset, void* stream);
+int bsx_step_continuous_range(void* state, int64_t E, int n, int64_t first, int64_t count, const void* actions, int action_kind,
+                              const double* u, float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner,
+                              const BsxRewards* cfg, uint32_t flags, uint64_t seed, int64_t env_offset, void* stream);
 
 /* T consecutive parallel_env.step calls in ONE launch (the caller's `for t: step(actions[t])` loop, battle_env.py:281, when
  * the actions of all T calls are known up front: scripted or random play, replays).  Same arguments and results as T calls

@@ -223,6 +223,59 @@ def test_graph_replay_equals_eager_steps():
     assert all(torch.equal(sa[k], sb[k]) for k in ("px", "py", "php", "tick", "counters", "bl_live"))
 
 
+@pytest.mark.parametrize("E,n,chains,mode", [(4096, 1, 2, "int"), (1000, 1, 3, "int"), (1300, 2, 2, "int"), (2049, 4, 3, "int"), (600, 6, 2, "int"),
+                                             (777, 3, 4, "cont64"), (1024, 1, 4, "scores"), (1025, 2, 8, "cont32")])
+def test_chained_graph_plays_the_same_games(E, n, chains, mode):
+    """capture_steps(chains=P): the batch as P game ranges, each its own chain of launches on a branch of ONE graph
+    (bsx_step_*_range) -- the games of chains=1, bit for bit: every tick's outputs, the final state, the counters; ragged last
+    range, ranges of unequal length, more chains asked for than there are 256-game blocks."""
+    A = 2 * n
+    cont = mode.startswith("cont")
+    a = _env(n_agents=n, n_envs=E, seed=21, auto_reset=True, continuous_actions=cont); a.reset()
+    b = _env(n_agents=n, n_envs=E, seed=21, auto_reset=True, continuous_actions=cont); b.reset()
+    ranges = b.chain_ranges(chains)
+    assert ranges[0][0] == 0 and sum(c for _, c in ranges) == E and all(f % 256 == 0 for f, _ in ranges)
+    assert all(ranges[i][0] + ranges[i][1] == ranges[i + 1][0] for i in range(len(ranges) - 1)) and len(ranges) == min(chains, -(-E // 256))
+    T = 60
+    g = torch.Generator(device="cuda"); g.manual_seed(E + n)
+    if mode == "int":
+        acts = _actions(T, E, A, 300 + E, p_shoot=0.7)
+    elif mode == "scores":
+        acts = torch.randn((T, E, A, 4), generator=g, device="cuda"); acts[..., 1] += 0.9
+    else:
+        acts = (torch.rand((T, E, A, 3), generator=g, device="cuda", dtype=torch.float64) * 2.6 - 1.3)
+        acts = acts.to(torch.float32).contiguous() if mode == "cont32" else acts
+    ga, outs_a = a.capture_steps(acts, store=True)
+    gb, outs_b = b.capture_steps(acts, store=True, chains=chains)
+    for rep in range(5):                                      # 300 calls: across the time-limit tie and the re-spawns
+        ga.replay(); gb.replay()
+        torch.cuda.synchronize()
+        for x, y, name in zip(outs_a, outs_b, ("obs", "rew", "done")):
+            assert torch.equal(x, y), (rep, name)
+    sa, sb = a.export_state(), b.export_state()
+    assert all(torch.equal(sa[k], sb[k]) for k in sa), [k for k in sa if not torch.equal(sa[k], sb[k])]
+    assert torch.equal(a._env_done, b._env_done) and torch.equal(a._winner, b._winner)
+
+
+def test_range_calls_in_any_order_make_one_step():
+    """bsx_step_discrete_range: three launches over disjoint game ranges, issued last range first, are one step() of the batch;
+    rows outside a launch's range are left alone."""
+    E, n = 1500, 2
+    a = _env(n_agents=n, n_envs=E, seed=5, auto_reset=True); a.reset()
+    b = _env(n_agents=n, n_envs=E, seed=5, auto_reset=True); b.reset()
+    acts = _actions(30, E, 2 * n, 77, p_shoot=0.6)
+    for t in range(30):
+        oa, ra, da = a.step_batch(acts[t], copy=True)
+        b._obs.fill_(7.0)
+        for i, games in enumerate(reversed(b.chain_ranges(3))):
+            b._launch(acts[t].data_ptr(), 0, False, None, b._obs.data_ptr(), b._rew.data_ptr(), b._done.data_ptr(), games=games)
+            if i == 0:                                        # only the last range has been written so far
+                assert bool((b._obs[:games[0]] == 7.0).all()) and torch.equal(b._obs[games[0]:], oa[games[0]:])
+        assert torch.equal(b._obs, oa) and torch.equal(b._rew, ra) and torch.equal(b._done.view(torch.bool), da.view(torch.bool)), t
+    sa, sb = a.export_state(), b.export_state()
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)
+
+
 @pytest.mark.parametrize("E,n,mode", [(4096, 1, "int"), (1000, 2, "int"), (515, 4, "int"), (300, 6, "int"), (33, 16, "int"), (70, 3, "cont64"),
                                       (2048, 1, "scores"), (1024, 2, "cont32"), (777, 1, "cont64")])
 def test_step_many_equals_consecutive_step_calls(E, n, mode):

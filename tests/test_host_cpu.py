@@ -53,6 +53,10 @@ def test_bad_arguments_are_rejected_before_any_launch():
     assert lib.bsx_step_many_discrete(ok, 4, 1, 0, ok, 0, None, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, 1, 0, 0, None) == -1
     assert lib.bsx_step_many_discrete(ok, 4, 1, 70000, ok, 0, None, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, 1, 0, 0, None) == -1
     assert lib.bsx_step_many_continuous(ok, 4, 1, 5, None, 0, None, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, 1, 0, 0, None) == -1
+    # a game range: whole 256-game blocks from `first`, inside the batch
+    rng = lambda first, count: lib.bsx_step_discrete_range(ok, 1024, 1, first, count, ok, 0, None, ok, ok, ok, None, None, ctypes.byref(cfg), 0, 0, 0, None)   # noqa: E731
+    assert rng(100, 50) == -1 and rng(512, 513) == -1 and rng(0, 0) == -1 and rng(-256, 256) == -1 and rng(1024, 1) == -1
+    assert lib.bsx_step_continuous_range(ok, 1024, 1, 256, 769, ok, 0, None, ok, ok, ok, None, None, ctypes.byref(cfg), 0, 0, 0, None) == -1
     assert lib.bsx_rollout_discrete(ok, 4, 5, 8, ok, 0, -1, ok, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1
     assert lib.bsx_rollout_discrete(ok, 4, 1, 8, ok, 7, -1, ok, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1
     assert lib.bsx_rollout_discrete(ok, 4, 1, 8, ok, 0, 2, ok, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, None, 0, 0, None, 0, 0, None) == -1
