@@ -201,12 +201,21 @@ class FusedActor:
             nz.ou_keep = 0 if ou.get("restart", True) else 1
         return nz
 
-    def forward_into(self, obs, scores, noise_std=0.0, seq=None, seq_base=None, ou=None, z=None, sample=None, value=None):
+    def forward_into(self, obs, scores, noise_std=0.0, seq=None, seq_base=None, ou=None, z=None, sample=None, value=None, games=None):
         """obs f32 [E, A, D] (contiguous) -> scores f32 [E, A, 4] (contiguous, 16-byte aligned), on the current stream.
         noise_std: Gaussian exploration noise.  ou: optional dict(scale, state[, theta, sigma, mu, env_done]) for the
         reference's Ornstein-Uhlenbeck noise (utils/noise.py): `state` is a float32 [E, A, 4] tensor updated in place,
         `env_done` a uint8 [E] tensor whose set rows restart the process.
-        seq_base: optional int64 device tensor (1 element) added to `seq` in-kernel (for captured graphs)."""
+        seq_base: optional int64 device tensor (1 element) added to `seq` in-kernel (for captured graphs).
+        games: (first, count) = evaluate only that range of the games (every tensor still the full one; the noise is keyed by the
+        global row, so the draws are those of the full call)."""
+        off = self.env_offset
+        if games is not None:
+            sl = slice(int(games[0]), int(games[0]) + int(games[1]))
+            cut = lambda d, keys: None if d is None else dict(d, **{k: d[k][sl] for k in keys if d.get(k) is not None})   # noqa: E731
+            obs, scores, z = obs[sl], scores[sl], (z[sl] if z is not None else None)
+            ou, sample, value = cut(ou, ("state", "env_done")), cut(sample, ("logp", "u")), cut(value, ("out",))
+            off += int(games[0])
         E = obs.shape[0]
         if seq is None:
             self.seq += 1
@@ -214,7 +223,7 @@ class FusedActor:
         nz = self.noise_struct(E, noise_std, ou, z, sample, value)
         _lib.check(self._lib.bsx_actor_forward(self.weights.data_ptr(), obs.data_ptr(), scores.data_ptr(), E, self.n, self.precision,
                                                _lib.ctypes.byref(nz) if nz is not None else None, self.seed, int(seq),
-                                               seq_base.data_ptr() if seq_base is not None else None, self.env_offset,
+                                               seq_base.data_ptr() if seq_base is not None else None, off,
                                                torch.cuda.current_stream(obs.device).cuda_stream), "bsx_actor_forward")
         return scores
 
@@ -240,11 +249,17 @@ class PolicyRollout:
     kernel and restarted per game; then clamp(-1, 1) as maddpg/agent.py:31 does."""
 
     def __init__(self, env, actor, T, noise_std=0.0, fused=True, seed=0, opponent=None, ou_scale=0.0, one_launch=False,
-                 precision="f32", ou_restart=True, sample=None, temperature=1.0, value_actor=None):
+                 precision="f32", ou_restart=True, sample=None, temperature=1.0, value_actor=None, chains=1):
         """actor: a StackedActor.  fused=True evaluates it with the hand-written HIP kernel (FusedActor), False with
         torch ops (the fp32 reference of the same op).  opponent: an `instinct.Team` that plays its team's planes
         instead of the actor (the reference's training setup, main.py:119-122: learned red vs scripted blue): its
         one-hot scores overwrite that team's rows of the score tensor each tick, on device."""
+        # chains > 1 (graph form, fused actor, no scripted opponent): the games as that many ranges, each its own chain of
+        # (actor -> step) launch pairs on a branch of the graph (battle_env.capture_steps(chains=)): one range's matrix-core actor
+        # pass runs under another range's step kernel.  Same transitions bit for bit.
+        self.chains = int(chains)
+        if self.chains > 1 and (one_launch or not fused or opponent is not None):
+            raise ValueError("chains > 1 is for the graph form with the fused actor and no scripted opponent")
         if env._compat or env.rng != "philox":
             raise ValueError("PolicyRollout needs a batched env with rng='philox'")
         self.continuous = bool(env.continuous_actions)
@@ -303,7 +318,7 @@ class PolicyRollout:
         self.done = self._done.view(torch.bool)
         # env_done[t] = the games' env_done BEFORE tick t (row 0: when the rollout starts; row t+1 is written by tick t)
         self.env_done = torch.ones((T + 1, E), dtype=torch.uint8, device=dev)
-        self.graph = None
+        self.graph, self._side = None, None
 
     @property
     def valid(self):
@@ -311,7 +326,17 @@ class PolicyRollout:
         (`while not env.env_done: step`, main.py:177-181)."""
         return self.env_done[:self.T] == 0
 
-    def _tick(self, t):
+    def _tick(self, t, games=None):
+        if games is not None:                          # a chain's tick: the fused actor and the step over one range of the games
+            ou = dict(self.ou, env_done=self.env_done[t] if self.ou["restart"] else None) if self.ou is not None else None
+            sample = dict(self._sample, logp=self.logp[t]) if self._sample is not None else None
+            value = dict(weights=self._value_w, out=self.value[t]) if self._value_w is not None else None
+            self.fused.forward_into(self.obs[t], self.scores[t], self.noise_std, seq=t, seq_base=self._seq_base, ou=ou, sample=sample,
+                                    value=value, games=games)
+            self.env._launch(self.scores[t].data_ptr(), self._kind, False, None,
+                             self.obs[t + 1].data_ptr(), self.rew[t].data_ptr(), self._done[t].data_ptr(),
+                             env_done_ptr=self.env_done[t + 1].data_ptr(), games=games)
+            return
         if self.fused is not None:
             # graph arguments are frozen: the noise key is (seed, seq_base + t, row) with seq_base a device word that the
             # graph advances by T once per replay (_body)
@@ -378,8 +403,22 @@ class PolicyRollout:
                                      env_done_t_ptr=self.env_done[1].data_ptr(),
                                      scripted_seed=0 if self.opponent is None else self.opponent.seed)
         else:
-            for t in range(self.T):
-                self._tick(t)
+            ranges = self.env.chain_ranges(self.chains)
+            if len(ranges) == 1:
+                for t in range(self.T):
+                    self._tick(t)
+            else:
+                main = torch.cuda.current_stream(self.env.device)
+                if self._side is None:
+                    self._side = [torch.cuda.Stream(self.env.device) for _ in ranges[1:]]
+                for s in self._side:
+                    s.wait_stream(main)
+                for r, games in enumerate(ranges):
+                    with torch.cuda.stream(main if r == 0 else self._side[r - 1]):
+                        for t in range(self.T):
+                            self._tick(t, games)
+                for s in self._side:
+                    main.wait_stream(s)
             self.env._env_done.copy_(self.env_done[self.T])        # the per-tick launches wrote their flags into the record
         self._seq_base.add_(self.T)                    # fresh exploration-noise keys for the next run
 

@@ -424,6 +424,43 @@ def test_exploration_noise_does_not_depend_on_the_sharding(one_launch):
     assert int(whole.env.counters()[:, 0].sum()) > 0
 
 
+@pytest.mark.parametrize("n,cont,chains,heads", [(1, False, 2, "ppo"), (2, False, 3, "noise"), (4, False, 2, "noise"), (2, True, 2, "noise"), (3, False, 4, "ppo")])
+def test_chained_rollout_records_the_same_transitions(n, cont, chains, heads):
+    """PolicyRollout(chains=P): the games as P ranges, each a chain of (actor -> step) launch pairs on its own branch of the graph --
+    the transitions of chains=1 bit for bit (observations, scores, rewards, flags, OU state, log-probabilities, values), eagerly and
+    as a captured graph."""
+    from deep_rl_battlespace_amd.rollout import PolicyRollout, StackedActor
+    E, T = 1100, 20
+    torch.manual_seed(n)
+    actor = StackedActor(2 * n, 3 * n + 2, 3 if cont else 4, device="cuda")
+    critic = StackedActor(2 * n, 3 * n + 2, 1, device="cuda")
+    with torch.no_grad():
+        actor.w3.mul_(60.0)
+    kw = dict(sample="categorical", temperature=0.7, value_actor=critic) if heads == "ppo" else dict(noise_std=0.3, ou_scale=0.2)
+
+    def play(P, graph):
+        env = _env(n_agents=n, n_envs=E, seed=17, auto_reset=True, continuous_actions=cont); env.reset()
+        ro = PolicyRollout(env, actor, T, seed=9, chains=P, **kw); ro.start()
+        if graph:
+            ro.capture()
+        for _ in range(9):
+            ro.run()
+        torch.cuda.synchronize()
+        return ro
+    one = play(1, False)
+    for graph in (False, True):
+        ch = play(chains, graph)
+        for name in ("obs", "scores", "rew", "done", "env_done") + (("logp", "value") if heads == "ppo" else ()):
+            assert torch.equal(getattr(one, name), getattr(ch, name)), (name, graph)
+        if heads != "ppo":
+            assert torch.equal(one.ou["state"], ch.ou["state"])
+        sa, sb = one.env.export_state(), ch.env.export_state()
+        assert all(torch.equal(sa[k], sb[k]) for k in sa) and torch.equal(one.env._env_done, ch.env._env_done)
+    assert int(one.env.counters()[:, 0].sum()) > 0
+    with pytest.raises(ValueError):
+        PolicyRollout(one.env, actor, T, chains=2, one_launch=True)
+
+
 def test_exported_game_state_renders_what_the_oracle_holds(tmp_path):
     """f-4 (battle_env.py:498-560 draws planes, bases and bullets of ONE game): the state block of a running batch is exported,
     one game of it equals the oracle's game field by field, and its host-side image shows every live sprite where the state
