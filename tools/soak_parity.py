@@ -18,6 +18,8 @@ ap.add_argument("--steps", type=int, default=1500); ap.add_argument("--check", t
 ap.add_argument("--policy", choices=("random", "instinct"), default="random"); ap.add_argument("--seed", type=int, default=2024)
 ap.add_argument("--wide", action="store_true", help="take the 64-bit-offset kernels (BSX_F_WIDE_OFFSETS)")
 ap.add_argument("--many", type=int, default=0, help="K > 0: the HIP side runs K ticks per launch (bsx_step_many_discrete); random policy only")
+ap.add_argument("--chains", type=int, default=0, help="P > 0 (with --many K): the HIP side replays ONE graph of K ticks whose launches are P chains over game ranges "
+                                                      "(capture_steps(chains=P), bsx_step_discrete_range) instead of a K-tick launch")
 args = ap.parse_args()
 E, n, T = args.envs, args.n_agents, args.steps
 A = 2 * n
@@ -31,7 +33,12 @@ t0 = time.time(); n_obs = n_exact = 0; max_rel = 0.0
 K = args.many
 if K and args.policy != "random":
     sys.exit("--many needs --policy random")
+if args.chains and (not K or T % K):
+    sys.exit("--chains needs --many K with K dividing --steps")
 chunk = None
+if args.chains:
+    g_act = torch.zeros((K, E, A), dtype=torch.int32, device="cuda")
+    g_graph, g_out = env.capture_steps(g_act, store=True, chains=args.chains)
 for t in range(T):
     if args.policy == "instinct":
         for tm in teams:
@@ -44,7 +51,11 @@ for t in range(T):
             k = min(K, T - t)
             ca = torch.randint(0, 4, (k, E, A), generator=g, device="cuda", dtype=torch.int32)
             ca = torch.where(torch.rand((k, E, A), generator=g, device="cuda") < 0.4, torch.ones_like(ca), ca)
-            chunk = (ca, env.step_many(ca, store=True))
+            if args.chains:
+                g_act.copy_(ca); g_graph.replay()
+                chunk = (ca, g_out)
+            else:
+                chunk = (ca, env.step_many(ca, store=True))
         acts = chunk[0][t % K]
         obs, rew, done = (x[t % K] for x in chunk[1])
         if (t % args.check == args.check - 1 or t == T - 1) and (t % K != K - 1 and t != T - 1):
@@ -73,7 +84,8 @@ for t in range(T):
                 print(json.dumps({"mismatch": f, "step": t})); sys.exit(1)
         print(f"step {t + 1}: ok ({time.time() - t0:.0f} s)", file=sys.stderr, flush=True)
 cnt = env.counters().sum(0)
-print(json.dumps({"soak": "ok", "policy": args.policy, "hip_launch": f"{K} ticks per launch (bsx_step_many_discrete)" if K else "one launch per step", "envs": E, "n_per_team": n, "steps": T, "agent_steps": E * A * T,
+print(json.dumps({"soak": "ok", "policy": args.policy, "hip_launch": (f"one graph of {K} ticks, {args.chains} chains of range launches (bsx_step_discrete_range)" if args.chains else
+                                 f"{K} ticks per launch (bsx_step_many_discrete)" if K else "one launch per step"), "envs": E, "n_per_team": n, "steps": T, "agent_steps": E * A * T,
                   "observation_values": n_obs, "observation_values_bit_identical": n_exact,
                   "games": int(cnt[0]), "ties": int(cnt[1]), "red_wins": int(cnt[2]), "blue_wins": int(cnt[3]),
                   "seconds": round(time.time() - t0, 1)}))
