@@ -1,0 +1,125 @@
+"""The randomised differential case generator and checker behind tools/fuzz_parity.py and tests/test_hip_fuzz.py: one random
+configuration of the HIP step() path (team size, ragged batch, action encoding, rewards, env_offset, resets, jitter source, offset
+width, launch form) played against the C oracle -- test infrastructure, like everything that touches oracle/."""
+import numpy as np
+import torch
+
+import deep_rl_battlespace_amd as bsx
+from oracle import cref
+
+STATE = ("px", "py", "pdir", "php", "palive", "base_xy", "bhp", "tick", "env_done", "winner", "bl_live", "counters")
+
+
+def draw_case(rng, max_envs=6000):
+    n = int(rng.choice([1, 1, 1, 2, 2, 3, 4, 4, 5, 6, 8, 12, 16]))
+    E = int(rng.choice([rng.integers(1, 40), rng.integers(40, max(41, max_envs // max(1, n // 2))),
+                        256 * rng.integers(1, 9) + rng.integers(-1, 2)]))
+    cont = bool(rng.random() < 0.35)
+    enc = str(rng.choice(["f32", "f64", "f32x4"])) if cont else str(rng.choice(["int", "int", "scores"]))
+    form = str(rng.choice(["step", "step", "many", "graph", "chains"]))
+    auto = bool(rng.random() < 0.75)
+    host_u = bool(form == "step" and rng.random() < 0.3)
+    case = dict(n=n, E=max(1, E), cont=cont, enc=enc, form=form, auto_reset=auto, host_u=host_u,
+                wide=bool(rng.random() < 0.3), env_offset=int(rng.choice([0, 0, 777, 2 ** 33 + 5])),
+                seed=int(rng.integers(0, 2 ** 31)), T=int(rng.integers(12, 26)) * 10, K=int(rng.choice([5, 10, 30])),
+                chains=int(rng.choice([2, 3, 4, 7])), p_shoot=float(rng.choice([0.25, 0.5, 0.8])),
+                rewards=[int(v) for v in (rng.integers(50, 150), rng.integers(1, 20), -rng.integers(0, 4), -rng.integers(0, 9), -rng.integers(0, 30))]
+                if rng.random() < 0.5 else [100, 10, -1, -5, -20])
+    return case
+
+
+def actions_for(case, T, gen):
+    E, A = case["E"], 2 * case["n"]
+    if case["cont"]:
+        a = torch.rand((T, E, A, 3), generator=gen, device="cuda", dtype=torch.float64) * 2.6 - 1.3      # beyond [-1, 1]: clipped in-kernel
+        a[..., 2] += case["p_shoot"] - 0.5
+        if case["enc"] == "f64":
+            return a.contiguous()
+        a = a.to(torch.float32)
+        if case["enc"] == "f32x4":
+            a = torch.cat([a, torch.full((T, E, A, 1), 9.0, device="cuda")], -1)
+        return a.contiguous()
+    if case["enc"] == "scores":
+        a = torch.randn((T, E, A, 4), generator=gen, device="cuda")
+        a[..., 1] += 3.0 * (case["p_shoot"] - 0.25)
+        return a.contiguous()
+    a = torch.randint(0, 4, (T, E, A), generator=gen, device="cuda", dtype=torch.int32)
+    a = torch.where(torch.rand((T, E, A), generator=gen, device="cuda") < case["p_shoot"], torch.ones_like(a), a)
+    a = torch.where(torch.rand((T, E, A), generator=gen, device="cuda") < 0.01, torch.full_like(a, 7), a)   # out of range: the plane stays
+    return a.contiguous()
+
+
+def oracle_actions(case, a_t):
+    a = a_t.cpu().numpy()
+    if case["enc"] == "f32x4":
+        a = np.ascontiguousarray(a[..., :3])
+    return a
+
+
+def run_case(case):
+    n, E, T = case["n"], case["E"], case["T"]
+    kw = dict(n_agents=n, seed=case["seed"], auto_reset=case["auto_reset"], env_offset=case["env_offset"], continuous_actions=case["cont"],
+              hit_base_reward=case["rewards"][0], hit_plane_reward=case["rewards"][1], miss_punishment=case["rewards"][2],
+              die_punishment=case["rewards"][3], lose_punishment=case["rewards"][4])
+    env = bsx.parallel_env(n_envs=E, wide_offsets=case["wide"], **kw)
+    c = cref.CRefBatch(E, **kw)
+    env.reset(); c.reset()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(case["seed"] ^ 0x5EED)
+    form, K = case["form"], case["K"]
+    T -= T % K
+    acts = actions_for(case, T, gen)
+    u_all = torch.rand((T, E, 2 * n), generator=gen, device="cuda", dtype=torch.float64) if case["host_u"] else None
+    stats = dict(vals=0, exact=0)
+    graph = None
+    if form in ("graph", "chains"):
+        g_act = torch.zeros_like(acts[:K])
+        graph, g_out = env.capture_steps(g_act, store=True, chains=case["chains"] if form == "chains" else 1)
+
+    def check_state(t):
+        sh = {k: v.cpu().numpy() for k, v in env.export_state().items()}
+        sc = c.export_state()
+        for f in STATE:
+            if not np.array_equal(sh[f], sc[f]):
+                return f"state {f} after call {t}"
+        m = sc["bl_live"].astype(bool)
+        for f in ("bl_x", "bl_y", "bl_dir"):
+            if not np.array_equal(sh[f][m], sc[f][m]):
+                return f"state {f} after call {t}"
+        return None
+
+    for t0 in range(0, T, K):
+        if form == "step":
+            outs = None
+        elif form == "many":
+            outs = env.step_many(acts[t0:t0 + K], store=True)
+        else:
+            g_act.copy_(acts[t0:t0 + K]); graph.replay()
+            outs = g_out
+        for k in range(K):
+            t = t0 + k
+            if form == "step":
+                a_t = acts[t][..., :3].contiguous() if case["enc"] == "f32x4" else acts[t]     # (4-wide rows are a T-call encoding: an actor's output buffer)
+                obs, rew, done = env.step_batch(a_t, u=u_all[t] if u_all is not None else None)
+            else:
+                obs, rew, done = outs[0][k], outs[1][k], outs[2][k]
+            co, cr, cd = c.step(oracle_actions(case, acts[t]), u=u_all[t].cpu().numpy() if u_all is not None else None)
+            o = obs.cpu().numpy()
+            if not np.array_equal(done.cpu().numpy().astype(bool), cd):
+                return f"done at call {t}", stats
+            if not np.array_equal(rew.cpu().numpy().astype(np.float64), cr):
+                return f"rew at call {t}", stats
+            diff = np.abs(o.astype(np.float64) - co)
+            if ((diff > 1e-7) & (diff / np.maximum(np.abs(co), 1e-30) > 1e-5)).any():
+                return f"obs at call {t}", stats
+            stats["vals"] += o.size; stats["exact"] += int((o == co).sum())
+        if form == "step" and not np.array_equal(env.env_done.cpu().numpy(), c.env_done.astype(bool)):
+            return f"env_done after call {t0 + K - 1}", stats
+        if (t0 // K) % 4 == 3 or t0 + K >= T:
+            bad = check_state(t0 + K - 1)
+            if bad:
+                return bad, stats
+        if not case["auto_reset"] and (t0 // K) % 3 == 2:          # re-spawn the finished games by hand (battle_env.py:246-279), both sides
+            mask = c.env_done.astype(bool).copy()
+            if mask.any():
+                env.reset(mask=torch.from_numpy(mask).cuda()); c.reset(mask=mask)
+    return None, stats
