@@ -45,6 +45,13 @@ constexpr bool X_CORNERS_ALL = true;
 constexpr bool X_CORNERS_ALL = false;
 #endif
 
+// -DBSX_X_DEPHASE=<k | 256>: the fused rollout's workgroups of the upper half of the grid (| 256: the odd ones) sleep k x 8 128 cycles
+// before their first tick (same results)
+#ifndef BSX_X_DEPHASE
+#define BSX_X_DEPHASE 0
+#endif
+constexpr int X_DEPHASE = BSX_X_DEPHASE;
+
 #ifdef BSX_STAMPS
 constexpr int BUILD_FLAGS = int(DIAG & 0xFFu) | 0x100;
 __device__ unsigned long long* g_stamps = nullptr;

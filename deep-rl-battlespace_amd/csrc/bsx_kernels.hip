@@ -49,6 +49,7 @@ constexpr int BUILD_FLAGS = 0;
 constexpr bool PACK_BULLETS = true;
 constexpr int OBS_FORM = 0;
 constexpr bool X_CHEAP_ALL = false, X_CORNERS_ALL = false;
+constexpr int X_DEPHASE = 0;
 #define STAMP(i) do { } while (0)
 #define FSTAMP(i) do { } while (0)
 #define PSTAMP(i) do { } while (0)
@@ -744,6 +745,10 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 
+    if constexpr (ACTOR && X_DEPHASE != 0) {             // variant builds only: half of the workgroups start late (do two waves of a SIMD fall into anti-phase?)
+        if ((X_DEPHASE & 256) ? (blockIdx.x & 1u) : (blockIdx.x >= gridDim.x / 2))
+            for (int i = 0; i < (X_DEPHASE & 255); ++i) __builtin_amdgcn_s_sleep(127);
+    }
     for (int tk = 0; tk < (MULTI ? p.T : 1); ++tk) {
     // In the tick loop the compiler would hoist everything loop-invariant -- 36 row addresses, the Philox key schedule,
     // every fp64 constant -- and run out of registers (256 VGPRs, 1-2 waves per SIMD, SGPR spills).  Passing the three

@@ -22,10 +22,11 @@ def main():
     ap.add_argument("--precision", default="f32")
     ap.add_argument("--ticks", type=int, default=32)
     ap.add_argument("--continuous", action="store_true")
+    ap.add_argument("--only-one-launch", action="store_true")
     args = ap.parse_args()
     dev, E, T = torch.device("cuda:0"), args.envs, args.ticks
     for n in args.teams:
-        forms = [("graph", P) for P in args.chains] + [("one_launch", 1)]
+        forms = ([] if args.only_one_launch else [("graph", P) for P in args.chains]) + [("one_launch", 1)]
         for form, P in forms:
             env = bsx.parallel_env(n_agents=n, n_envs=E, auto_reset=True, seed=1234, device=dev, continuous_actions=args.continuous)
             env.reset()
