@@ -45,8 +45,8 @@ constexpr bool X_CORNERS_ALL = true;
 constexpr bool X_CORNERS_ALL = false;
 #endif
 
-// -DBSX_X_DEPHASE=<k | 256>: the fused rollout's workgroups of the upper half of the grid (| 256: the odd ones) sleep k x 8 128 cycles
-// before their first tick (same results)
+// -DBSX_X_DEPHASE=<k | 256 | 512 | 1024>: the fused rollout's (| 512: every step kernel's) workgroups of the upper half of the grid
+// (| 256: the odd ones) sleep k x 8 128 (| 1024: k x 1 984) cycles before their first tick (same results)
 #ifndef BSX_X_DEPHASE
 #define BSX_X_DEPHASE 0
 #endif

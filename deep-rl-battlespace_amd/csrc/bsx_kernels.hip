@@ -745,9 +745,9 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 
-    if constexpr (ACTOR && X_DEPHASE != 0) {             // variant builds only: half of the workgroups start late (do two waves of a SIMD fall into anti-phase?)
+    if constexpr ((ACTOR || (X_DEPHASE & 512)) && X_DEPHASE != 0) {   // variant builds only: half of the workgroups start late (do the waves of a SIMD fall into anti-phase?)
         if ((X_DEPHASE & 256) ? (blockIdx.x & 1u) : (blockIdx.x >= gridDim.x / 2))
-            for (int i = 0; i < (X_DEPHASE & 255); ++i) __builtin_amdgcn_s_sleep(127);
+            for (int i = 0; i < (X_DEPHASE & 63); ++i) __builtin_amdgcn_s_sleep((X_DEPHASE & 1024) ? 31 : 127);
     }
     for (int tk = 0; tk < (MULTI ? p.T : 1); ++tk) {
     // In the tick loop the compiler would hoist everything loop-invariant -- 36 row addresses, the Philox key schedule,
