@@ -38,6 +38,9 @@ pass, as MI355X_MICROARCH.md prescribes) right after the timed region -- the cou
 `traffic_source` says so, or names the profiles/traffic.json series that was used instead (`--no-live-traffic`, no rocprofv3, a
 profiler already attached, N > 1; always for `other_workloads`).  frac_claimed = min(frac, frac_on_traffic) is the figure to quote;
 live_aware_bytes_per_launch is what this build's layout must move with the measured bullet load (b_live below).
+chained_graphs (not the headline; `--chains P` runs any workload that way): the same K steps with every graph's launches as P
+independent chains over game ranges (parallel_env.capture_steps(chains=P), bsx_step_*_range): per step the whole batch still
+advances one tick -- as P launches that wait only for their own range's previous launch.  Same games bit for bit.
 cpu_baseline: the CPU oracle (oracle/battlespace_ref.py, the scalar Python restatement of the reference's step()) on
 configs[0] -- 1 game of 1v1, the same uniform random actions, reset on done -- timed on one host core of this box.
 """
