@@ -21,6 +21,8 @@ if True:
     L = _lib.load()
     G = 2 if n == 1 else (4 if n == 2 else 8)
     waves = (E * G + 63) // 64
+    if mode == "rollout":
+        waves = (E + 31) // 32                      # the fused kernel's workgroup = 32 games; stamps are indexed by workgroup (its waves share a row)
     buf = torch.zeros(waves * 10, dtype=torch.int64, device="cuda")
     L.bsx_debug_set_stamps.argtypes = [ctypes.c_void_p]
     acts = (torch.rand((64, E, 2 * n, 3), device='cuda') * 2 - 1) if cont else torch.randint(0, 4, (64, E, 2 * n), dtype=torch.int32, device="cuda")
