@@ -677,7 +677,9 @@ class parallel_env:
                 for i, a in enumerate(ids):
                     if d[i]:
                         self.dones[a] = True
-        rewards = {a: (int(round(float(r[i]))) if self._int_rewards else float(r[i])) for i, a in enumerate(ids)}
+        # the reference starts every agent at int 0 and adds the constants of the events that occur (battle_env.py:299,338-362): an agent
+        # without an event keeps the int 0 whatever the constants' types; sums come from the kernel's float64 accumulator through float32
+        rewards = {a: (int(round(float(r[i]))) if (self._int_rewards or r[i] == 0.0) else float(r[i])) for i, a in enumerate(ids)}
         return ({a: o[i].copy() for i, a in enumerate(ids)}, rewards, self.dones, {a: {} for a in ids})
 
     # ------------------------------------------------------------------ observe (battle_env.py:202-244)

@@ -123,3 +123,103 @@ def run_case(case):
             if mask.any():
                 env.reset(mask=torch.from_numpy(mask).cuda()); c.reset(mask=mask)
     return None, stats
+
+
+# ---------------------------------------------------------------------------------------------- the drop-in surface (one game)
+def draw_dropin_case(rng):
+    """One game behind the reference's own surface (n_envs=None: dict actions, numpy rows, Python numbers, stdlib `random` draws in the
+    reference's order) against the Python oracle on the same random stream."""
+    n = int(rng.choice([1, 1, 2, 2, 3, 4, 6]))
+    cont = bool(rng.random() < 0.35)
+    return dict(n=n, cont=cont, seed=int(rng.integers(0, 2 ** 31)), T=int(rng.integers(150, 420)), p_shoot=float(rng.choice([0.25, 0.5, 0.8])),
+                encoding=str(rng.choice(["int", "int", "vector"])) if not cont else str(rng.choice(["f64", "f32"])),
+                all_agents=bool(rng.random() < 0.5), p_empty=float(rng.choice([0.0, 0.0, 0.01])),
+                rewards=[[100, 10, -1, -5, -20], [1.0, 0.9, -0.02, -0.03, -0.05],      # the reference's defaults / its training config (main.py:33-37)
+                         [float(v) for v in (rng.integers(50, 150) + 0.5, rng.integers(1, 20) + 0.25, -0.5 * rng.integers(1, 4), -1.5 * rng.integers(1, 6),
+                                             -float(rng.integers(1, 30)))]][int(rng.integers(0, 3))])
+
+
+def _dropin_actions(case, T):
+    """The action dicts of T calls, as (list of {agent index: value}, list of bool 'empty call'); drawn once, fed to both sides."""
+    g = np.random.default_rng(case["seed"] ^ 0xAC7)
+    A = 2 * case["n"]
+    out = []
+    for _ in range(T):
+        if g.random() < case["p_empty"]:
+            out.append(None)
+            continue
+        row = {}
+        for i in range(A):
+            if case["cont"]:
+                v = g.random(3) * 2.6 - 1.3
+                v[2] += case["p_shoot"] - 0.5
+                row[i] = v.astype(np.float32) if case["encoding"] == "f32" else v
+            elif case["encoding"] == "vector":
+                v = g.standard_normal(4).astype(np.float32)
+                v[1] += 3.0 * (case["p_shoot"] - 0.25)
+                row[i] = v
+            else:
+                a = int(g.integers(0, 4))
+                if g.random() < case["p_shoot"]:
+                    a = 1
+                if g.random() < 0.01:
+                    a = int(g.choice([-1, 4, 7]))                  # out of range: the plane stays where it is
+                row[i] = a
+        out.append(row)
+    return out
+
+
+def _play(env, case, acts):
+    """Reset, then T calls; a finished game is reset by hand as the reference's loops do (main.py:166-181).  Every return value."""
+    ids = env.possible_agents
+    rec = []
+    obs = env.reset()
+    rec.append(("reset", np.stack([np.asarray(obs[i]) for i in ids])))
+    for a in acts:
+        if env.env_done:
+            obs = env.reset()
+            rec.append(("reset", np.stack([np.asarray(obs[i]) for i in ids])))
+        if a is None:
+            d = {}
+        else:
+            live = ids if case["all_agents"] else list(env.agents)
+            d = {i: (np.array(a[ids.index(i)], copy=True) if isinstance(a[ids.index(i)], np.ndarray) else a[ids.index(i)]) for i in live}
+        obs, rew, done, _ = env.step(d)
+        rec.append(("step", np.stack([np.asarray(obs[i]) for i in ids]), [rew[i] for i in ids], [bool(done[i]) for i in ids],
+                    bool(env.env_done), list(env.agents)))
+    tally = (int(env.total_games), int(env.ties), int(env.team["red"]["wins"]), int(env.team["blue"]["wins"]))
+    return rec, tally
+
+
+def run_dropin_case(case):
+    """-> (None | what differed, {vals, exact}).  Both sides see the same stdlib random stream: the HIP env through the global generator
+    (rng='python', as the reference uses it), the oracle through its own random.Random(seed)."""
+    import random
+    from oracle import battlespace_ref as ref
+    kw = dict(n_agents=case["n"], continuous_actions=case["cont"], hit_base_reward=case["rewards"][0], hit_plane_reward=case["rewards"][1],
+              miss_punishment=case["rewards"][2], die_punishment=case["rewards"][3], lose_punishment=case["rewards"][4])
+    acts = _dropin_actions(case, case["T"])
+    random.seed(case["seed"])
+    got, tally_h = _play(bsx.parallel_env(**kw), case, acts)
+    want, tally_o = _play(ref.RefEnv(rng=random.Random(case["seed"]), **kw), case, acts)
+    stats = dict(vals=0, exact=0)
+    if len(got) != len(want):
+        return f"{len(got)} records against {len(want)}", stats
+    for t, (g, w) in enumerate(zip(got, want)):
+        if g[0] != w[0]:
+            return f"record {t}: {g[0]} against {w[0]}", stats
+        o, co = np.asarray(g[1], np.float64), np.asarray(w[1], np.float64)
+        diff = np.abs(o - co)
+        if ((diff > 1e-7) & (diff / np.maximum(np.abs(co), 1e-30) > 1e-5)).any():
+            return f"obs at record {t}", stats
+        stats["vals"] += o.size; stats["exact"] += int((np.asarray(g[1]) == np.asarray(w[1])).sum())
+        if g[0] == "step":
+            # values: equal for integer constants; float constants reach the caller through the kernel's float32 output (1e-6)
+            ints = all(isinstance(v, int) for v in case["rewards"])
+            if (g[2] != w[2] if ints else not np.allclose(g[2], w[2], rtol=1e-6, atol=1e-9)) or [type(x) for x in g[2]] != [type(x) for x in w[2]]:
+                return f"rewards at record {t}: {g[2]} against {w[2]}", stats
+            if g[3:] != w[3:]:
+                return f"flags / live agents at record {t}: {g[3:]} against {w[3:]}", stats
+    if tally_h != tally_o:
+        return f"tally {tally_h} against {tally_o}", stats
+    return None, stats

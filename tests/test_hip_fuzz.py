@@ -19,3 +19,18 @@ def test_random_configurations_against_the_c_oracle(seed):
         assert bad is None, (bad, case)
         forms.add(case["form"]); vals += st["vals"]; exact += st["exact"]
     assert len(forms) >= 3 and exact >= vals * (1 - 1e-6)
+
+
+def test_random_single_games_behind_the_reference_surface():
+    """The drop-in surface (one game, dict actions, reference return types, stdlib `random` in the reference's draw order) against the
+    Python oracle on the same random stream: 1v1 ... 6v6, discrete ints / score vectors / continuous float32 and float64, integer and
+    float reward constants, actions for all or only the live agents, `step({})`, resets after every finished game."""
+    import fuzz_util as fz
+    rng = np.random.default_rng(21)
+    vals = exact = 0
+    for _ in range(16):
+        case = fz.draw_dropin_case(rng)
+        bad, st = fz.run_dropin_case(case)
+        assert bad is None, (bad, case)
+        vals += st["vals"]; exact += st["exact"]
+    assert exact >= vals * (1 - 1e-6)

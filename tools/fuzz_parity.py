@@ -14,27 +14,35 @@ import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-from fuzz_util import draw_case, run_case          # the generator and the checker live with the tests (they drive the oracle)
+from fuzz_util import draw_case, run_case, draw_dropin_case, run_dropin_case   # the generators and checkers live with the tests (they drive the oracles)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0); ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-envs", type=int, default=6000); ap.add_argument("--cases", type=int, default=0, help="stop after this many cases (0 = by time)")
+    ap.add_argument("--dropin-share", type=float, default=0.15, help="share of cases that play ONE game behind the reference's own surface "
+                                                                     "(dict actions, reference return types, stdlib random) against the Python oracle")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     t0 = time.time()
     by, total = {}, dict(cases=0, agent_steps=0, vals=0, exact=0)
     while (time.time() - t0 < args.seconds) and (not args.cases or total["cases"] < args.cases):
-        case = draw_case(rng, args.max_envs)
+        dropin = rng.random() < args.dropin_share
+        case = draw_dropin_case(rng) if dropin else draw_case(rng, args.max_envs)
         try:
-            bad, st = run_case(case)
+            bad, st = run_dropin_case(case) if dropin else run_case(case)
         except Exception as exc:                                 # an argument the build refuses is a finding too
             bad, st = f"{type(exc).__name__}: {str(exc)[:200]}", dict(vals=0, exact=0)
         if bad:
             print(json.dumps({"fuzz": "MISMATCH", "what": bad, "case": case})); sys.exit(1)
-        total["cases"] += 1; total["agent_steps"] += case["E"] * 2 * case["n"] * (case["T"] - case["T"] % case["K"])
-        total["vals"] += st["vals"]; total["exact"] += st["exact"]
+        total["cases"] += 1; total["vals"] += st["vals"]; total["exact"] += st["exact"]
+        if dropin:
+            total["agent_steps"] += 2 * case["n"] * case["T"]
+            for key in ("drop-in surface", f"n={case['n']}", f"enc={case['encoding']}"):
+                by[key] = by.get(key, 0) + 1
+            continue
+        total["agent_steps"] += case["E"] * 2 * case["n"] * (case["T"] - case["T"] % case["K"])
         for key in (f"n={case['n']}", f"form={case['form']}", f"enc={case['enc']}", "wide" if case["wide"] else "narrow",
                     "auto_reset" if case["auto_reset"] else "masked_resets", "host_u" if case["host_u"] else "philox"):
             by[key] = by.get(key, 0) + 1
