@@ -226,3 +226,87 @@ def run_dropin_case(case):
     if tally_h != tally_o:
         return f"tally {tally_h} against {tally_o}", stats
     return None, stats
+
+
+# ---------------------------------------------------------------------------------------------- the policy in the loop (rows f-1, f-2)
+def draw_rollout_case(rng):
+    """A PolicyRollout in a random form -- one launch for all ticks / the two-kernel graph / the graph as chains over game ranges;
+    1v1 ... 4v4 (the graph forms also 5v5 ... 8v8); discrete or continuous; no noise / Gaussian / Ornstein-Uhlenbeck / a categorical
+    draw (with or without a value head); a scripted opponent on either side; f32 / bf16x3 / bf16x6 -- whose games the C oracle then
+    replays from the recorded score rows."""
+    form = str(rng.choice(["one_launch", "one_launch", "graph", "chains"]))
+    n = int(rng.choice([1, 1, 2, 2, 3, 4])) if form == "one_launch" else int(rng.choice([1, 2, 3, 4, 5, 6, 8]))
+    cont = bool(rng.random() < 0.35)
+    noise = str(rng.choice(["none", "gauss", "ou", "gauss+ou"] + ([] if cont else ["categorical"])))
+    opp = "none" if form == "chains" else str(rng.choice(["none", "none", "red", "blue"]))
+    if cont and opp != "none":
+        opp = "none"          # (the scripted rows are played in float64 and RECORDED in float32: the record alone does not replay them)
+    return dict(form=form, n=n, cont=cont, noise=noise, opponent=opp, precision=str(rng.choice(["f32", "f32", "bf16x3", "bf16x6"])),
+                E=int(rng.choice([rng.integers(33, 300), rng.integers(300, 2500), 256 * rng.integers(1, 6) + rng.integers(-1, 2)])),
+                T=int(rng.choice([8, 16, 24])), runs=int(rng.integers(7, 12)), chains=int(rng.choice([2, 3])),
+                value=bool(noise == "categorical" and (n == 1 or form != "one_launch") and rng.random() < 0.5),
+                ou_restart=bool(rng.random() < 0.7), seed=int(rng.integers(0, 2 ** 31)))
+
+
+def run_rollout_case(case):
+    from deep_rl_battlespace_amd import instinct
+    from deep_rl_battlespace_amd.rollout import PolicyRollout, StackedActor
+    n, E, T, cont = case["n"], case["E"], case["T"], case["cont"]
+    kw = dict(n_agents=n, seed=case["seed"], auto_reset=True, continuous_actions=cont)
+    env = bsx.parallel_env(n_envs=E, **kw)
+    c = cref.CRefBatch(E, **kw)
+    env.reset(); o_c = c.reset().copy()
+    torch.manual_seed(case["seed"] & 0xFFFF)
+    actor = StackedActor(2 * n, 3 * n + 2, 3 if cont else 4, device="cuda")
+    with torch.no_grad():
+        actor.w3.mul_(60.0)
+    rk = dict(one_launch=case["form"] == "one_launch", precision=case["precision"], seed=case["seed"] % 1000, ou_restart=case["ou_restart"],
+              chains=case["chains"] if case["form"] == "chains" else 1)
+    if "gauss" in case["noise"]:
+        rk["noise_std"] = 0.3
+    if "ou" in case["noise"]:
+        rk["ou_scale"] = 0.2
+    if case["noise"] == "categorical":
+        rk.update(sample="categorical", temperature=0.8)
+        if case["value"]:
+            rk["value_actor"] = StackedActor(2 * n, 3 * n + 2, 1, device="cuda")
+    if case["opponent"] != "none":
+        mine, theirs = (env.possible_red, env.possible_blue) if case["opponent"] == "red" else (env.possible_blue, env.possible_red)
+        rk["opponent"] = instinct.Team(mine, theirs, env)
+    ro = PolicyRollout(env, actor, T, **rk)
+    ro.start(); ro.capture()
+    stats = dict(vals=0, exact=0)
+    for run in range(case["runs"]):
+        ro.run()
+        torch.cuda.synchronize()
+        obs, sc, rew, done, edone = (x.cpu().numpy() for x in (ro.obs, ro.scores, ro.rew, ro._done, ro.env_done))
+        if run == 0 and not np.allclose(obs[0], o_c, rtol=1e-5, atol=1e-7):
+            return "the observations the rollout starts from", stats
+        for t in range(T):
+            if not np.array_equal(edone[t], c.env_done):
+                return f"env_done before tick {t} of run {run}", stats
+            co, cr, cd = c.step(np.ascontiguousarray(sc[t][..., :3]) if cont else sc[t])
+            if not np.array_equal(done[t].astype(bool), cd):
+                return f"done at tick {t} of run {run}", stats
+            if not np.array_equal(rew[t].astype(np.float64), cr):
+                return f"rew at tick {t} of run {run}", stats
+            diff = np.abs(obs[t + 1].astype(np.float64) - co)
+            if ((diff > 1e-7) & (diff / np.maximum(np.abs(co), 1e-30) > 1e-5)).any():
+                return f"obs after tick {t} of run {run}", stats
+            stats["vals"] += co.size; stats["exact"] += int((obs[t + 1] == co).sum())
+        if not np.array_equal(edone[T], c.env_done) or not np.array_equal(env.winner.cpu().numpy(), c.winner):
+            return f"flags after run {run}", stats
+    sh = {k: v.cpu().numpy() for k, v in env.export_state().items()}
+    scx = c.export_state()
+    for f in STATE:
+        if not np.array_equal(sh[f], scx[f]):
+            return f"state {f} at the end", stats
+    m = scx["bl_live"].astype(bool)
+    for f in ("bl_x", "bl_y", "bl_dir"):
+        if not np.array_equal(sh[f][m], scx[f][m]):
+            return f"state {f} at the end", stats
+    if case["noise"] == "categorical":                       # the recorded log-probability belongs to the recorded row's arg-max, and is one
+        lp = ro.logp.cpu().numpy()
+        if not (np.isfinite(lp).all() and (lp <= 1e-6).all()):
+            return "log-probabilities", stats
+    return None, stats

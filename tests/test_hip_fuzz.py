@@ -34,3 +34,19 @@ def test_random_single_games_behind_the_reference_surface():
         assert bad is None, (bad, case)
         vals += st["vals"]; exact += st["exact"]
     assert exact >= vals * (1 - 1e-6)
+
+
+@pytest.mark.parametrize("seed", [31, 32])
+def test_random_policy_rollouts_replayed_by_the_c_oracle(seed):
+    """PolicyRollout in random forms (one launch / two-kernel graph / chains; 1v1 ... 8v8; discrete, continuous; Gaussian, OU,
+    categorical + value head; scripted opponents; f32 and split-bf16 actors): the C oracle replays the games from the recorded score
+    rows -- rewards, flags and the final state identical, observations within 1e-5."""
+    import fuzz_util as fz
+    rng = np.random.default_rng(seed)
+    forms = set()
+    for _ in range(12):
+        case = fz.draw_rollout_case(rng)
+        bad, st = fz.run_rollout_case(case)
+        assert bad is None, (bad, case)
+        forms.add(case["form"])
+    assert len(forms) >= 2

@@ -14,7 +14,7 @@ import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-from fuzz_util import draw_case, run_case, draw_dropin_case, run_dropin_case   # the generators and checkers live with the tests (they drive the oracles)
+from fuzz_util import draw_case, run_case, draw_dropin_case, run_dropin_case, draw_rollout_case, run_rollout_case   # the generators and checkers live with the tests (they drive the oracles)
 
 
 def main():
@@ -23,15 +23,17 @@ def main():
     ap.add_argument("--max-envs", type=int, default=6000); ap.add_argument("--cases", type=int, default=0, help="stop after this many cases (0 = by time)")
     ap.add_argument("--dropin-share", type=float, default=0.15, help="share of cases that play ONE game behind the reference's own surface "
                                                                      "(dict actions, reference return types, stdlib random) against the Python oracle")
+    ap.add_argument("--rollout-share", type=float, default=0.1, help="share of cases that run a PolicyRollout in a random form and let the C oracle replay its games")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     t0 = time.time()
     by, total = {}, dict(cases=0, agent_steps=0, vals=0, exact=0)
     while (time.time() - t0 < args.seconds) and (not args.cases or total["cases"] < args.cases):
-        dropin = rng.random() < args.dropin_share
-        case = draw_dropin_case(rng) if dropin else draw_case(rng, args.max_envs)
+        r_kind = rng.random()
+        dropin, rollout = r_kind < args.dropin_share, args.dropin_share <= r_kind < args.dropin_share + args.rollout_share
+        case = draw_dropin_case(rng) if dropin else (draw_rollout_case(rng) if rollout else draw_case(rng, args.max_envs))
         try:
-            bad, st = run_dropin_case(case) if dropin else run_case(case)
+            bad, st = run_dropin_case(case) if dropin else (run_rollout_case(case) if rollout else run_case(case))
         except Exception as exc:                                 # an argument the build refuses is a finding too
             bad, st = f"{type(exc).__name__}: {str(exc)[:200]}", dict(vals=0, exact=0)
         if bad:
@@ -40,6 +42,12 @@ def main():
         if dropin:
             total["agent_steps"] += 2 * case["n"] * case["T"]
             for key in ("drop-in surface", f"n={case['n']}", f"enc={case['encoding']}"):
+                by[key] = by.get(key, 0) + 1
+            continue
+        if rollout:
+            total["agent_steps"] += case["E"] * 2 * case["n"] * case["T"] * case["runs"]
+            for key in ("policy rollout", f"rollout form={case['form']}", f"rollout noise={case['noise']}", f"rollout opponent={case['opponent']}",
+                        f"rollout precision={case['precision']}", f"n={case['n']}"):
                 by[key] = by.get(key, 0) + 1
             continue
         total["agent_steps"] += case["E"] * 2 * case["n"] * (case["T"] - case["T"] % case["K"])
