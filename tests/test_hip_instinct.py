@@ -63,11 +63,11 @@ def test_continuous_instinct_reproduces_reference_agent(n):
     assert float(a1.abs().max()) <= 1.0 and not torch.equal(a1, a2)
 
 
-@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 6])
 def test_closed_loop_instinct_vs_instinct_matches_cpu_oracles(n):
     """Both teams scripted, env and opponent on device, against C-oracle env + Python-oracle opponent: same games."""
     from deep_rl_battlespace_amd import instinct
-    E, A, T = 96, 2 * n, 10 * (10 + 2 * n) + 30
+    E, A, T = (96 if n <= 2 else 40), 2 * n, 10 * (10 + 2 * n) + 30
     env = _env(n_agents=n, n_envs=E, seed=17, auto_reset=True)
     c = cref.CRefBatch(E, n_agents=n, seed=17, auto_reset=True)
     obs_h = env.reset(); obs_c = c.reset().copy()
