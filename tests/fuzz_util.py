@@ -23,6 +23,7 @@ def draw_case(rng, max_envs=6000):
                 wide=bool(rng.random() < 0.3), env_offset=int(rng.choice([0, 0, 777, 2 ** 33 + 5])),
                 seed=int(rng.integers(0, 2 ** 31)), T=int(rng.integers(12, 26)) * 10, K=int(rng.choice([5, 10, 30])),
                 chains=int(rng.choice([2, 3, 4, 7])), p_shoot=float(rng.choice([0.25, 0.5, 0.8])),
+                resume=bool(form in ("step", "many") and rng.random() < 0.3),    # checkpoint mid-run, throw the env away, continue in a new one
                 rewards=[int(v) for v in (rng.integers(50, 150), rng.integers(1, 20), -rng.integers(0, 4), -rng.integers(0, 9), -rng.integers(0, 30))]
                 if rng.random() < 0.5 else [100, 10, -1, -5, -20])
     return case
@@ -88,6 +89,10 @@ def run_case(case):
         return None
 
     for t0 in range(0, T, K):
+        if case.get("resume") and t0 // K == 2:
+            sd = env.state_dict()
+            env = bsx.parallel_env(n_envs=E, wide_offsets=case["wide"], **kw)      # (never reset: everything comes from the snapshot)
+            env.load_state_dict(sd)
         if form == "step":
             outs = None
         elif form == "many":

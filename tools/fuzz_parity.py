@@ -52,7 +52,8 @@ def main():
             continue
         total["agent_steps"] += case["E"] * 2 * case["n"] * (case["T"] - case["T"] % case["K"])
         for key in (f"n={case['n']}", f"form={case['form']}", f"enc={case['enc']}", "wide" if case["wide"] else "narrow",
-                    "auto_reset" if case["auto_reset"] else "masked_resets", "host_u" if case["host_u"] else "philox"):
+                    "auto_reset" if case["auto_reset"] else "masked_resets", "host_u" if case["host_u"] else "philox",
+                    "checkpoint + resume in a new env" if case.get("resume") else "uninterrupted"):
             by[key] = by.get(key, 0) + 1
         if total["cases"] % 10 == 0:
             print(f"{total['cases']} cases, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
