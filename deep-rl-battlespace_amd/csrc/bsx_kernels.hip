@@ -792,7 +792,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // (the kernel is latency-bound at 65 536 games -- 2 waves per SIMD -- so memory-level parallelism is what pays)
     if (!MULTI || tk == 0) {
         const uint4 erw = *elem(reinterpret_cast<const uint4*>(env_), ix_t(ec));
-        cnt4 = *elem(cnt_, ix_t(ec));                                 // .x = games finished so far = episode id of the RNG streams
+        if (!(DIAG & 16u)) cnt4 = *elem(cnt_, ix_t(ec));              // .x = games finished so far = episode id of the RNG streams
         games = cnt4.x;
         const uint4 prw = *elem(reinterpret_cast<const uint4*>(plane_), gt);
         if (!MULTI) load_inputs(0, rin);
