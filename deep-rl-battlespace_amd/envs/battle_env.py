@@ -497,8 +497,9 @@ class parallel_env:
         """The batch as `chains` contiguous game ranges [(first, count), ...] in whole 256-game blocks (what bsx_step_*_range takes);
         fewer ranges than asked when there are not that many blocks."""
         blocks = -(-self.n_envs // 256)
-        if chains == "auto":                               # measured on 65 536 ... 16 384 games (profiles/r03_4v4_issue_bound.json)
-            chains = {1: 1, 4: 3}.get(self.n_agents, 2)
+        if chains == "auto":                               # measured (profiles/r03_4v4_issue_bound.json): pays from ~260 k agents per step;
+            # below that the launches are short enough for the branches' bookkeeping (~1 us per step and branch) to cost more than it hides
+            chains = {1: 1, 4: 3}.get(self.n_agents, 2) if self.n_envs * self._A >= (1 << 18) else 1
         chains = max(1, min(int(chains), blocks))
         cuts = [(blocks * r // chains) * 256 for r in range(chains)] + [self.n_envs]
         return [(cuts[r], cuts[r + 1] - cuts[r]) for r in range(chains)]
@@ -516,7 +517,9 @@ class parallel_env:
                  are those of chains=1 bit for bit; what changes is that a range's step t+1 waits for ITS step t only, and one chain's
                  kernel boundary (launch, first loads, store drain) runs under the other chains' arithmetic.  Measured: nothing to
                  gain at 1v1; two chains take 13 ... 26 % off a step for 2v2, 3v3, 6v6 ... 16v16, three chains 16 % at 4v4; more
-                 branches than that cost more in graph bookkeeping than they hide.  "auto" picks by team size accordingly.
+                 branches than that cost more in graph bookkeeping than they hide -- as do any with fewer than ~260 k agents per
+                 step (16 384 x 4v4: 10.7 -> 9.8 us on the device but 10.8 -> 10.9 on the wall clock; 8 192 games: slower either
+                 way).  "auto" picks by team size and batch size accordingly.
         Returns (graph, outputs): graph.replay() runs the T steps; outputs = (obs, rew, done) tensors.
         Needs rng='philox' (no host draws inside a graph)."""
         if self.rng != "philox" or self._compat:

@@ -234,7 +234,7 @@ def test_chained_graph_plays_the_same_games(E, n, chains, mode):
     a = _env(n_agents=n, n_envs=E, seed=21, auto_reset=True, continuous_actions=cont); a.reset()
     b = _env(n_agents=n, n_envs=E, seed=21, auto_reset=True, continuous_actions=cont); b.reset()
     ranges = b.chain_ranges(chains)
-    assert len(b.chain_ranges("auto")) == min({1: 1, 4: 3}.get(n, 2), -(-E // 256))
+    assert len(b.chain_ranges("auto")) == 1                    # a batch this small gains nothing from chains
     assert ranges[0][0] == 0 and sum(c for _, c in ranges) == E and all(f % 256 == 0 for f, _ in ranges)
     assert all(ranges[i][0] + ranges[i][1] == ranges[i + 1][0] for i in range(len(ranges) - 1)) and len(ranges) == min(chains, -(-E // 256))
     T = 60
