@@ -494,15 +494,9 @@ class parallel_env:
                                                           *common), "bsx_rollout_discrete")
 
     def chain_ranges(self, chains):
-        """The batch as `chains` contiguous game ranges [(first, count), ...] in whole 256-game blocks (what bsx_step_*_range takes);
-        fewer ranges than asked when there are not that many blocks."""
-        blocks = -(-self.n_envs // 256)
-        if chains == "auto":                               # measured (profiles/r03_4v4_issue_bound.json): pays from ~260 k agents per step;
-            # below that the launches are short enough for the branches' bookkeeping (~1 us per step and branch) to cost more than it hides
-            chains = {1: 1, 4: 3}.get(self.n_agents, 2) if self.n_envs * self._A >= (1 << 18) else 1
-        chains = max(1, min(int(chains), blocks))
-        cuts = [(blocks * r // chains) * 256 for r in range(chains)] + [self.n_envs]
-        return [(cuts[r], cuts[r + 1] - cuts[r]) for r in range(chains)]
+        """The batch as `chains` contiguous game ranges [(first, count), ...] in whole 256-game blocks (sharding.chain_ranges)."""
+        from ..sharding import chain_ranges
+        return chain_ranges(self.n_envs, self.n_agents, chains)
 
     def capture_steps(self, actions, store=False, chains=1):
         """Capture T consecutive step() launches into ONE HIP graph (the launch-bound inner loop of a rollout).

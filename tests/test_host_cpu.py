@@ -126,6 +126,22 @@ def test_env_range_partitions_exactly():
         env_range(8, 2, 2)
 
 
+def test_chain_ranges_partition_the_batch_in_256_game_blocks():
+    """sharding.chain_ranges: what capture_steps(chains=) hands to bsx_step_*_range -- contiguous, exhaustive, every first game a
+    multiple of 256, never more ranges than blocks; "auto" by team size and batch size."""
+    from deep_rl_battlespace_amd import sharding as sh
+    for E in (1, 255, 256, 257, 1000, 4096, 65536, 65537, 1048576):
+        for P in (1, 2, 3, 4, 7, 100):
+            r = sh.chain_ranges(E, 2, P)
+            assert r[0][0] == 0 and sum(c for _, c in r) == E and all(c > 0 and f % 256 == 0 for f, c in r)
+            assert all(r[i][0] + r[i][1] == r[i + 1][0] for i in range(len(r) - 1)) and len(r) == min(P, -(-E // 256))
+            assert max(c for _, c in r) - min(c for _, c in r[:-1] or r) <= 256 + 255     # balanced to a block (the last range takes the ragged rest)
+    auto = lambda E, n: len(sh.chain_ranges(E, n, "auto"))   # noqa: E731
+    assert auto(65536, 1) == 1 and auto(1048576, 1) == 1                 # 1v1: nothing to gain
+    assert auto(65536, 2) == 2 and auto(65536, 3) == 2 and auto(65536, 4) == 3 and auto(16384, 16) == 2
+    assert auto(16384, 4) == 1 and auto(8192, 2) == 1 and auto(100, 8) == 1   # short launches: the branches cost more than they hide
+
+
 def test_spaces_metadata():
     from deep_rl_battlespace_amd.spaces import Box, Discrete
     b = Box(np.ones(5, np.float32), -np.ones(5, np.float32))
