@@ -257,6 +257,8 @@ class PolicyRollout:
         # chains > 1 (graph form, fused actor, no scripted opponent): the games as that many ranges, each its own chain of
         # (actor -> step) launch pairs on a branch of the graph (battle_env.capture_steps(chains=)): one range's matrix-core actor
         # pass runs under another range's step kernel.  Same transitions bit for bit.
+        if chains == "auto":                           # two chains where they were measured to pay: 2v2 and larger, from ~260 k agents per tick
+            chains = 2 if (env.n_agents >= 2 and env.n_envs * 2 * env.n_agents >= (1 << 18) and not one_launch and fused and opponent is None) else 1
         self.chains = int(chains)
         if self.chains > 1 and (one_launch or not fused or opponent is not None):
             raise ValueError("chains > 1 is for the graph form with the fused actor and no scripted opponent")
