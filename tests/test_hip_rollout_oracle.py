@@ -459,6 +459,7 @@ def test_chained_rollout_records_the_same_transitions(n, cont, chains, heads):
     assert int(one.env.counters()[:, 0].sum()) > 0
     with pytest.raises(ValueError):
         PolicyRollout(one.env, actor, T, chains=2, one_launch=True)
+    assert PolicyRollout(one.env, actor, T, chains="auto").chains == 1 and PolicyRollout(one.env, actor, T, chains="auto", one_launch=n <= 4).chains == 1   # a batch this small: one chain
 
 
 def test_exported_game_state_renders_what_the_oracle_holds(tmp_path):
