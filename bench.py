@@ -800,15 +800,17 @@ def rollout_lines(dev, E, K):
         except Exception as exc:                            # a variant this build does not offer is reported, not hidden
             out[tag] = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
         torch.cuda.empty_cache()
-    try:
-        out["reference evaluation workload (evaluate.py:32-76): 2v2, shipped checkpoints vs scripted instinct team"] = evaluation_line(dev, E)
-    except Exception as exc:
-        out["reference evaluation workload (evaluate.py:32-76): 2v2, shipped checkpoints vs scripted instinct team"] = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
+    for tag, prec in (("reference evaluation workload (evaluate.py:32-76): 2v2, shipped checkpoints vs scripted instinct team", "f32"),
+                      ("reference evaluation workload, the checkpoints' 64x64 layers as six bf16 matrix products of three-term splits (float32-class accuracy)", "bf16x6")):
+        try:
+            out[tag] = evaluation_line(dev, E, prec)
+        except Exception as exc:
+            out[tag] = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
     return {"workload": f"BASELINE.json configs[4]: {E} games x 1v1 + on-device actor per plane (obs 5 -> 64 -> LayerNorm -> 64 -> LayerNorm -> 4, "
                         "maddpg/networks.py:54-85), end to end", "variants": out}
 
 
-def evaluation_line(dev, E):
+def evaluation_line(dev, E, precision="f32"):
     """The reference's own evaluation workload on this path: 2v2, reward config models/completed_model/cf.json, red = the shipped
     checkpoints actor_plane0 / actor_plane1 (weights recorded in tests/golden/g12_evaluation.npz: data, not code) with
     Ornstein-Uhlenbeck noise 0.1 that is never restarted, blue = the scripted instinct team in-kernel, one launch per 32 ticks;
@@ -822,7 +824,7 @@ def evaluation_line(dev, E):
     n = int(g12["n_agents"])
     actor = reference_checkpoint_actor(g12, n, device=dev)
     env = bsx.parallel_env(n_agents=n, n_envs=E, auto_reset=True, seed=1234, device=dev, **cf)
-    res = play_reference_evaluation(env, actor, games=3 * E, T=32, one_launch=True, seed=12)      # ~3 games per slot: past the start-up transient
+    res = play_reference_evaluation(env, actor, games=3 * E, T=32, one_launch=True, seed=12, precision=precision)   # ~3 games per slot: past the start-up transient
     ro = res.pop("rollout")
     torch.cuda.synchronize(dev)
     samples = []
