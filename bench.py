@@ -101,33 +101,62 @@ def _cpu_model():
     return platform.processor() or platform.machine()
 
 
-def cpu_baseline(seconds_target=12.0):
-    """configs[0]: the oracle's step() on 1 game of 1v1, uniform random actions (seed 1234), reset on done; 1 core."""
+def _pin_one_core():
+    """"1 process pinned to 1 core".  Pins this process to ONE of the cores it may run on (the highest-numbered
+    one: core 0 takes the box's interrupts) and returns (restore(), core or None when the platform has no affinity call)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        core = allowed[-1]
+        os.sched_setaffinity(0, {core})
+        return (lambda: os.sched_setaffinity(0, set(allowed))), core
+    except (AttributeError, OSError):
+        return (lambda: None), None
+
+
+def _time_port(n_agents, seconds_target, warm=2000):
+    """The oracle's step() on ONE game of n_agents-v-n_agents, uniform random actions (seed 1234), reset on done -> (calls, seconds)."""
     import random
     import numpy as np
     from oracle import battlespace_ref as ref
     random.seed(1234)
-    env = ref.RefEnv(n_agents=1)
+    env = ref.RefEnv(n_agents=n_agents)
     ids = env.possible_agents
-    acts = np.random.default_rng(1234).integers(0, 4, size=(200_000, 2)).tolist()
+    A = len(ids)
+    acts = np.random.default_rng(1234).integers(0, 4, size=(200_000, A)).tolist()
     env.reset()
-    for k in range(2000):                                   # warm-up
+    for k in range(warm):
         if env.env_done:
             env.reset()
-        env.step({ids[0]: acts[k][0], ids[1]: acts[k][1]})
+        env.step(dict(zip(ids, acts[k])))
     calls = 0
     t0 = time.perf_counter()
     while True:
-        for k in range(10_000):
+        for k in range(2_000):
             if env.env_done:
                 env.reset()
-            a = acts[(calls + k) % 200_000]
-            env.step({ids[0]: a[0], ids[1]: a[1]})
-        calls += 10_000
+            env.step(dict(zip(ids, acts[(calls + k) % 200_000])))
+        calls += 2_000
         dt = time.perf_counter() - t0
         if dt >= seconds_target:
-            break
-    extra = {}
+            return calls, dt
+
+
+def cpu_baseline(seconds_target=12.0):
+    """configs[0]: the oracle's step() (the Python port of the reference's, oracle/battlespace_ref.py) on 1 game of 1v1, uniform
+    random actions (seed 1234), reset on done; one process pinned to one core, as BASELINE.md section 3 words it.  Beside it the
+    same port on 1 game of 4v4 (`port_4v4`: the same-run CPU figure for configs[2]) and, as context, the C port on all cores."""
+    import numpy as np
+    restore, core = _pin_one_core()
+    try:
+        calls, dt = _time_port(1, seconds_target)
+        calls4, dt4 = _time_port(4, seconds_target / 2, warm=500)
+    finally:
+        restore()
+    pin = f"pinned to core {core}" if core is not None else "not pinned (no sched_setaffinity)"
+    extra = {"port_4v4": {"value": round(calls4 * 8 / dt4, 1), "unit": "agent-steps/s", "cores": 1, "kind": "port",
+                          "sample": f"{calls4} step() calls of 1 game x 4v4 in {dt4:.1f} s, {pin}"},
+             "reference_published": {"1v1": 25500, "2v2": 23600, "4v4": 18600, "unit": "agent-steps/s",
+                                     "note": "BASELINE.md section 2: the reference itself (get_pos blits included), other hardware"}}
     try:    # context only: the C restatement of the same path (oracle/battlespace_ref.c, OpenMP over games), all host cores
         from oracle import cref
         Ec, Tc = 16384, 100
@@ -144,14 +173,13 @@ def cpu_baseline(seconds_target=12.0):
             dtc = time.perf_counter() - t1
             if dtc >= 2.0:
                 break
-        extra = {"c_port_all_cores": {"value": round(Ec * 2 * done_steps / dtc, 1), "unit": "agent-steps/s", "cores": os.cpu_count(),
-                                      "sample": f"{done_steps} steps of {Ec} games x 1v1 in {dtc:.1f} s, oracle/battlespace_ref.c, OpenMP"}}
+        extra["c_port_all_cores"] = {"value": round(Ec * 2 * done_steps / dtc, 1), "unit": "agent-steps/s", "cores": os.cpu_count(),
+                                     "sample": f"{done_steps} steps of {Ec} games x 1v1 in {dtc:.1f} s, battlespace_ref.c, OpenMP"}
     except Exception as exc:      # the C oracle is optional context; the Python port above is the reported baseline
-        extra = {"c_port_all_cores": {"error": str(exc)[:120]}}
-    return {**extra, "value": round(calls * 2 / dt, 1), "unit": "agent-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{calls} step() calls of 1 game x 1v1 (configs[0]), uniform random actions seed 1234, "
-                      f"reset on done, {dt:.1f} s on 1 of {os.cpu_count()} host cores ({_cpu_model()}, {platform.machine()}, "
-                      f"CPython {platform.python_version()}); oracle/battlespace_ref.py"}
+        extra["c_port_all_cores"] = {"error": str(exc)[:120]}
+    return {"value": round(calls * 2 / dt, 1), "unit": "agent-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{calls} step() calls of 1 game x 1v1 (configs[0]) in {dt:.1f} s, {pin} of {os.cpu_count()}",
+            "host": f"{_cpu_model()}, CPython {platform.python_version()}", **extra}
 
 
 def hashed_bits(T, lo, hi, A, k, seed, device):
@@ -244,8 +272,7 @@ def dropin_one_game(dev, calls=3000):
         env.step({ids[0]: acts[k][0], ids[1]: acts[k][1]})
     dt = time.perf_counter() - t0
     return {"agent_steps_per_s": round(calls * 2 / dt, 1), "step_calls_per_s": round(calls / dt, 1), "us_per_call": round(dt / calls * 1e6, 1),
-            "calls": calls, "note": "1 game x 1v1 (configs[0]) on the GPU behind the reference's own surface; bounded by the per-call "
-                                    "host <-> device round trip, not by the kernel"}
+            "calls": calls, "note": "1 game x 1v1 behind the reference's surface: one host<->device round trip per call"}
 
 
 def parse_args(argv=None):
@@ -347,48 +374,34 @@ def main():
     dev_index = 0 if args.rehearse_on_device0 else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    backend_note = None
+    backend_note, tgroup, clean_exit = None, None, True
     if world > 1:                                           # used for the barrier / max-time reduction only
-        import datetime
-        if args.backend == "nccl":
-            # RCCL carries nothing but the barrier and two tiny reductions here (the step path has no collective), so a node on
-            # which it cannot come up must not cost the measurement: every rank then falls back to gloo, and the line says so
-            try:
-                try:
-                    dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=180))  # RCCL over xGMI
-                except TypeError:                                   # older torch: no device_id argument
-                    dist.init_process_group("nccl", timeout=datetime.timedelta(seconds=180))
-                probe = torch.ones(1, device=dev)
-                dist.all_reduce(probe)
-                torch.cuda.synchronize(dev)
-                if int(probe.item()) != world:
-                    raise RuntimeError(f"all_reduce probe returned {probe.item()} for world size {world}")
-            except Exception as exc:                            # noqa: BLE001 -- whatever RCCL raised, the fallback is the same
-                backend_note = f"nccl (RCCL) did not come up: {type(exc).__name__}: {str(exc)[:160]}; gloo carries the barrier instead"
-                try:
-                    dist.destroy_process_group()
-                except Exception:                               # noqa: BLE001
-                    pass
-                args.backend = "gloo"
-                dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=180))
-        else:
-            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=180))
+        # RCCL carries nothing but the barrier and a few tiny reductions here (the step path has no collective), so a node on which
+        # it cannot come up must not cost the measurement -- and the decision must be the SAME on every rank: gloo comes up first,
+        # the RCCL probe runs beside it, and the ranks agree over gloo before anyone proceeds (sharding.init_timing_group)
+        tgroup, args.backend, backend_note, clean_exit = sharding.init_timing_group(args.backend, dev)
     red_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     def barrier():
         torch.cuda.synchronize(dev)
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=tgroup)
         torch.cuda.synchronize(dev)
 
-    def max_over_ranks(values):
+    per_rank = {}                                           # name -> [world][R] samples of every rank (N > 1 only)
+
+    def max_over_ranks(values, name=None):
         if world == 1:
             return list(values)
         t = torch.tensor(values, device=red_dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if name is not None:                                # every rank's own samples, for the per-rank arrays of the line
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(parts, t, group=tgroup)
+            per_rank[name] = [q.tolist() for q in parts]
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=tgroup)
         return t.tolist()
 
-    def timed_blocks(run, K, R, restore=None, run_b=None, Kb=None):
+    def timed_blocks(run, K, R, restore=None, run_b=None, Kb=None, tag=None):
         """-> (wall seconds per repeat, kernel ms per launch per repeat); see the module docstring (A), (B).
         restore: a recorded trajectory is rewound before every block (its device copy is what keeps the queue busy in (B)).
         run_b / Kb: (B) brackets Kb >= 100 launches -- the K-step block repeated inside ONE graph -- when K itself is shorter than
@@ -415,7 +428,7 @@ def main():
             ev1.record()
             torch.cuda.synchronize(dev)
             kms.append(ev0.elapsed_time(ev1) / Kb)
-        return max_over_ranks(walls), max_over_ranks(kms)
+        return max_over_ranks(walls, tag and tag + "walls"), max_over_ranks(kms, tag and tag + "kms")
 
     def ramp(run, ms, K):
         torch.cuda.synchronize(dev)
@@ -452,7 +465,7 @@ def main():
         turn = torch.where(hy * (600 - px) - hx * (400 - py) > 0, 2, 3)
         return torch.where(out | near_base, turn, torch.ones_like(turn)).to(torch.int32)
 
-    def measure(n, E, K, W, mode, graph_len, mix="uniform", continuous=False, R=None, do_stagger=True, chains=1):
+    def measure(n, E, K, W, mode, graph_len, mix="uniform", continuous=False, R=None, do_stagger=True, chains=1, tag=None):
         """K timed step() calls of E games x n-v-n on this rank, R times -> dict(env, walls, kms, G, live)."""
         A = 2 * n
         R = R or args.repeats
@@ -537,7 +550,7 @@ def main():
             ramp(run, args.ramp_ms, K)
         else:
             ramp(lambda k: (restore(), graph.replay()), args.ramp_ms, K)
-        walls, kms = timed_blocks(run, K, R, restore, run_b, Kb)
+        walls, kms = timed_blocks(run, K, R, restore, run_b, Kb, tag)
         if live is None and E * A <= (1 << 22):
             live = round(float(env.export_state(("bl_live",))["bl_live"].float().sum()) / (E * A), 3)
         return dict(env=env, walls=walls, kms=kms, G=G, live=live, Kb=Kb or K)
@@ -570,8 +583,7 @@ def main():
             out.update(traffic=tb, frac_on_traffic=fot, traffic_source=f"profiles/traffic.json[{key}] (series {te.get('series')})")
         out["frac_claimed"], out["roofline_frac"] = claim(frac, fot)
         if frac > 1.0:
-            out["roofline_frac_note"] = (f"the contract formula gives {frac}: its 12-slot algorithmic byte count is more than this workload moves "
-                                         "(state stays in the L2 / few bullets in flight); frac_on_traffic is the meaningful figure")
+            out["roofline_frac_note"] = f"contract formula gives {frac} > 1: its 12-slot count exceeds what moves"
         return out
 
     n, E = args.n_agents, args.envs_per_gpu
@@ -579,9 +591,9 @@ def main():
     K, W = args.steps, args.warmup
     if args.chains != 1 and args.mode != "graph":
         raise SystemExit("--chains is a property of the captured graph (--mode graph)")
-    head = measure(n, E, K, W, args.mode, args.graph_len, mix=args.action_mix, continuous=args.continuous, chains=args.chains)
+    head = measure(n, E, K, W, args.mode, args.graph_len, mix=args.action_mix, continuous=args.continuous, chains=args.chains, tag="head_")
     env = head["env"]
-    games = sharding.reduce_counters(sharding.local_counter_sums(env).to(red_dev))   # logging only, after the timed region
+    games = sharding.reduce_counters(sharding.local_counter_sums(env).to(red_dev), group=tgroup)   # logging only, after the timed region
     if args.digest_dir:
         # cross-process shard check (tests/test_hip_sharding.py): what this rank's games look like after the run
         import hashlib
@@ -640,8 +652,7 @@ def main():
             torch.cuda.empty_cache()
         # The same step() workloads with the graph's launches as independent chains over game ranges (capture_steps(chains=)): per step
         # the whole batch still advances one tick, as P launches that wait only for their own range's previous launch
-        chained = {"note": "one HIP graph, P branches = P game ranges, each a chain of per-step launches (bsx_step_*_range); same games bit for bit "
-                           "(tests/test_hip_fullsize.py::test_chained_graph_plays_the_same_games); us_per_step = HIP events around the replays / steps"}
+        chained = {"note": "one HIP graph, P chains of per-step launches over game ranges; same games bit for bit"}
         for tag, (n2, E2, K2, cont2, P2) in {
                 "65536 x 1v1, 2 chains": (1, 65536, Ko, False, 2),
                 "65536 x 4v4, 2 chains": (4, 65536, Ko, False, 2),
@@ -668,8 +679,7 @@ def main():
         key = f"E{E}_n{n}" + ("_cont" if args.continuous else "") + ("_dense" if args.action_mix == "dense" else "") + ("_many" if many else "")
         te = traffic_entry(key) if args.action_mix in ("uniform", "dense") else None
         traffic = te["hbm_bytes_per_tick" if many else "hbm_bytes_per_launch"] if te else None
-        tsrc = (f"profiles/traffic.json[{key}] (series {te.get('series')}): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                "workload, read side x2 (MI355X_MICROARCH.md); a constant from that profile, not measured by this run") if te else None
+        tsrc = f"profiles/traffic.json[{key}] series {te.get('series')} (a constant, not this run)" if te else None
         tdetail = None
         cpu_base = cpu_baseline() if (world == 1 and not args.no_cpu_baseline) else None      # before the counter passes: a quiet host
         if world == 1 and not args.no_live_traffic and args.chains == 1:   # (a chained graph's launches cover a range each: the per-launch counters do not describe a step)
@@ -680,56 +690,55 @@ def main():
             live_b, info = live_traffic(args, kernel_name(n, args.continuous, many, E), grid_threads)
             if live_b is not None:
                 traffic, tdetail = live_b, info
-                tsrc = ("measured by this run: two child passes of this script under rocprofv3 --kernel-trace --pmc (FETCH_SIZE, WRITE_SIZE "
-                        "separately), KiB units, read side x2 (MI355X_MICROARCH.md), mean per launch" +
-                        (f"; profiles/traffic.json[{key}] (series {te.get('series')}) holds {te['hbm_bytes_per_tick' if many else 'hbm_bytes_per_launch']}" if te else ""))
+                tsrc = "this run: 2 rocprofv3 --pmc child passes, 2 x FETCH_SIZE + WRITE_SIZE (KiB)"
             else:
-                tsrc = (tsrc or "none") + f" [live measurement unavailable: {info}]"
+                tsrc = (tsrc or "none") + f" [live passes unavailable: {str(info)[:60]}]"
         mixname = {"uniform": "uniform random", "forward": "all-forward", "shoot": "all-shoot", "dense": "recorded keep-shooting"}[args.action_mix]
         fot = round(traffic / (km * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None
         frac_raw = round(achieved / HBM_PEAK_GBS, 5)
         frac_claimed, frac_contract = claim(frac_raw, fot)
-        frac_note = None if frac_contract is not None else (f"the contract formula gives {frac_raw}: its 12-slot algorithmic byte count is more than this "
-                                                            "workload moves; frac_on_traffic is the meaningful figure")
+        frac_note = None if frac_contract is not None else f"contract formula gives {frac_raw} > 1: its 12-slot count exceeds what moves"
         # shots per agent-step: the share of `shoot` in the action table (an upper bound: dead planes and finished games do not fire)
         shots = {"uniform": 0.25, "forward": 0.0, "shoot": 1.0, "dense": 0.78}[args.action_mix] if not args.continuous else 0.5
+        # what bounds the launch: HBM only where the measured traffic runs at half of the peak or more; below that the step is bound by
+        # instruction issue and the kernel boundary (two waves per SIMD at C2)
+        bound = "hbm" if (fot is not None and fot >= 0.5) else "issue/latency"
+        cfg_no = {1: 1, 4: 2}.get(n)
         out = {
             "metric": "agent-steps/sec", "value": round(agent_steps / wall, 1), "unit": "agent-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(wall / K * 1e3, 6),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64/i16", "data": "synthetic",
-            "config": {"workload": f"{E} games x {n}v{n} per GPU, {mixname} {'continuous' if args.continuous else 'discrete'} actions, fused HIP step(), auto-reset, "
-                                   f"staggered game clocks (BASELINE.json configs[{1 if n == 1 else 2}]{' x ' + str(world) + ' shards' if world > 1 else ''})",
-                       "envs_per_gpu": E, "n_agents_per_team": n, "agents_per_env": A, "launch": args.mode + (f", {args.chains} chains of launches over game ranges" if args.chains > 1 else ""),
+            "config": {"workload": f"{E} games x {n}v{n} per GPU, {mixname} {'continuous' if args.continuous else 'discrete'} actions, fused HIP step(), auto-reset"
+                                   + (f" (BASELINE configs[{3 if (world == 8 and n == 1 and E == 65536) else cfg_no}])" if cfg_no else ""),
+                       "envs_per_gpu": E, "n_agents_per_team": n, "agents_per_env": A, "launch": args.mode + (f", {args.chains} chains" if args.chains > 1 else ""),
                        "graph_len": head["G"] if args.mode == "graph" else None, "parallelism": f"{world} independent env shards, no collective",
                        "process_group": (args.backend if world > 1 else None), "process_group_note": backend_note,
                        "rehearsal_all_ranks_on_device0": bool(args.rehearse_on_device0) or None},
             "timing": {"repeats": len(head["walls"]), "statistic": "median", "ramp_ms": args.ramp_ms,
                        "ms_per_step_samples": [round(w / K * 1e3, 6) for w in head["walls"]],
                        "avg_launch_us_samples": [round(k * 1e3, 3) for k in head["kms"]], "launches_per_event_bracket": head["Kb"],
-                       "note": "ms_per_step: wall clock around K steps between barrier+synchronize pairs (at K = 20 the ~30 us of "
-                               "synchronisation are 15 % of the block); avg_launch_us: HIP events around the same K steps queued behind "
-                               "an untimed block, device time only"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "note": "ms_per_step: wall clock, barrier+sync pairs; avg_launch_us: HIP events, device time only"},
+            "roofline": {"bound": bound, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": frac_contract, "traffic": traffic, "frac_on_traffic": fot, "frac_claimed": frac_claimed,
-                         "claim": "frac_claimed = min(frac, frac_on_traffic) is the figure to quote: frac prices the contract's algorithmic bytes "
-                                  "(12 bullet slots per agent, SURVEY.md section 8d), frac_on_traffic the bytes that reached HBM (PMC); "
-                                  "at this size the step is bound by instruction issue and the kernel boundary, not by HBM (DESIGN.md section 6)",
+                         "claim": "frac_claimed = min(frac [contract bytes], frac_on_traffic [PMC bytes])",
                          "frac_note": frac_note,
                          "live_aware_bytes_per_launch": round(b_live(n, head["live"] or 0.0, shots, args.continuous) * E * A),
-                         "live_aware_note": f"bytes this layout has to move with {head['live']} bullets in flight and {round(shots, 3)} shots per agent-step "
-                                            "(bench.py b_live): plane + game record + 8 B read and 4 B written per live bullet + 16 B per shot + outputs",
                          "traffic_source": tsrc, "traffic_detail": tdetail,
                          "kernel": kernel_name(n, args.continuous, many, E), "avg_launch_us": round(km * 1e3, 3),
                          "algorithmic_bytes_per_launch": round(bytes_per_launch), "bytes_per_agent_step": round(b_alg(n, args.continuous), 2),
                          # SURVEY.md section 8d asks for these beside it: the API-only lower bound (action in; obs, reward, done out)
                          "io_only_bytes_per_agent_step": b_io(n, args.continuous),
                          "io_only_frac": round(b_io(n, args.continuous) * E * A / (km * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         "live_bullets_per_agent": head["live"],
-                         "regime": "latency-bound at this size: 2 wavefronts per SIMD, working set 48 MB inside the 256 MB Infinity Cache "
-                                   "(DESIGN.md section 6)" if (n, E) == (1, 65536) and not many else None},
+                         "live_bullets_per_agent": head["live"], "shots_per_agent_step": round(shots, 3),
+                         "regime": "2 waves per SIMD, 48 MB working set inside the 256 MB Infinity Cache" if (n, E) == (1, 65536) and not many else None},
             "games_finished": int(games[0]), "ties": int(games[1]), "red_wins": int(games[2]), "blue_wins": int(games[3]),
             "tie_tick": head_env_tie_tick,
         }
+        if world > 1:
+            # every rank's own medians: placement (which XCDs a shard's workgroups land on) is the one thing that could bend the
+            # scaling curve of independent shards, and it would show here as one rank slower than the others
+            out["per_rank"] = {"ms_per_step": [round(statistics.median(v) / K * 1e3, 6) for v in per_rank.get("head_walls", [])],
+                               "avg_launch_us": [round(statistics.median(v) * 1e3, 3) for v in per_rank.get("head_kms", [])]}
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         out["other_workloads"] = others
@@ -738,10 +747,57 @@ def main():
         out["loop_incl_action_sampling"] = loop_sampling
         out["policy_rollouts"] = rollouts
         out["drop_in_one_game"] = dropin
+        # LAST key, numbers only: every BASELINE.json config in a form that survives a truncated record of this line
+        out["baseline_configs"] = baseline_summary(out, n, E, world, km, frac_claimed)
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        dist.barrier()                                      # the gloo control group: every rank is done
+        if clean_exit:
+            dist.destroy_process_group()
+        else:                                               # a probe thread is still blocked inside RCCL: no destructors, no joins
+            sys.stdout.flush()
+            os._exit(0)
+
+
+def baseline_summary(out, n, E, world, km, frac_claimed):
+    """BASELINE.json's five configs (+ the streaming and evaluation workloads) as one compact dict of numbers: agent-steps/s,
+    us per step (HIP events; per tick and wall clock for the rollouts) and the claimed roofline fraction.  A config this run did not
+    measure is null."""
+    def pick(d, *path):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d
+
+    def line(d, us="avg_launch_us"):
+        if not isinstance(d, dict) or "agent_steps_per_s" not in d:
+            return None
+        r = {"agent_steps_per_s": round(d["agent_steps_per_s"]), "us": d.get(us)}
+        if d.get("frac_claimed") is not None:
+            r["frac_claimed"] = round(d["frac_claimed"], 3)
+        return r
+    head = {"agent_steps_per_s": round(out["value"]), "us": round(km * 1e3, 3), "frac_claimed": frac_claimed and round(frac_claimed, 3)}
+    ow, ro, ch = out.get("other_workloads") or {}, pick(out, "policy_rollouts", "variants") or {}, out.get("chained_graphs") or {}
+    cb = out.get("cpu_baseline") or {}
+    by = lambda d, word: next((v for k, v in d.items() if word in k), None)     # noqa: E731
+    ev = by(ro, "reference evaluation workload (")
+    s = {"C1_cpu_port_1core": cb.get("value"), "C1_cpu_port_4v4_1core": pick(cb, "port_4v4", "value"),
+         "C1_gpu_dropin_1game": pick(out, "drop_in_one_game", "agent_steps_per_s"),
+         "C2": head if (n, E, world) == (1, 65536, 1) else None,
+         "C3": head if (n, E, world) == (4, 65536, 1) else line(by(ow, "configs[2]")),
+         "C3_3chains": line(by(ch, "4v4, 3 chains"), "us_per_step"),
+         "C4": head if (n, E, world) == (1, 65536, 8) else None,
+         "C5_graph": line(by(ro, "graph of 2 kernels per tick, both"), "us_per_tick"),
+         "C5_one_launch": line(by(ro, "one launch for all ticks, both"), "us_per_tick"),
+         "C5_one_launch_bf16x6": line(by(ro, "six bf16"), "us_per_tick"),
+         "C5_ppo_one_launch": line(by(ro, "PPO-shaped rollout, one launch: "), "us_per_tick"),
+         "eval_2v2": ev and {**line(ev, "us_per_tick"), "red_win_rate": round(ev["win_rate_red"], 4)},
+         "1M_1v1": line(by(ow, "1048576")),
+         "multi_tick_C2": line(out.get("multi_tick_launch"), "us_per_tick")}
+    if world > 1 and s["C4"] is None:
+        s[f"N{world}_x_{E}_{n}v{n}"] = head
+    return s
 
 
 def rollout_lines(dev, E, K):

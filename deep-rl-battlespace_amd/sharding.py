@@ -63,3 +63,90 @@ def local_counter_sums(env):
     """int64 [4] on env.device: this shard's (games, ties, red wins, blue wins)."""
     c = env.export_state(("counters",))["counters"]
     return c.to(torch.int64).sum(0)
+
+
+# ---------------------------------------------------------------------------------------------- the timing group of a multi-rank job
+def _rccl_probe(device, world_size, timeout_s):
+    """Create the RCCL (backend "nccl") group next to the gloo control group and prove it with one all-reduce.  Blocking and
+    collective: it returns only when EVERY rank has joined, so it is run on a worker thread (init_timing_group)."""
+    import datetime
+    import torch.distributed as dist
+    g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=timeout_s))
+    probe = torch.ones(1, device=device)
+    dist.all_reduce(probe, group=g)
+    torch.cuda.synchronize(device)
+    if int(probe.item()) != world_size:
+        raise RuntimeError(f"all_reduce probe returned {probe.item()} for world size {world_size}")
+    return g
+
+
+def _rccl_preflight(device):
+    """What a rank can check alone, before anything collective: the backend is compiled in, its card is there and takes work."""
+    import torch.distributed as dist
+    if not dist.is_nccl_available():
+        raise RuntimeError("torch.distributed was built without the nccl (RCCL) backend")
+    if not torch.cuda.is_available() or device.index >= torch.cuda.device_count():
+        raise RuntimeError(f"{device} is not visible to this rank")
+    torch.ones(1, device=device).add_(1)
+    torch.cuda.synchronize(device)
+
+
+def init_timing_group(backend, device, timeout_s=180.0, probe_wait_s=90.0, poll_s=0.05):
+    """Process groups of a multi-rank bench job -> (group for the barrier / timing reductions, backend in use, note, clean).
+
+    The step path has no collective; the groups carry a barrier and a few tiny reductions.  gloo always comes up first, as the
+    default (control) group.  With backend "nccl" every rank then (1) checks alone what it can check alone, (2) runs the collective
+    RCCL probe on a worker thread while its main thread watches the control store, and the ranks AGREE on the outcome before
+    anyone proceeds: a rank that fails says so through the store at once, every rank that sees a failure (its own, a peer's, or
+    no result within probe_wait_s) stops waiting, and a MIN all-reduce over gloo makes the decision the same everywhere -- all
+    ranks time over RCCL, or all fall back to gloo together within seconds; never a mixture (the ranks that succeeded would sit
+    in their next RCCL collective until its timeout).  clean = False says a probe thread was left behind blocked inside RCCL:
+    the caller must leave through os._exit() once its line is printed."""
+    import datetime
+    import threading
+    import time
+    import torch.distributed as dist
+    rank, world, _ = rank_world()
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=timeout_s))
+    if backend != "nccl":
+        return None, "gloo", None, True
+    try:
+        from torch.distributed.distributed_c10d import _get_default_store
+        store = dist.PrefixStore("bsx_rccl_probe", _get_default_store())
+    except Exception:                                       # noqa: BLE001 -- no store to publish through: the timeout alone bounds the wait
+        store = None
+    box = {}
+
+    def attempt():
+        try:
+            _rccl_preflight(device)
+            box["group"] = _rccl_probe(device, world, timeout_s)
+        except BaseException as exc:                        # noqa: BLE001 -- whatever RCCL raised, the fallback is the same
+            box["error"] = f"{type(exc).__name__}: {str(exc)[:160]}"
+            if store is not None:
+                try:
+                    store.add("failed", 1)
+                except Exception:                           # noqa: BLE001
+                    pass
+    th = threading.Thread(target=attempt, name="bsx-rccl-probe", daemon=True)
+    th.start()
+    t0 = time.time()
+    seen_peer_failure = False
+    while th.is_alive() and time.time() - t0 < probe_wait_s:
+        th.join(poll_s)
+        if store is not None and th.is_alive():
+            try:
+                seen_peer_failure = store.add("failed", 0) > 0
+            except Exception:                               # noqa: BLE001
+                store = None
+            if seen_peer_failure:
+                break
+    mine_ok = (not th.is_alive()) and "group" in box
+    agreed = torch.tensor([1 if mine_ok else 0], dtype=torch.int32)
+    dist.all_reduce(agreed, op=dist.ReduceOp.MIN)           # over gloo: every rank leaves with the same decision
+    if int(agreed.item()) == 1:
+        return box["group"], "nccl", None, True
+    why = box.get("error") or ("a peer rank reported a failure" if seen_peer_failure else
+                               ("this rank's probe passed, another rank's did not" if mine_ok else f"no result within {probe_wait_s:.0f} s"))
+    note = f"nccl (RCCL) did not come up on every rank ({why}); all ranks use gloo"
+    return None, "gloo", note[:200], not th.is_alive()

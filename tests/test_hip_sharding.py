@@ -24,18 +24,23 @@ def _bench(args, timeout=600):
     return json.loads(lines[0])
 
 
-def test_two_rank_job_equals_the_single_process_job(tmp_path):
+@pytest.mark.parametrize("world,per_rank", [(2, 65536), (6, 16384)])     # 6 = the most processes this pool lets share one card
+def test_multi_rank_job_equals_the_single_process_job(tmp_path, world, per_rank):
     common = ["--steps", "150", "--warmup", "10", "--repeats", "2", "--ramp-ms", "0", "--no-cpu-baseline", "--no-other-workloads", "--no-live-traffic"]
-    d2, d1 = str(tmp_path / "two"), str(tmp_path / "one")
-    two = _bench(["--gpus", "2", "--rehearse-on-device0", "--envs-per-gpu", "65536", "--digest-dir", d2, *common])
-    one = _bench(["--gpus", "1", "--envs-per-gpu", "131072", "--digest-dir", d1, *common])
-    assert two["n_gpus"] == 2 and one["n_gpus"] == 1 and two["scaling"] == "weak"
-    assert two["config"]["rehearsal_all_ranks_on_device0"] is True
-    # whole-job throughput of the two-rank line = the games of BOTH ranks over the slower rank's time
-    assert abs(two["value"] - 2 * 65536 * 2 * 150 / (two["ms_per_step"] * 1e-3 * 150)) / two["value"] < 1e-3
-    metas = [json.load(open(os.path.join(d2, f"rank{r}.json"))) for r in range(2)]
-    assert [m["env_offset"] for m in metas] == [0, 65536] and all(m["n_envs"] == 65536 and m["world"] == 2 for m in metas)
-    parts = [torch.load(os.path.join(d2, f"rank{r}.pt")) for r in range(2)]
+    d2, d1 = str(tmp_path / "many"), str(tmp_path / "one")
+    two = _bench(["--gpus", str(world), "--rehearse-on-device0", "--envs-per-gpu", str(per_rank), "--digest-dir", d2, *common])
+    one = _bench(["--gpus", "1", "--envs-per-gpu", str(world * per_rank), "--digest-dir", d1, *common])
+    assert two["n_gpus"] == world and one["n_gpus"] == 1 and two["scaling"] == "weak"
+    assert two["config"]["rehearsal_all_ranks_on_device0"] is True and two["config"]["process_group"] == "gloo"
+    # whole-job throughput of the N-rank line = the games of ALL ranks over the slowest rank's time
+    assert abs(two["value"] - world * per_rank * 2 * 150 / (two["ms_per_step"] * 1e-3 * 150)) / two["value"] < 1e-3
+    # every rank's own medians travel in the line (imbalance between shards would show here); the job's figure is not below any of them
+    pr = two["per_rank"]
+    assert len(pr["ms_per_step"]) == world and len(pr["avg_launch_us"]) == world and all(v > 0 for v in pr["ms_per_step"] + pr["avg_launch_us"])
+    assert "per_rank" not in one and two["baseline_configs"][f"N{world}_x_{per_rank}_1v1"]["agent_steps_per_s"] == round(two["value"])
+    metas = [json.load(open(os.path.join(d2, f"rank{r}.json"))) for r in range(world)]
+    assert [m["env_offset"] for m in metas] == [r * per_rank for r in range(world)] and all(m["n_envs"] == per_rank and m["world"] == world for m in metas)
+    parts = [torch.load(os.path.join(d2, f"rank{r}.pt")) for r in range(world)]
     whole = torch.load(os.path.join(d1, "rank0.pt"))
     for k in sorted(whole):
         cat = torch.cat([p[k] for p in parts])

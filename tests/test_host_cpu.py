@@ -183,6 +183,82 @@ def test_two_rank_counter_reduction_over_gloo(tmp_path):
     assert all(f"ok {r}" in outs[r] for r in range(2))
 
 
+_PROBE_WORKER = r'''
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from deep_rl_battlespace_amd import sharding
+rank, world, _ = sharding.rank_world()
+case = sys.argv[2]
+sharding._rccl_preflight = lambda device: None                     # no card here: the collective half is what is under test
+def probe(device, world_size, timeout_s):
+    g = dist.new_group(backend="gloo")                             # stands in for the RCCL group (its creation is itself collective)
+    if case == "one_rank_fails":
+        if rank == 1:
+            raise RuntimeError("injected: ncclCommInitRank failed on this rank")
+        time.sleep(3600)                                           # the other ranks sit in the collective that rank 1 never joins
+    if case == "one_rank_hangs" and rank == 1:
+        time.sleep(3600)                                           # nobody reports anything: only the bounded wait ends this
+    return g
+sharding._rccl_probe = probe
+t0 = time.time()
+group, backend, note, clean = sharding.init_timing_group("nccl", torch.device("cpu"), probe_wait_s=float(sys.argv[3]))
+dt = time.time() - t0
+t = torch.tensor([rank + 1.0])
+dist.all_reduce(t, group=group)                                    # the group every rank was handed works, and it is the same one
+assert t.item() == world * (world + 1) / 2
+print(f"RESULT {rank} {backend} {int(clean)} {dt:.2f} {note}", flush=True)
+dist.barrier()
+os._exit(0) if not clean else dist.destroy_process_group()
+'''
+
+
+def _run_probe_case(tmp_path, case, wait_s, world=3):
+    import socket
+    script = tmp_path / "probe_worker.py"
+    script.write_text(_PROBE_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, case, str(wait_s)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    res = {}
+    for o in outs:
+        f = [l for l in o.splitlines() if l.startswith("RESULT ")][0].split(" ", 5)
+        res[int(f[1])] = dict(backend=f[2], clean=f[3] == "1", dt=float(f[4]), note=f[5])
+    return res
+
+
+def test_rccl_failure_on_one_rank_moves_every_rank_to_gloo_within_seconds(tmp_path):
+    """bench.py's N > 1 process-group setup (sharding.init_timing_group): an RCCL-init failure injected on ONE rank while the other
+    ranks sit in the collective probe -- every rank must come out on gloo, together and quickly (the failing rank publishes through
+    the control store; nobody waits for a collective timeout), and say why."""
+    res = _run_probe_case(tmp_path, "one_rank_fails", wait_s=120)
+    assert {r["backend"] for r in res.values()} == {"gloo"}, res
+    assert max(r["dt"] for r in res.values()) < 30, res                  # seconds, not the 120 s bound or RCCL's own timeout
+    assert "injected" in res[1]["note"] and res[1]["clean"]
+    assert all("peer rank reported a failure" in res[r]["note"] and not res[r]["clean"] for r in (0, 2)), res
+
+
+def test_rccl_probe_that_never_returns_is_bounded_and_agreed(tmp_path):
+    """A rank whose probe neither returns nor raises: the other ranks' probes pass, the stuck rank gives up after probe_wait_s, and the
+    MIN all-reduce over gloo still puts ALL ranks on gloo -- never a mixture."""
+    res = _run_probe_case(tmp_path, "one_rank_hangs", wait_s=5)
+    assert {r["backend"] for r in res.values()} == {"gloo"}, res
+    assert "no result within" in res[1]["note"] and not res[1]["clean"]
+    assert all("another rank" in res[r]["note"] and res[r]["clean"] for r in (0, 2)), res
+
+
+def test_rccl_probe_passing_everywhere_hands_out_the_probed_group(tmp_path):
+    res = _run_probe_case(tmp_path, "all_pass", wait_s=60, world=2)
+    assert all(r["backend"] == "nccl" and r["clean"] and r["note"] == "None" for r in res.values()), res
+
+
 def test_render_frame_from_exported_state(tmp_path):
     """f-4: one game's exported state rasterised on the host (no pygame): shapes, colours, dead plane hollow."""
     from deep_rl_battlespace_amd import render

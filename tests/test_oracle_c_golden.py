@@ -74,3 +74,28 @@ def test_c_oracle_equals_python_oracle_on_random_play(n, cont):
             assert np.array_equal(rew[e], np.asarray([float(rw[i]) for i in ids])), (t, e)
             assert [bool(dn[i]) for i in ids] == done[e].tolist()
             assert bool(cb.env_done[e]) == p.env_done and int(cb.winner[e]) == pyref.WINNER_CODE[p.winner]
+
+
+def test_c_oracle_production_draws_have_the_reference_distribution():
+    """The C oracle's Philox spawns (reset and auto-reset streams) and shot jitter against what the REFERENCE draws (fixture g7,
+    sprites.py:314) -- the same checks tests/test_hip_rng_pin.py runs on the GPU's production path, so that "GPU == C oracle under
+    Philox" (the full-size and soak tests) also says "both draw from the reference's ranges and support"."""
+    from rng_pin_util import check_jitter, check_spawn_table, spawn_table
+    E = 200_000
+    c = cref.CRefBatch(E, n_agents=2, seed=20261004, auto_reset=True)
+    c.reset()
+    st = c.export_state()
+    d = spawn_table(st)
+    check_spawn_table(d, "C oracle, stream RESET")
+    d0 = st["pdir"].copy()
+    c.step(np.ones((E, 4), np.int32))                         # every plane fires: one fresh bullet each
+    st = c.export_state()
+    live = st["bl_live"].astype(bool)
+    assert (live.sum(-1) == 1).all()
+    check_jitter(st["bl_dir"][live], d0.reshape(-1), "C oracle, shot jitter")
+    c.step(np.ones((E, 4), np.int32), empty=True)            # tie ...
+    assert c.env_done.all()
+    c.step(np.ones((E, 4), np.int32))                         # ... and the in-step re-spawn (stream AUTORESET)
+    d2 = spawn_table(c.export_state())
+    check_spawn_table(d2, "C oracle, stream AUTORESET")
+    assert (d2 != d).any(1).mean() > 0.999
