@@ -132,7 +132,12 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    # "hbm" only where the measured traffic runs at half of the peak or more; 65 536 x 1v1 is bound by instruction issue and the kernel boundary
+    assert r["bound"] == ("hbm" if (r["frac_on_traffic"] or 0) >= 0.5 else "issue/latency")
+    # the LAST key is the compact numeric summary of every BASELINE.json config (it must survive a truncated record of the line)
+    assert list(d)[-1] == "baseline_configs" and d["baseline_configs"]["C2"]["agent_steps_per_s"] == round(d["value"])
+    assert len(json.dumps(d["baseline_configs"])) < 1200
     # the figure to quote is the smaller of the contract fraction and the one on measured traffic; no fraction above 1 anywhere
     assert r["frac_claimed"] == min(v for v in (r["frac"], r["frac_on_traffic"]) if v is not None) and r["frac_claimed"] <= 1.0
     assert r["live_aware_bytes_per_launch"] < r["algorithmic_bytes_per_launch"]
