@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # bsx_build_flags() is non-zero (results are not the reference's) is refused unless BSX_ALLOW_DIAG=1 is set as well.
 LIB_PATH = os.environ.get("BSX_LIB_PATH") or os.path.join(_HERE, "csrc", "libbattlespace_hip.so")
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 BULLET_SLOTS = 12
 MAX_N = 16
 MAX_T = 65535

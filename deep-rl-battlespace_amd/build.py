@@ -23,10 +23,10 @@ COMMON = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-
 # the one-call kernels compile to the same code either way.
 # -amdgpu-mfma-vgpr-form: MFMA accumulators in ordinary VGPRs (every kernel here fits 256 of them at two waves per SIMD);
 # the default puts them in AGPRs and pays a v_accvgpr_read per value the LayerNorm / head then touches (11 % of the actor).
-# -amdgpu-kernarg-preload-count=11: the step kernels' six leading arguments (game count and the pointers of a wave's first
+# -amdgpu-kernarg-preload-count=15: the step kernels' eight leading arguments (game count and the pointers of a wave's first
 # loads) arrive in SGPRs with the dispatch instead of through a cold scalar-cache fetch at the start of every wave.
 SOURCES = [(os.path.join(CSRC, "bsx_kernels.hip"), ["-ffp-contract=off", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-mfma-vgpr-form",
-                                                    "-mllvm", "-amdgpu-kernarg-preload-count=11"]),
+                                                    "-mllvm", "-amdgpu-kernarg-preload-count=15"]),
            (os.path.join(CSRC, "bsx_actor.hip"), ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form"])]
 
 

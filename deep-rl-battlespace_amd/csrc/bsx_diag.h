@@ -9,7 +9,6 @@
 //                       else reads; a stamped build is for reading SHARES, not run time
 //   -DBSX_STAMPS -DBSX_STAMPS_FINE   stamps 3..6 move INSIDE the shot phase (after the slot table / the Philox draw / sincos / the
 //                       first slot fetch); FSTAMP stores from every active lane (it sits in divergent code), the phase stamps 3..6 are off
-//   -DBSX_X_NOPACK      the per-lane item walk instead of the wave-packed bullet pass for every team size (same results)
 //   -DBSX_X_OBS=<0|1|2> the store form of the observation rows (below; same results)
 #pragma once
 
@@ -17,12 +16,6 @@
 #define BSX_DIAG 0
 #endif
 constexpr unsigned DIAG = BSX_DIAG;
-
-#ifdef BSX_X_NOPACK
-constexpr bool PACK_BULLETS = false;
-#else
-constexpr bool PACK_BULLETS = true;
-#endif
 
 // how the observation rows of the per-step kernels leave (round 3's measurement of the 4v4 write side; same results):
 //   -DBSX_X_OBS=0  straight from registers, 16-byte non-temporal stores per lane + tail (the product)

@@ -46,7 +46,6 @@
 #else
 constexpr unsigned DIAG = 0;
 constexpr int BUILD_FLAGS = 0;
-constexpr bool PACK_BULLETS = true;
 constexpr int OBS_FORM = 0;
 constexpr bool X_CHEAP_ALL = false, X_CORNERS_ALL = false;
 constexpr int X_DEPHASE = 0;
@@ -95,36 +94,47 @@ constexpr double BULLET_STEP = 45.0;               // 450 * 0.1 in binary64
 constexpr double TIME_STEP = 0.1;
 
 // ---------------------------------------------------------------------------------------------- state layout
-struct __align__(16) PlaneRec {   // 16 B per agent
-    int16_t x, y;                 // sprite centre (pygame Rect ints)
-    uint16_t live;                // number of entries (0..12) in this agent's bullet list
-    int8_t hp;                    // alive <=> hp > 0 (sprites.py:143-153)
-    uint8_t xf;                   // 1 = some bullet of this agent's list carries the exact-path flag (step_code); cleared when the list runs empty
-    double dir;                   // degrees, [0, 360]
-};
-struct __align__(16) EnvRec {     // 16 B per env
-    int16_t brx, bry, bbx, bby;   // base centres
-    int16_t bhp_r, bhp_b;         // may go negative within a step (sprites.py:260-262)
-    uint16_t tick;                // number of time increments this game (total_time == tick * 0.1 accumulated)
-    uint8_t done;                 // env_done
-    uint8_t winner;               // BSX_WINNER_*
-};
-struct Layout { size_t lut, env, cnt, plane, bent, bdir, bd, total; };
+// Records are sized by what a call MOVES: every field a step() rewrites sits in an 8-byte record of its own array, what a game never
+// changes (its base positions) in another, and what only a game's end touches (the win / tie counters) is updated there by atomics.
+//   plane  uint2 [E*A]   .x = x | y << 16 (sprite centre, pygame Rect ints)
+//                        .y = heading in whole degrees (9 bits, 0..360) | hp << 9 (3 bits; alive <=> hp > 0, sprites.py:143-153)
+//                             | 1 << 12: the heading is fractional and lives in `pdirf` (continuous actions only)
+//   pdirf  double [E*A]  heading in degrees, [0, 360]: read and written by the continuous kernels only
+//   envc   uint2 [E]     base centres: .x = red x | y << 16, .y = blue x | y << 16; written by reset / auto-reset only
+//   envd   uint2 [E]     .x = red base hp (9 bits, signed: may go negative within a step, sprites.py:260-262) | blue base hp << 9
+//                             | tick << 18 (9 bits: total_time == tick * 0.1 accumulated) | done << 27 | winner << 28
+//                        .y = games this slot has finished = the episode number the random streams are keyed by
+//   cnt    int4 [E]      games, ties, red wins, blue wins: touched at a game's end only (atomic adds; export reads them)
+//   bullets: one POOL per wave block (the 64 lanes = 64 / G games a wavefront of the step kernel owns): `bcnt[block]` entries, dense,
+//            in no particular order, at `bent[block * POOL_CAP ...]`; an entry names its owner lane.  The wave reads its pool with
+//            fully coalesced loads whatever the bullets' distribution over the planes (the first 64 entries unconditionally, in the
+//            first batch of loads: no dependent round trip) and writes the survivors back compacted.
+constexpr int POOL_CAP = 64 * BSX_BULLET_SLOTS;   // every lane of a wave block with a full list (11 older bullets + this call's shot)
+struct Layout { size_t lut, envc, envd, cnt, plane, pdirf, bcnt, bent, bdir, bd, total; };
 
 __host__ __device__ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+__host__ __device__ constexpr int group_width(int n) {
+    int g = 2;
+    while (g < 2 * n) g <<= 1;
+    return g;
+}
+__host__ __device__ inline int64_t wave_blocks(int64_t E, int n) { const int epb = 64 / group_width(n); return (E + epb - 1) / epb; }
 
 __host__ __device__ inline Layout make_layout(int64_t E, int n) {
     Layout L;
     const size_t EA = size_t(E) * size_t(2 * n);
+    const size_t NB = size_t(wave_blocks(E, n));
     size_t o = 0;
     L.lut = o;   o = align256(o + 361 * sizeof(double2));
-    L.env = o;   o = align256(o + size_t(E) * sizeof(EnvRec));
+    L.envc = o;  o = align256(o + size_t(E) * sizeof(uint2));
+    L.envd = o;  o = align256(o + size_t(E) * sizeof(uint2));
     L.cnt = o;   o = align256(o + size_t(E) * sizeof(int4));
-    L.plane = o; o = align256(o + EA * sizeof(PlaneRec));
-    // Bullets of an agent are a DENSE list in creation order (entry j of every agent is row j: lanes read the same row
-    // -> coalesced however sparse the bullets are); an entry = two words: .x = x(11) | y(10) | age(4), rewritten by every
-    // update; .y = the step code (step_code below), written by the shot and carried along when compaction moves the entry.
-    L.bent = o;  o = align256(o + size_t(K) * EA * sizeof(uint2));    // [K][EA] entries; age 1..11 = updates so far, 15 = tombstone
+    L.plane = o; o = align256(o + EA * sizeof(uint2));
+    L.pdirf = o; o = align256(o + EA * sizeof(double));
+    L.bcnt = o;  o = align256(o + NB * sizeof(uint32_t));
+    // A pool entry = two words: .x = x (11 bits) | age << 11 | exact-path flag << 15 | y << 16 (10 bits) | owner lane << 26, rewritten by
+    // every update; .y = the step code (step_code below), written by the shot.
+    L.bent = o;  o = align256(o + NB * size_t(POOL_CAP) * sizeof(uint2));
     L.bdir = o;  o = align256(o + size_t(K) * EA * sizeof(double));   // [K][EA]: heading, RING by birth tick % 12 (export only)
     L.bd = o;    o = align256(o + size_t(K) * EA * sizeof(double2));  // [K][EA]: float64 step (45cos, 45sin), RING by birth tick % 12, of the RARE shots whose
                                                                       //          step code carries the exact-path flag; never read or written otherwise
@@ -133,14 +143,14 @@ __host__ __device__ inline Layout make_layout(int64_t E, int n) {
 }
 
 struct StatePtrs {
-    const double2* lut; EnvRec* env; int4* cnt; PlaneRec* plane; uint2* bent; double* bdir; double2* bd;
+    const double2* lut; uint2* envc; uint2* envd; int* cnt; uint2* plane; double* pdirf; uint32_t* bcnt; uint2* bent; double* bdir; double2* bd;
 };
 inline StatePtrs state_ptrs(void* base, int64_t E, int n) {
     Layout L = make_layout(E, n);
     char* b = static_cast<char*>(base);
-    return StatePtrs{reinterpret_cast<const double2*>(b + L.lut), reinterpret_cast<EnvRec*>(b + L.env),
-                     reinterpret_cast<int4*>(b + L.cnt), reinterpret_cast<PlaneRec*>(b + L.plane),
-                     reinterpret_cast<uint2*>(b + L.bent), reinterpret_cast<double*>(b + L.bdir),
+    return StatePtrs{reinterpret_cast<const double2*>(b + L.lut), reinterpret_cast<uint2*>(b + L.envc), reinterpret_cast<uint2*>(b + L.envd),
+                     reinterpret_cast<int*>(b + L.cnt), reinterpret_cast<uint2*>(b + L.plane), reinterpret_cast<double*>(b + L.pdirf),
+                     reinterpret_cast<uint32_t*>(b + L.bcnt), reinterpret_cast<uint2*>(b + L.bent), reinterpret_cast<double*>(b + L.bdir),
                      reinterpret_cast<double2*>(b + L.bd)};
 }
 
@@ -329,6 +339,7 @@ __device__ inline uint32_t pack_xy(int x, int y) { return (uint32_t(x) & 0xFFFFu
 // move and every rectangle test below work on both at once (v_pk_*_i16).  .y = the per-update step as two signed 16-bit halves.
 constexpr uint32_t TOMBSTONE_AGE = 15;
 constexpr uint32_t ENT_XY = 0x03FF07FFu, ENT_AGE = 0x7800u, ENT_EXACT = 0x8000u;
+constexpr int ENT_OWNER_SHIFT = 26;                     // bits 26..31: the owner's lane in its wave block
 __device__ inline uint32_t pack_bullet(int x, int y, int age) { return uint32_t(x) | (uint32_t(age) << 11) | (uint32_t(y) << 16); }
 __device__ inline int bullet_x(uint32_t w) { return int(w & 0x7FFu); }
 __device__ inline int bullet_y(uint32_t w) { return int((w >> 16) & 0x3FFu); }
@@ -366,12 +377,6 @@ __device__ inline uint32_t step_pk(uint32_t xy, uint32_t code) {
     return pk_bits(b - (b >> 15));
 }
 __device__ inline int ring_pos(int ks, int back) { const int q = ks - back; return q + ((q >> 31) & BSX_BULLET_SLOTS); }   // (ks - back) mod 12, 0 <= back < 12
-
-__host__ __device__ constexpr int group_width(int n) {
-    int g = 2;
-    while (g < 2 * n) g <<= 1;
-    return g;
-}
 
 // np.argmax over four scores (battle_env.py:327-328): the first maximum; a NaN compares as the maximum.  The running maximum is a
 // register, not v[arg]: a dynamically indexed local array lives in scratch memory.
@@ -428,12 +433,13 @@ __device__ inline void write_obs(float* __restrict__ out, int n, bool alive, int
 }
 
 // Spawn draws (sprites.py:74-91,238-252).  Every lane of an env computes the same base draws.
-__device__ inline void spawn_bases(uint64_t seed, int64_t genv, uint32_t stream, uint32_t seq, EnvRec& er) {
+template <class ENV>
+__device__ inline void spawn_bases(uint64_t seed, int64_t genv, uint32_t stream, uint32_t seq, ENV& er) {
     const uint4 r = draw4(seed, genv, stream, seq, 0xFFFFu);
-    er.brx = int16_t(randint(r.x, 62, 379));     // randint(w, (W-w)//3)
-    er.bry = int16_t(randint(r.y, 62, 738));
-    er.bbx = int16_t(randint(r.z, 758, 1138));   // randint((W-w)//3*2, W-w)
-    er.bby = int16_t(randint(r.w, 62, 738));
+    er.brx = randint(r.x, 62, 379);     // randint(w, (W-w)//3)
+    er.bry = randint(r.y, 62, 738);
+    er.bbx = randint(r.z, 758, 1138);   // randint((W-w)//3*2, W-w)
+    er.bby = randint(r.w, 62, 738);
 }
 __device__ inline void spawn_plane(uint64_t seed, int64_t genv, uint32_t stream, uint32_t seq, int a, int n,
                                    int& x, int& y, double& dir) {
@@ -463,6 +469,7 @@ constexpr int tie_tick_const(int n) {
 }
 static_assert(tie_tick_const(1) == 121 && tie_tick_const(2) == 141 && tie_tick_const(3) == 161 && tie_tick_const(4) == 181 &&
               tie_tick_const(5) == 200, "time-limit tick");
+static_assert(tie_tick_const(BSX_MAX_N) < 512, "the game clock fits the 9 bits of the game record");
 
 // The scripted opponent's target choice and discrete action (instinct/agent.py:10-39,56-62) from one observation row,
 // ob(k) = value k of the row: score every target by dist * |angle| (base first, strict '<' keeps the first minimum, a dead
@@ -505,28 +512,29 @@ __device__ inline float4 one_hot_scores(int act) {               // what the sco
 }
 
 // ---------------------------------------------------------------------------------------------- the step kernel
-// Record (un)packing on raw 16-byte words: keeps the loads as single dwordx4 instructions with no byte shuffling.
-__device__ inline void unpack_plane(const uint4 w, int& x, int& y, uint32_t& live, int& hp, uint32_t& xf, double& dir) {
-    x = sx16(w.x); y = sy16(w.x); live = w.y & 0xFFFFu; hp = int(int8_t((w.y >> 16) & 0xFFu)); xf = w.y >> 24;
-    dir = __hiloint2double(int(w.w), int(w.z));
+// Record (un)packing on raw words (layout: see make_layout).
+constexpr uint32_t PLANE_FRAC = 1u << 12;               // plane word 1: the heading is fractional and lives in pdirf
+__device__ inline void unpack_plane(const uint2 w, int& x, int& y, int& hp, double& dir) {
+    x = sx16(w.x); y = sy16(w.x); hp = int((w.y >> 9) & 7u);
+    dir = double(int(w.y & 511u));                      // whole degrees; a continuous kernel replaces it by pdirf when PLANE_FRAC is set
 }
-__device__ inline uint4 pack_plane(int x, int y, uint32_t live, int hp, uint32_t xf, double dir) {
-    return make_uint4(pack_xy(x, y), (live & 0xFFFFu) | ((uint32_t(hp) & 0xFFu) << 16) | (xf << 24), uint32_t(__double2loint(dir)),
-                      uint32_t(__double2hiint(dir)));
+__device__ inline uint2 pack_plane(int x, int y, int hp, double dir, bool frac) {
+    return make_uint2(pack_xy(x, y), (uint32_t(int(dir)) & 511u) | (uint32_t(hp) << 9) | (frac ? PLANE_FRAC : 0u));
 }
-struct EnvU {   // EnvRec fields in registers
+struct EnvU {   // a game's record in registers
     int brx, bry, bbx, bby, bhp_r, bhp_b, tick, done, winner;
 };
-__device__ inline EnvU unpack_env(const uint4 w) {
+__device__ inline EnvU unpack_env(const uint2 c, const uint32_t d) {
     EnvU e;
-    e.brx = sx16(w.x); e.bry = sy16(w.x); e.bbx = sx16(w.y); e.bby = sy16(w.y);
-    e.bhp_r = sx16(w.z); e.bhp_b = sy16(w.z); e.tick = int(w.w & 0xFFFFu); e.done = int((w.w >> 16) & 0xFFu); e.winner = int(w.w >> 24);
+    e.brx = sx16(c.x); e.bry = sy16(c.x); e.bbx = sx16(c.y); e.bby = sy16(c.y);
+    e.bhp_r = int(d << 23) >> 23; e.bhp_b = int(d << 14) >> 23; e.tick = int((d >> 18) & 511u); e.done = int((d >> 27) & 1u); e.winner = int((d >> 28) & 3u);
     return e;
 }
-__device__ inline uint4 pack_env(const EnvU& e) {
-    return make_uint4(pack_xy(e.brx, e.bry), pack_xy(e.bbx, e.bby), pack_xy(e.bhp_r, e.bhp_b),
-                      (uint32_t(e.tick) & 0xFFFFu) | (uint32_t(e.done) << 16) | (uint32_t(e.winner) << 24));
+__device__ inline uint2 pack_envc(const EnvU& e) { return make_uint2(pack_xy(e.brx, e.bry), pack_xy(e.bbx, e.bby)); }
+__device__ inline uint32_t pack_envd(const EnvU& e) {
+    return (uint32_t(e.bhp_r) & 511u) | ((uint32_t(e.bhp_b) & 511u) << 9) | (uint32_t(e.tick) << 18) | (uint32_t(e.done) << 27) | (uint32_t(e.winner) << 28);
 }
+static_assert(5 * BSX_MAX_N < 256 && 12 * BSX_MAX_N < 256, "base hit points (start 5n, at most 12n hits in one call) fit 9 signed bits");
 
 // Range / angle-off pair of one observer->target (battle_env.py:230-231,240-241)
 __device__ inline void obs_pair(int x, int y, double dir, int tx, int ty, float& od, float& oa) {
@@ -560,12 +568,12 @@ template <class T> __device__ inline T* elem(T* base, uint32_t i) {
 template <class T> __device__ inline T* elem(T* base, size_t i) { return base + i; }
 template <int N, bool CONT, bool MULTI, bool ACTOR = false, bool LG = false, bool OFF32 = false>
 __global__ __launch_bounds__(SPB * (ACTOR ? group_width(N > 0 ? N : 1) / 2 : WPB)) __attribute__((amdgpu_waves_per_eu((ACTOR && N > 1) ? 2 : 1)))
-void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* const cnt_, const PlaneRec* const plane_, const void* const act_,
-                     const int kind_, const StepArgs p_) {
+void bsx_step_kernel(const int64_t E_, const uint2* const envc_, const uint2* const envd_, const uint2* const plane_, const void* const act_,
+                     const uint2* const bent_, const uint32_t* const bcnt_, const int kind_, const StepArgs p_) {
     const StepArgs& p = p_;                              // (the tick loop of the multi-tick forms shadows this name: see there)
-    // The six leading arguments repeat p.E, p.st.env, p.st.cnt, p.st.plane, p.actions, p.action_kind: eleven dwords that the
-    // dispatcher preloads into SGPRs (-amdgpu-kernarg-preload-count), so that a wave's first loads need nothing from the
-    // kernarg segment and do not queue behind its cold scalar-cache fetch.
+    // The eight leading arguments repeat p.E, p.st.envc, p.st.envd, p.st.plane, p.actions, p.st.bent, p.st.bcnt, p.action_kind: fifteen
+    // dwords that the dispatcher preloads into SGPRs (-amdgpu-kernarg-preload-count), so that a wave's first loads need nothing
+    // from the kernarg segment and do not queue behind its cold scalar-cache fetch.
     STAMP(8);                                            // diagnostic builds: kernel entry, before any kernarg load
     typedef typename std::conditional<OFF32, uint32_t, size_t>::type ix_t;     // row / element offsets
     typedef typename std::conditional<OFF32, int32_t, int64_t>::type ixs_t;    // game indices
@@ -605,11 +613,9 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // n >= 2: every plane-to-plane pair is computed ONCE, by one of its two planes, and handed to the other through these
     __shared__ float s_pd_all[(N >= 2) ? WAVES * SPB * N : 1];      // range (symmetric)
     __shared__ double s_pr_all[(N >= 2) ? WAVES * SPB * N : 1];     // the owner's bearing in radians, [0, 2 pi)
-    // wave-packed bullet pass (N = 1 .. 4): the bullets of ALL lanes of the wave are laid out back to back as work slots
-    constexpr bool PACK = PACK_BULLETS && N >= 1 && N <= 4;
-    constexpr int OWN_CAP = SPB * (K + 1) + 2;             // every lane with a full list plus this call's shot (+ one scratch entry, see part 1)
-    __shared__ uint16_t s_own_all[PACK ? WAVES * OWN_CAP : 1];   // slot -> owner lane | item index << 8 | "this call's shot" << 15
-    __shared__ uint32_t s_agg_all[PACK ? WAVES * SPB : 1];       // per owner: survivor bit per entry | misses << 16 | base hits << 24
+    // wave-packed bullet pass: the wave's pool entries (and this call's shots behind them) are WORK SLOTS, one per lane and round
+    __shared__ __attribute__((aligned(8))) u32x2 s_new_all[WAVES * SPB];   // this call's shots as pool entries (age 0, the PRE-move pose), by shot rank
+    __shared__ uint32_t s_agg_all[WAVES * SPB];          // per owner: misses << 16 | base hits << 24
     // The rectangles a bullet is tested against (enemy base, enemy planes' sprites), staged per owner / per plane for the work slots.
     // 1v1: as (lower corner, upper corner) pairs of packed (x, y) halves BIASED by +64, so that no half is ever negative and the
     // corners are plain 32-bit adds of packed literals: a bullet at b overlaps <=> no half of (b - lower) | (upper - b) is negative
@@ -618,8 +624,8 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // (4v4 23.1 us against 24.7 with corners; the same launches, four runs each).
     constexpr bool CORNERS = N == 1 || X_CORNERS_ALL;
     typedef typename std::conditional<CORNERS, u32x2, uint32_t>::type rect_t;
-    __shared__ __attribute__((aligned(8))) rect_t s_eb_all[PACK ? WAVES * SPB : 1];        // per owner: the enemy base, dx in [-33, 33], dy in [-32, 31]
-    __shared__ __attribute__((aligned(8))) rect_t s_pq_all[PACK ? WAVES * SPB : 1];        // per plane: its post-move sprite, dx in [-27, 27], dy in [-25, 24]; dead: never hit
+    __shared__ __attribute__((aligned(8))) rect_t s_eb_all[WAVES * SPB];        // per owner: the enemy base, dx in [-33, 33], dy in [-32, 31]
+    __shared__ __attribute__((aligned(8))) rect_t s_pq_all[WAVES * SPB];        // per plane: its post-move sprite, dx in [-27, 27], dy in [-25, 24]; dead: never hit
     // rect(centre, alive, margins below / above): what the owner side stages
     auto make_rect = [](uint32_t c, bool alive, int xl, int yl, int xh, int yh) {
         if constexpr (CORNERS) return alive ? u32x2{c + pk_const(PK_BIAS - xl, PK_BIAS - yl), c + pk_const(PK_BIAS + xh, PK_BIAS + yh)} : u32x2{0x7F007F00u, 0u};
@@ -633,20 +639,27 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
             return ~pk_any_negative(pk_bits(d + as_pk(pk_const(xl, yl))) | pk_bits(as_pk(pk_const(xh, yh)) - d)) & (int(r << 16) >> 31);
         }
     };
-    __shared__ uint32_t s_nw_all[PACK ? WAVES * SPB : 1];        // per owner: this call's shot as an entry word (age 0) | the owner's tick % 12 << 26
-    __shared__ uint32_t s_ns_all[PACK ? WAVES * SPB : 1];        // ... its step code
-    __shared__ __attribute__((aligned(16))) double s_nd_all[PACK ? WAVES * SPB * 2 : 2];   // ... and its float64 step (written and read on the exact path only)
-    __shared__ unsigned long long s_ov_all[PACK ? WAVES * SPB : 1], s_pm_all[PACK ? WAVES * SPB : 1];   // per owner: overlap fields / positions by age
-    auto* const s_own = BSX_LDS(uint16_t, s_own_all) + (PACK ? wave * OWN_CAP : 0);
-    auto* const s_agg = BSX_LDS(uint32_t, s_agg_all) + (PACK ? wave * SPB : 0);
-    auto* const s_eb = BSX_LDS(rect_t, s_eb_all) + (PACK ? wave * SPB : 0);
-    auto* const s_pq = BSX_LDS(rect_t, s_pq_all) + (PACK ? wave * SPB : 0);
-    auto* const s_nw = BSX_LDS(uint32_t, s_nw_all) + (PACK ? wave * SPB : 0);
-    auto* const s_ns = BSX_LDS(uint32_t, s_ns_all) + (PACK ? wave * SPB : 0);
-    auto* const s_nd = BSX_LDS(double, s_nd_all) + (PACK ? wave * SPB * 2 : 0);
-    auto* const s_ov = BSX_LDS(unsigned long long, s_ov_all) + (PACK ? wave * SPB : 0);
-    auto* const s_pm = BSX_LDS(unsigned long long, s_pm_all) + (PACK ? wave * SPB : 0);
-    if constexpr (PACK) { s_ov[tid] = 0ull; s_pm[tid] = 0ull; }   // cleared again by whoever finds them set
+    // per owner: what a work slot must know about its bullet's owner: the owner's tick % 12 (the exact-path ring) | 16: the owner's game
+    // is in its physics call (its bullets fly) | 32: the game is being re-spawned by this call (its bullets are dropped)
+    constexpr uint32_t OWN_PHYS = 16u, OWN_DROP = 32u;
+    __shared__ uint32_t s_fl_all[WAVES * SPB];
+    __shared__ __attribute__((aligned(16))) double s_nd_all[WAVES * SPB * 2];   // per owner: this call's shot's float64 step (written and read on the exact path only)
+    // plane-overlap candidates per owner, by AGE (rare): FW bits per age (which enemy planes the bullet of that age overlaps), and where
+    // that bullet's entry now sits in the pool (for the tombstone of a consumed bullet)
+    constexpr int FW = (N > 0 && N <= 4) ? 4 : 16;       // bits per overlap field
+    constexpr int OW = (FW == 4) ? 1 : 3;                // 64-bit words holding the 12 fields
+    __shared__ unsigned long long s_ov_all[WAVES * SPB * OW];
+    __shared__ uint16_t s_pp_all[WAVES * SPB * K];
+    auto* const s_new = BSX_LDS(u32x2, s_new_all) + wave * SPB;
+    auto* const s_agg = BSX_LDS(uint32_t, s_agg_all) + wave * SPB;
+    auto* const s_eb = BSX_LDS(rect_t, s_eb_all) + wave * SPB;
+    auto* const s_pq = BSX_LDS(rect_t, s_pq_all) + wave * SPB;
+    auto* const s_fl = BSX_LDS(uint32_t, s_fl_all) + wave * SPB;
+    auto* const s_nd = BSX_LDS(double, s_nd_all) + wave * SPB * 2;
+    auto* const s_ov = BSX_LDS(unsigned long long, s_ov_all) + wave * SPB * OW;
+    auto* const s_pp = BSX_LDS(uint16_t, s_pp_all) + wave * SPB * K;
+#pragma unroll
+    for (int q = 0; q < OW; ++q) s_ov[tid * OW + q] = 0ull;   // cleared again by whoever finds them set
     float* const s_pd = s_pd_all + ((N >= 2) ? wave * SPB * N : 0);
     double* const s_pr = s_pr_all + ((N >= 2) ? wave * SPB * N : 0);
     // (explicit LDS address space: a volatile access through a generic pointer compiles to flat_load / flat_store)
@@ -691,11 +704,15 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // lane of a game computes the same record) -- so a later tick starts with its bullet loads instead of a state round
     // trip, and the inputs of tick t+1 are fetched while tick t computes.  Bullet lists and counters go to memory every
     // tick, the plane and game records once, after the last one.
-    int x = 0, y = 0, hp = 0, games = 0;
-    int4 cnt4 = make_int4(0, 0, 0, 0);                   // my game's counters (games, ties, red wins, blue wins): loaded with the other T0 words
-    uint32_t live = 0, xf = 0;
+    int x = 0, y = 0, hp = 0;
+    uint32_t games = 0;                                  // games my slot has finished = episode number of the random streams (travels in the game record)
     double dir = 0.0;
     EnvU er = {};
+    // my wave block's bullet pool: `pc` entries at bent[pool0 ...] (wave-uniform); the first 64 entries are requested with the first
+    // batch of loads, whatever pc is (a mapped, aligned 512-byte row: fully coalesced, and no load of the step depends on another)
+    const ix_t pool0 = ix_t(wblk) * ix_t(POOL_CAP);
+    uint32_t pc = 0;
+    uint2 pool_first = make_uint2(0u, 0u);
     RawIn rin = {}, rin_next = {};
     struct DecIn { int act; double a0, a1, a2, uu; };    // a call's inputs, decoded
     auto decode = [&](const RawIn& r) {
@@ -771,14 +788,14 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // The kernel's arguments likewise: ~60 scalar registers of pointers, strides and reward constants were held across the tick
     // loop, ~40 of them spilled to VGPR lanes before it and read back one v_readlane at a time in every tick (78 of them at
     // 1v1).  Inside a tick the arguments are read through the kernarg segment's own address, made opaque per tick: scalar loads
-    // of 4 ... 16 dwords next to their use, nothing carried.  (StepArgs follows six leading arguments: 5 x 8 + 4 bytes, padded to 48.)
+    // of 4 ... 16 dwords next to their use, nothing carried.  (StepArgs follows eight leading arguments: 7 x 8 + 4 bytes, padded to 64.)
     typedef const StepArgs __attribute__((address_space(4))) StepArgsK;
     static_assert(alignof(StepArgs) == 8, "kernarg offset of StepArgs");
     const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
     if (MULTI) asm volatile("" : "+s"(ka));
     // (the one-call kernels keep the parameter itself: their argument fetch is placed by hand in the shadow of the first loads, and
     //  through the segment pointer it measured slower -- C2 7.21 -> 7.37 us, 4v4 23.4 -> 27.3)
-    auto& p = [&]() -> decltype(auto) { if constexpr (MULTI) return (*reinterpret_cast<StepArgsK*>(ka + 48)); else return (p_); }();
+    auto& p = [&]() -> decltype(auto) { if constexpr (MULTI) return (*reinterpret_cast<StepArgsK*>(ka + 64)); else return (p_); }();
     const int tid = tid_k, lane = tid, a = tid & (G - 1);
     const int gl = tid & ~(G - 1);                       // first thread of my env's group
     const int team = (a < n) ? 0 : 1;                    // 0 red, 1 blue
@@ -788,22 +805,29 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     float* const rew_t = MULTI ? p.rew + int64_t(tk) * p.rew_ts : p.rew;
     uint8_t* const done_t = MULTI ? p.done + int64_t(tk) * p.done_ts : p.done;
     STAMP(0);
-    // ================= T0: every load that depends on no other load, issued back to back, raw 16-byte words ========
+    // ================= T0: every load of the step, issued back to back as raw words: none depends on another ========
     // (the kernel is latency-bound at 65 536 games -- 2 waves per SIMD -- so memory-level parallelism is what pays)
     if (!MULTI || tk == 0) {
-        const uint4 erw = *elem(reinterpret_cast<const uint4*>(env_), ix_t(ec));
-        if (!(DIAG & 16u)) cnt4 = *elem(cnt_, ix_t(ec));              // .x = games finished so far = episode id of the RNG streams
-        games = cnt4.x;
-        const uint4 prw = *elem(reinterpret_cast<const uint4*>(plane_), gt);
+        const uint2 ecw = *elem(envc_, ix_t(ec));
+        const uint2 edw = *elem(envd_, ix_t(ec));         // .y = games finished so far = episode id of the RNG streams
+        const uint2 prw = *elem(plane_, gt);
+        double dirf = 0.0;
+        if constexpr (CONT) dirf = *elem(p.st.pdirf, gt);
         if (!MULTI) load_inputs(0, rin);
+        pool_first = *elem(bent_, pool0 + ix_t(lane));
+        if (!(DIAG & 2u)) pc = __builtin_amdgcn_readfirstlane(*elem(bcnt_, ix_t(wblk)));
         if (!MULTI) {
             // every kernel argument the step needs later is fetched HERE, in the shadow of the first vector loads: left to
             // the compiler, the ones first used inside a branch are loaded there -- a cold scalar fetch with nothing to hide it
             asm volatile("" : "+s"(seed_t), "+s"(env_offset_t));
             if (N == 0) asm volatile("" : "+s"(tie_tick));
         }
-        unpack_plane(prw, x, y, live, hp, xf, dir);
-        er = unpack_env(erw);
+        unpack_plane(prw, x, y, hp, dir);
+        if constexpr (CONT) dir = (prw.y & PLANE_FRAC) ? dirf : dir;
+        er = unpack_env(ecw, edw.x);
+        games = edw.y;
+    } else {
+        pool_first = *elem(bent_, pool0 + ix_t(lane));   // this tick's first 64 entries (the last tick's stores precede this load in program order)
     }
     const DecIn din = MULTI ? din_next : decode(rin);
     int act = din.act;
@@ -918,30 +942,14 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         }
     }
 
-    // ================= T1: the one dependent round trip: per-update steps of my LIVE bullets ========================
-    const uint32_t live0 = live;
-    // Bullets are sparse (uniform random play: 0.6 per agent, 12 at most), and each agent's bullets are a dense list in
-    // creation order: entry j of every agent lives in row j, so the lanes of a wave that own a j-th bullet read ONE
-    // contiguous row.  The first four entries are statically indexed "items", their four loads issued here in one
-    // batch; longer lists are finished by a wave-uniform loop further down.  A missing item reads the heading
-    // table's first entry (one shared cache line, no DRAM traffic).
+    // ================= T1: the heading-table entry -- the one dependent load of the common path =====================
     // The heading table (361 x 16 B, read by every wave of every launch) stays hot in each CU's L1: the entry for the
-    // post-rotation heading is gathered FIRST in this batch, so the plane can move while the bullet loads are in flight.
+    // post-rotation heading is gathered as soon as the action is known, so the plane can move while the shot is prepared.
     double dir_rot = dir;
     if (!CONT) dir_rot = rotate_dir(dir, act == 2 ? 15.0 : (act == 3 ? -15.0 : 0.0));   // one straight-line rotate (+0 leaves any heading in [0, 360] as it is)
     double2 dl = make_double2(0.0, 0.0);
     if (!CONT) dl = p.st.lut[min(max(int(dir_rot), 0), 360)];   // 21.5*cos(-radians(d)), 21.5*sin(-radians(d)) from host libm
-    constexpr int NI = 4;
-    const int cnt0 = (DIAG & 2u) ? 0 : int(live0 & 15u);
-    uint2 ien[NI];
-    if constexpr (!PACK) {
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const bool has = j < cnt0;
-            ien[j] = *(has ? &p.st.bent[size_t(j) * EAt + gt] : reinterpret_cast<const uint2*>(p.st.lut));
-        }
-        if (MULTI && !ACTOR && tk + 1 < p.T) load_inputs(tk + 1, rin_next);   // behind this tick's own loads: nothing waits for it before the tick ends
-    }
+    if (MULTI && !ACTOR && tk + 1 < p.T) load_inputs(tk + 1, rin_next);   // behind this tick's own loads: nothing waits for it before the tick ends
     const bool alive0 = valid && hp > 0;
     STAMP(1);
 
@@ -962,7 +970,6 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     if (!env_ok) mode = M_INERT;
 
     int4 cnt_delta = make_int4(0, 0, 0, 0);              // games, ties, red wins, blue wins
-    const int x0 = x, y0 = y;
     const double d0 = dir;
     const int64_t genv = env_offset_t + ec;
     // does this call fire? (battle_env.py:404-406 / :423; the shot leaves from the PRE-move pose, so it is prepared first:
@@ -972,66 +979,21 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // ---- Bullet.__init__ (sprites.py:293-318) for this call's shot: heading = pre-move heading + (u*8 - 4)
     const bool phys = (mode == M_PHYS) && valid && !(DIAG & 2u);
     const int ks = tick % K;                             // birth-tick ring slot of this call's shot (heading, export only)
-    // ---- wave-packed bullet pass, part 1: lay the wave's bullets out as work slots and fetch the first 64 of them.
-    // Under uniform play an agent holds 0.6 bullets and fires every fourth call, so a per-lane walk over list entries
-    // (4 static items + the shot + a loop for the 58 % of waves in which some lane holds more) runs 7 mostly-empty rounds; packed,
-    // the wave's ~50 bullets fill ONE round of 64 slots.  Slots are numbered ENTRY-major: first every lane's entry 0 (in lane
-    // order), then every entry 1, ...; a lane's own shot is its last entry.  Lists are stored entry-major too ([entry j][agent]),
-    // so the lanes of a round read and write along rows, as coalesced as a per-lane walk -- also when lists are long.
-    // Slot w is served by lane w % 64 in round w / 64; the slot of (lane l, entry k) = #entries below k in the wave + #lanes
-    // below l that have an entry k: one ballot per k.
+    // ---- wave-packed bullet pass, part 1.  The wave's bullets ARE a packed array -- its pool, pc entries in memory -- and this call's
+    // shots queue up behind them in LDS by shot rank: slot w < pc is pool entry w, slot pc + r the r-th shooter's new bullet; slot w is
+    // served by lane w % 64 in round w / 64.  Under uniform play a plane holds 0.6 bullets and fires every fourth call: ~37 + 16 slots,
+    // ONE round.  What a slot needs from its bullet's owner (named by the entry) is staged per owner lane in LDS.
     FSTAMP(3);
-    int slots = 0;                                       // wave total
-    struct Slot { int o, k; bool isnew, on; uint2 en; ix_t go; };   // owner lane, list index, "this call's shot", in use; entry; owner's row
-    Slot cur = {0, 0, false, false, make_uint2(0u, 0u), 0};
-    ix_t gbt = ix_t(wblk * EPB) * ix_t(A);         // row of lane 0's agent; owner lane o sits (o / G) * A + (o % G) rows on
-    if (MULTI) asm volatile("" : "+v"(gbt));
-    auto fetch_slot = [&](int rd) {                      // slot rd * 64 + lane: who owns it, and its list entry (loads in flight on return)
-        Slot f;
-        const int w = rd * SPB + lane;
-        f.on = w < slots;
-        const uint32_t v = f.on ? uint32_t(s_own[w]) : 0u;
-        f.o = int(v & 63u); f.k = int((v >> 8) & 15u); f.isnew = (v >> 15) != 0u;
-        f.go = gbt + ix_t(f.o / G) * ix_t(A) + ix_t(f.o & (G - 1));
-        const bool ld = f.on && !f.isnew;
-        f.en = *elem(p.st.bent, ld ? ix_t(f.k) * EAt + f.go : ix_t(0));   // (a slot that loads nothing reads element 0: one shared line, any mapped address will do)
-        return f;
-    };
-    if constexpr (PACK) {
-        const int ci = phys ? cnt0 + (spawn ? 1 : 0) : 0;
-        // The first UNR list indices straight-line: a loop iteration here is a chain of vector compare -> scalar test -> branch
-        // (~230 cycles each in the stamps, 5 to 6 of them under uniform play); without the branches an index costs ~10
-        // instructions -- a lane without an entry k writes the scratch entry behind the table instead of being masked off.
-        constexpr int UNR = 6;
-#pragma unroll
-        for (int k = 0; k < UNR; ++k) {
-            const bool h = k < ci;
-            const unsigned long long hk = __ballot(h);               // lanes that have an entry k
-            const int w = slots + int(__builtin_amdgcn_mbcnt_hi(uint32_t(hk >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(hk), 0u)));
-            s_own[h ? w : OWN_CAP - 1] = uint16_t(uint32_t(lane) | (uint32_t(k) << 8) | ((k == cnt0) ? 0x8000u : 0u));
-            slots += __popcll(hk);
-        }
-        for (int k = UNR;; ++k) {
-            const unsigned long long hk = __ballot(k < ci);
-            if (hk == 0ull) break;
-            if (k < ci) {
-                const int w = slots + int(__builtin_amdgcn_mbcnt_hi(uint32_t(hk >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(hk), 0u)));
-                s_own[w] = uint16_t(uint32_t(lane) | (uint32_t(k) << 8) | ((k == cnt0) ? 0x8000u : 0u));
-            }
-            slots += __popcll(hk);
-        }
-        FSTAMP(4);
-        s_agg[tid] = 0u;
-        s_eb[tid] = make_rect(pack_xy(team == 0 ? er.bbx : er.brx, team == 0 ? er.bby : er.bry), true, 33, 32, 33, 31);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
+    const unsigned long long shb = __ballot(spawn);
+    const int srank = int(__builtin_amdgcn_mbcnt_hi(uint32_t(shb >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(shb), 0u)));
+    const int slots = int(pc) + __popcll(shb);           // wave-uniform
+    s_agg[tid] = 0u;
+    s_eb[tid] = make_rect(pack_xy(team == 0 ? er.bbx : er.brx, team == 0 ? er.bby : er.bry), true, 33, 32, 33, 31);
+    s_fl[tid] = uint32_t(ks) | (phys ? OWN_PHYS : 0u) | ((mode == M_RESET && valid) ? OWN_DROP : 0u);
+    // does this call touch the pool at all?  (not if no game of the wave is in its physics call or being re-spawned: entries stay as they are)
+    const bool pool_pass = __any(phys || (mode == M_RESET && valid));
+    FSTAMP(4);
     FSTAMP(5);
-    // the first round's entries are requested as soon as the slot table exists -- BEFORE the shot: the ~150 cycles of the table's
-    // LDS round trip are exposed here, and the loads leave ~1.5k cycles (Philox + sincos) earlier; they are what the bullet
-    // rounds wait for, and the move + observation geometry alone are shorter than a round trip to the MALL / HBM
-    if constexpr (PACK) cur = fetch_slot(0);
     // 1v1 discrete: the shot's step from the heading table by angle addition instead of a float64 sincos (below).  Larger teams keep
     // the sincos: there the shorter shot measured SLOWER (4v4 23.3 -> 25.3 us, two runs each) -- the table entry it needs arrives
     // later than the ~110 instructions of the sincos take, and nothing else is left to cover it.
@@ -1043,7 +1005,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     if (spawn) {
         double uu = uu_in;
         if (!u_t && !(DIAG & 8u)) {
-            const uint4 r = draw4(seed_t, genv, STREAM_JITTER, uint32_t(games), (uint32_t(tick) << 8) | uint32_t(a));
+            const uint4 r = draw4(seed_t, genv, STREAM_JITTER, games, (uint32_t(tick) << 8) | uint32_t(a));
             uu = uniform53(r.x, r.y);
         }
         const double jit = uu * 8.0 - 4.0;
@@ -1068,28 +1030,22 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         }
         ncode = step_code(nd.x, nd.y, nexact);
         st_store<NT_STATE>(elem(p.st.bdir, ix_t(ks) * EAt + gt), nbdir);      // ring by birth tick: never moves, read only by bsx_export_state
-        xf |= nexact ? 1u : 0u;                          // rare (step_code): this bullet moves by the float64 sum
+        // the shot as a pool entry, queued by shot rank: age 0, the PRE-move pose, my lane as its owner
+        s_new[srank] = u32x2{pack_bullet(x, y, 0) | (nexact ? ENT_EXACT : 0u) | (uint32_t(lane) << ENT_OWNER_SHIFT), ncode};
     }
-    // does any bullet this wave is about to update take the float64 path?  Asked once, here, long before anything branches on it
-    const bool wave_exact = __any(phys && xf != 0u);
-    if constexpr (PACK) {                                // this call's shot as the work slot will read it: entry (age 0, the PRE-move pose; the owner's tick % 12 rides in the spare bits)
-        s_nw[tid] = pack_bullet(x, y, 0) | (nexact ? ENT_EXACT : 0u) | (uint32_t(ks) << 26);
-        s_ns[tid] = ncode;
-        if (MULTI && !ACTOR && tk + 1 < p.T) load_inputs(tk + 1, rin_next);   // behind this tick's own loads
-    }
+    // rare (step_code): a shot that moves by the float64 sum.  Asked once per wave, here, long before anything branches on it
+    const bool shot_exact = __any(spawn && nexact);
     FSTAMP(6);
 
     STAMP(2);
     if (mode == M_RESET) {
         // re-spawn in place of the inert call; episode id = games played so far
-        EnvRec nb; memset(&nb, 0, sizeof(nb));
-        spawn_bases(seed_t, genv, STREAM_AUTORESET, uint32_t(games), nb);
-        er.brx = nb.brx; er.bry = nb.bry; er.bbx = nb.bbx; er.bby = nb.bby;
+        spawn_bases(seed_t, genv, STREAM_AUTORESET, games, er);
         er.bhp_r = er.bhp_b = 5 * n;
         er.tick = 0; er.done = 0; er.winner = BSX_WINNER_NONE;
         tick = 0;
-        spawn_plane(seed_t, genv, STREAM_AUTORESET, uint32_t(games), a < A ? a : A - 1, n, x, y, dir);
-        hp = PLANE_HP; live = 0; xf = 0;
+        spawn_plane(seed_t, genv, STREAM_AUTORESET, games, a < A ? a : A - 1, n, x, y, dir);
+        hp = PLANE_HP;
     } else if (mode == M_PHYS && alive0) {
         // ---- process_action (battle_env.py:383-424)
         if (!CONT) {
@@ -1115,7 +1071,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // ---- hand the post-move pose and hit points to the other planes of the game.  1v1: the only other plane is the lane
     //      next door, three cross-lane moves (DPP) instead of LDS round trips; larger teams stage the block in LDS.
     int nx_ = 0, ny_ = 0, nhp_ = 0;                      // 1v1: the enemy's x, y, hit points
-    if constexpr (PACK) s_pq[tid] = make_rect(pack_xy(x, y), valid && hp > 0, 27, 25, 27, 24);
+    s_pq[tid] = make_rect(pack_xy(x, y), valid && hp > 0, 27, 25, 27, 24);
     if constexpr (N == 1) {
         nx_ = __shfl_xor(x, 1); ny_ = __shfl_xor(y, 1); nhp_ = __shfl_xor(valid ? hp : 0, 1);
     } else {
@@ -1128,7 +1084,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     PSTAMP(3);
     // ---- observation geometry (battle_env.py:202-244) from the staged block, BEFORE the bullets: poses are final after
     //      the move, only the alive flags can still change; this fp64 math runs while the bullet-step loads are in flight.
-    if (wave_exact) {                                    // wave-uniform and rare: a flagged shot leaves its float64 step in the ring (and in LDS for its first update)
+    if (shot_exact) {                                    // wave-uniform and rare: a flagged shot leaves its float64 step in the ring (and in LDS for its first update)
         if constexpr (N == 1) asm volatile("");          // (keeps this a scalar branch; see the bullet rounds)
         if (spawn && nexact) {
             if constexpr (CHEAP_SHOT) {                  // the exact float64 step, as Bullet.update evaluates it (sprites.py:35-42,330-333)
@@ -1137,7 +1093,7 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
                 nd = make_double2(BULLET_STEP * cs, BULLET_STEP * sn);
             }
             *elem(p.st.bd, ix_t(ks) * EAt + gt) = nd;
-            if constexpr (PACK) { s_nd[2 * tid] = nd.x; s_nd[2 * tid + 1] = nd.y; }
+            s_nd[2 * tid] = nd.x; s_nd[2 * tid + 1] = nd.y;
         }
     }
     const int obx = team == 0 ? er.bbx : er.brx, oby = team == 0 ? er.bby : er.bry;   // enemy base
@@ -1205,21 +1161,11 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     }
 
     PSTAMP(4);
-    // ---- Bullet.update (sprites.py:321-351) per list entry ("item"), predicates as integer sign masks (0 / -1).
-    //      Survivors are written back compacted (position `pos` <= own index), which keeps creation order.
-    constexpr int FW = (N > 0 && N <= 4) ? 4 : 16;       // bits per overlap field, indexed by AGE (1..11)
-    constexpr int OW = (FW == 4) ? 1 : 3;                // 64-bit words holding the 12 fields
+    // ---- Bullet.update (sprites.py:321-351) per work slot, predicates as integer sign masks (0 / -1).
     uint64_t ovl[OW];
 #pragma unroll
     for (int q = 0; q < OW; ++q) ovl[q] = 0;
     int nmiss = 0, nbase = 0, nplane = 0;
-    int pos = 0;                                         // entries written so far = new list length
-    uint64_t posmap = 0;                                 // 4 bits per age: where the survivor of that age now sits
-    int eam[NE];
-    if (N > 0) {
-#pragma unroll
-        for (int j = 0; j < NE; ++j) eam[j] = ((N == 1 ? nhp_ : s_hp[eb + j]) > 0) ? -1 : 0;
-    }
     // the float64 move of the rare entries that carry the exact-path flag (exact_step() fetches the step the shot left in the ring)
     auto move_exact = [&](uint32_t ew, auto exact_step) {
         const double2 dd = exact_step();
@@ -1227,115 +1173,68 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         const int eby = int(double(bullet_y(ew)) + dd.y);
         return (uint32_t(ebx) & 0xFFFFu) | (uint32_t(eby) << 16);
     };
-    // one bullet of MINE (per-lane walk): entry `en` (updates so far = its age field), list index `j` it was read from (-1: this call's shot)
-    auto update_item = [&](int j, uint2 en, int lvm) {
-        const int age0 = bullet_age(en.x);
-        uint32_t bpk = step_pk(en.x & ENT_XY, en.y);
-        if (wave_exact) {                                // wave-uniform, decided before the bullets
-            asm volatile("");
-            if (lvm != 0 && (en.x & ENT_EXACT) != 0u)
-                bpk = move_exact(en.x, [&]() { return j < 0 ? nd : *elem(p.st.bd, ix_t(ring_pos(ks, age0 > 11 ? 0 : age0)) * EAt + gt); });
-        }
-        const int bx = sx16(bpk), by = sy16(bpk);
-        const int age = age0 + 1;
-        // miss: dist_travelled >= 500 <=> 12th update (45*12 >= 500 > 45*11); else off the field (x>1200|x<0|y>800|y<0)
-        const int missm = ((bx | (FIELD_W - bx) | by | (FIELD_H - by) | (11 - age)) >> 31);
-        // base: 6x3 bullet rect vs 62x62 base rect, strict overlap <=> dx in [-33,33] and dy in [-32,31]
-        const int dxb = bx - obx, dyb = by - oby;
-        const int basem = ~(((dxb + 33) | (33 - dxb) | (dyb + 32) | (31 - dyb)) >> 31) & ~missm;
-        // planes: vs the un-rotated 50x48 rect at the post-move pose <=> dx in [-27,27] and dy in [-25,24]
-        uint32_t m = 0;
-        if (N > 0) {
-#pragma unroll
-            for (int q = 0; q < NE; ++q) {
-                const int dxp = bx - ex[q], dyp = by - ey[q];
-                const int pm = ~(((dxp + 27) | (27 - dxp) | (dyp + 25) | (24 - dyp)) >> 31) & eam[q];
-                m |= uint32_t(pm) & (1u << q);
-            }
-        } else {
-            for (int q = 0; q < n; ++q) {
-                const int dxp = bx - s_x[eb + q], dyp = by - s_y[eb + q];
-                const int pm = ~(((dxp + 27) | (27 - dxp) | (dyp + 25) | (24 - dyp)) >> 31) & (s_hp[eb + q] > 0 ? -1 : 0);
-                m |= uint32_t(pm) & (1u << q);
-            }
-        }
-        const int gonem = (missm | basem) & lvm;
-        const int keepm = lvm & ~gonem;
-        m &= uint32_t(keepm);
-        nmiss -= missm & lvm;
-        nbase -= basem & lvm;
-        const int ag = age & 15;
-        if (OW == 1) ovl[0] |= uint64_t(m) << (ag * FW);
-        else {
-            const uint64_t f = uint64_t(m) << ((ag & 3) * 16);
-            ovl[0] |= (ag >> 2) == 0 ? f : 0ull; ovl[OW > 1 ? 1 : 0] |= (ag >> 2) == 1 ? f : 0ull; ovl[OW > 2 ? 2 : 0] |= (ag >> 2) == 2 ? f : 0ull;
-        }
-        if (keepm) {
-            const uint32_t nw_ = pack_bullet(bx, by, age) | (en.x & ENT_EXACT);
-            if (pos != j) p.st.bent[size_t(pos) * EAt + gt] = make_uint2(nw_, en.y);   // the entry moved down (or is new): its step moves with it
-            else p.st.bent[size_t(pos) * EAt + gt].x = nw_;
-            posmap |= uint64_t(pos) << (4 * ag);
-            pos += 1;
-        }
-    };
-    if constexpr (PACK) {
+    bool any_hit = false;
+    if (pool_pass) {
         // ---- wave-packed bullet pass, part 2: Bullet.update per work slot.  A slot reads what its bullet's OWNER would have had
-        // in registers -- the enemy base, the enemy planes' post-move poses and alive flags, this call's shot -- from the wave's
-        // LDS block, moves the bullet, and hands the outcome back: one LDS add per slot (survivor bit, miss and base-hit counts),
-        // the survivor straight to its compacted list position, the rare plane-overlap candidates as the by-age bit fields the
-        // ordered resolve below walks.
+        // in registers -- the enemy base, the enemy planes' post-move poses and alive flags -- from the wave's LDS block, moves the
+        // bullet, and hands the outcome back: one LDS add per bullet that ended (miss and base-hit counts), the survivor straight to
+        // its place in the compacted pool (a wave-wide prefix count of the survivors: one ballot), the rare plane-overlap candidates
+        // as the by-age bit fields the ordered resolve below walks.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): the first round's loads arrived behind the observation geometry
+        __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): the pool's first entries arrived long ago, behind the shot and the observation geometry
                                                          // (and no later wait is held up by the stores issued since: vmcnt is in-order)
-        bool any_hit = false;
         // a round's survivor stores are issued at the START of the next round (after the loop for the last one), i.e. BEFORE the
         // loads of the round after: loads and stores share the in-order vmcnt, so a wait for loads issued ahead of stores would
-        // also sit out the stores' acknowledgement; issued behind them, both are long done when the entries are needed
-        bool st_on = false, st_mv = false; ix_t st_go = 0; int st_ps = 0; uint32_t st_w = 0u, st_c = 0u;
+        // also sit out the stores' acknowledgement; issued behind them, both are long done when the entries are needed.  A round's
+        // survivors land below that round's first slot, i.e. never on an entry that is still to be read.
+        bool st_on = false; int st_ps = 0; uint2 st_w = make_uint2(0u, 0u);
         auto flush_stores = [&]() {
-            if (st_on) {
-                uint2* const q = elem(p.st.bent, ix_t(st_ps) * EAt + st_go);
-                st_store<NT_STATE>(&q->x, st_w);
-                if (st_mv) st_store<NT_STATE>(&q->y, st_c);  // the entry moved down (or is new): its step code moves with it
-            }
+            if (st_on) st_store<NT_STATE>(reinterpret_cast<u32x2*>(elem(p.st.bent, pool0 + ix_t(st_ps))), u32x2{st_w.x, st_w.y});
         };
+        const ix_t gb0 = ix_t(wblk * EPB) * ix_t(A);     // row of lane 0's agent; owner lane o sits (o / G) * A + (o % G) rows on
         // what a slot needs from its owner's side of the game, read from the wave's LDS block: enemy base, enemy planes (post-move
-        // pose + alive flag), this call's shot
-        struct Ctx { rect_t ebw, pq[NE]; uint32_t nw, ns; };
+        // pose + alive flag), the owner's flags
+        struct Ctx { rect_t ebw, pq[NE]; uint32_t fl; int ebl; };
         auto fetch_ctx = [&](int o) {
             Ctx c;
             c.ebw = s_eb[o];
-            const int ebl = (o & ~(G - 1)) + (((o & (G - 1)) < N) ? N : 0);     // first lane of the owner's enemy team
+            c.ebl = (o & ~(G - 1)) + (((o & (G - 1)) < n) ? n : 0);          // first lane of the owner's enemy team
+            if constexpr (N > 0) {
 #pragma unroll
-            for (int q = 0; q < NE; ++q) c.pq[q] = s_pq[ebl + q];
-            c.nw = s_nw[o]; c.ns = s_ns[o];
+                for (int q = 0; q < NE; ++q) c.pq[q] = s_pq[c.ebl + q];
+            }
+            c.fl = s_fl[o];
             return c;
         };
-        Ctx cx = fetch_ctx(cur.o);
+        int wpos = 0;                                    // survivors written so far = the pool's new length (wave-uniform)
+        uint2 nxt = pool_first;                          // slot rd * 64 + lane of the round about to run, as loaded from the pool
         auto do_round = [&](const int rd) {
-            const int o = cur.o, k = cur.k; const bool isnew = cur.isnew, on = cur.on;
-            uint2 en = cur.en;
-            const ix_t go = cur.go;
-            const Ctx c = cx;
+            const int w = rd * SPB + lane;
+            const bool on = w < slots;
+            uint2 en = nxt;
+            if (w >= int(pc)) { const u32x2 sh = s_new[on ? w - int(pc) : 0]; en = make_uint2(sh.x, sh.y); }                 // one of this call's shots (LDS, by shot rank)
+            const int o = on ? int(en.x >> ENT_OWNER_SHIFT) : lane;
+            const Ctx c = fetch_ctx(o);
             if (rd > 0) flush_stores();
-            // more than 64 bullets in the wave: the next round's entries and context are fetched while this one is worked on
-            if ((rd + 1) * SPB < slots) { cur = fetch_slot(rd + 1); cx = fetch_ctx(cur.o); }
-            if (isnew) en = make_uint2(c.nw, c.ns);
+            // more than 64 slots in the wave: the next round's pool entries are fetched while this one is worked on
+            if ((rd + 1) * SPB < int(pc)) nxt = *elem(p.st.bent, pool0 + ix_t((rd + 1) * SPB + lane));
             const uint32_t age0f = en.x & ENT_AGE;                              // updates so far, << 11
-            const int lvm = (on && age0f != (TOMBSTONE_AGE << 11)) ? -1 : 0;     // a tombstone (plane hit last call) is dropped
+            const bool ophys = on && (c.fl & OWN_PHYS) != 0u;                   // the owner's game is in its physics call
+            const int lvm = (ophys && age0f != (TOMBSTONE_AGE << 11)) ? -1 : 0;  // a tombstone (plane hit last call) is dropped
             // Everything from here to the outcome works on (x, y) PAIRS in the two 16-bit halves of a register: the move, and every
             // rectangle test as "some lower or upper margin is negative" = a sign bit in either half.
             uint32_t bpk = step_pk(en.x & ENT_XY, en.y);
-            if (wave_exact) {                            // wave-uniform, decided before the rounds: the float64 move of flagged entries
-                if constexpr (N == 1) asm volatile("");   // (1v1: keeps this a scalar branch -- merged with the per-lane test below it is a masked block on the common
-                                                           //  path; larger teams measured faster with the merged form: 4v4 22.9 us against 23.7)
-                if (lvm != 0 && (en.x & ENT_EXACT) != 0u)                       // (this call's shot left its step in LDS, older ones in the ring by birth tick)
+            if (__any(lvm != 0 && (en.x & ENT_EXACT) != 0u)) {                  // wave-uniform and rare: the float64 move of flagged entries
+                if constexpr (N == 1) asm volatile("");   // (1v1: keeps this a scalar branch on the common path)
+                if (lvm != 0 && (en.x & ENT_EXACT) != 0u) {                     // (this call's shot left its step in LDS, older ones in the ring by birth tick)
+                    const ix_t go = gb0 + ix_t(o / G) * ix_t(A) + ix_t(o & (G - 1));
                     bpk = move_exact(en.x, [&]() {
-                        return isnew ? make_double2(s_nd[2 * o], s_nd[2 * o + 1])
-                                     : *elem(p.st.bd, ix_t(ring_pos(int((c.nw >> 26) & 15u), int(age0f >> 11))) * EAt + go);
+                        return age0f == 0u ? make_double2(s_nd[2 * o], s_nd[2 * o + 1])
+                                           : *elem(p.st.bd, ix_t(ring_pos(int(c.fl & 15u), int(age0f >> 11))) * EAt + go);
                     });
+                }
             }
             // miss: off the field (x > 1200 | x < 0 | y > 800 | y < 0), or dist_travelled >= 500 <=> this is the 12th update.  Plain
             // 32-bit arithmetic with literals on the packed pair: a half that borrows from (or carries into) its neighbour does so
@@ -1348,29 +1247,34 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
             const int basem = hits_rect(b2, c.ebw, 33, 32, 33, 31) & ~missm;
             // planes: vs the un-rotated 50x48 rect at the post-move pose <=> dx in [-27, 27] and dy in [-25, 24]
             uint32_t m = 0;
+            if constexpr (N > 0) {
 #pragma unroll
-            for (int q = 0; q < NE; ++q) m |= uint32_t(hits_rect(b2, c.pq[q], 27, 25, 27, 24)) & (1u << q);
+                for (int q = 0; q < NE; ++q) m |= uint32_t(hits_rect(b2, c.pq[q], 27, 25, 27, 24)) & (1u << q);
+            } else {
+                for (int q = 0; q < n; ++q) m |= uint32_t(hits_rect(b2, s_pq[c.ebl + q], 27, 25, 27, 24)) & (1u << q);
+            }
             const int age = int(age0f >> 11) + 1;
             const int gonem = (missm | basem) & lvm;
             const int keepm = lvm & ~gonem;
             m &= uint32_t(keepm);
-            // One LDS add per slot hands the outcome to the owner: survivor bit k | misses << 16 | base hits << 24 (each entry adds
-            // its bit once, so the add is an OR there).  Entries below k of the same owner sit in earlier slots -- an earlier round
-            // or lower lanes of this one -- and their adds are done when the word is read back: list position of a survivor =
-            // number of survivor bits below k.
-            const uint32_t add = (uint32_t(keepm & 1) << k) | (uint32_t(missm & lvm & 1) << 16) | (uint32_t(basem & lvm & 1) << 24);
+            // One LDS add hands a bullet that ended to its owner: misses << 16 | base hits << 24.
+            const uint32_t add = (uint32_t(missm & lvm & 1) << 16) | (uint32_t(basem & lvm & 1) << 24);
             if (add) __hip_atomic_fetch_add(&s_agg[o], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int ps = __popc(s_agg[o] & ((1u << k) - 1u));
-            st_on = keepm != 0; st_mv = isnew || ps != k; st_go = go; st_ps = ps; st_c = en.y;
-            st_w = ((en.x & (ENT_AGE | ENT_EXACT)) | bpk) + 0x800u;             // the new position, age + 1, the flag as it was
+            // What stays in the pool: a bullet that flies on (new position, age + 1), and -- untouched -- the entries of games that are
+            // not in their physics call (finished and waiting, or tied by this call); the entries of a game this call re-spawns go.
+            const bool asis = on && !ophys && (c.fl & OWN_DROP) == 0u;
+            const bool stay = keepm != 0 || asis;
+            const unsigned long long kb = __ballot(stay);
+            const int ps = wpos + int(__builtin_amdgcn_mbcnt_hi(uint32_t(kb >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(kb), 0u)));
+            wpos += __popcll(kb);
+            st_on = stay; st_ps = ps;
+            st_w = make_uint2(asis ? en.x : (((en.x & ~ENT_XY) | bpk) + 0x800u), en.y);   // the new position, age + 1; flag and owner as they were
             if (__any(m != 0u)) {                        // wave-uniform and rare: a bullet overlaps a live enemy plane
                 any_hit = true;
                 if (m != 0u) {
-                    __hip_atomic_fetch_or(&s_ov[o], (unsigned long long)(m) << (age * FW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_or(&s_pm[o], (unsigned long long)(ps) << (4 * age), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if constexpr (OW == 1) __hip_atomic_fetch_or(&s_ov[o], (unsigned long long)(m) << (age * FW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else __hip_atomic_fetch_or(&s_ov[o * OW + (age >> 2)], (unsigned long long)(m) << ((age & 3) * 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    s_pp[o * K + age] = uint16_t(ps);    // (age 1 .. 11 here: a 12th update is always a range miss)
                 }
             }
         };
@@ -1379,43 +1283,20 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
         if (slots > 0) do_round(0);
         for (int rd = 1; rd * SPB < slots; ++rd) do_round(rd);
         if (slots > 0) flush_stores();
+        if (wpos != int(pc) || MULTI) {                  // the pool's new length (one word per wave)
+            if (lane == 0 && !MULTI) *elem(p.st.bcnt, ix_t(wblk)) = uint32_t(wpos);
+            pc = uint32_t(wpos);
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const uint32_t agg = s_agg[tid];
-        nmiss = int((agg >> 16) & 0xFFu); nbase = int((agg >> 24) & 0xFFu); pos = __popc(agg & 0xFFFFu);
+        nmiss = int((agg >> 16) & 0xFFu); nbase = int((agg >> 24) & 0xFFu);
         if (any_hit) {
-            ovl[0] = s_ov[tid]; posmap = s_pm[tid];
-            s_ov[tid] = 0ull; s_pm[tid] = 0ull;
+#pragma unroll
+            for (int q = 0; q < OW; ++q) { ovl[q] = s_ov[tid * OW + q]; s_ov[tid * OW + q] = 0ull; }
         }
         if (N != 1 && nbase) __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)(&s_bhit[gl + team]), nbase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (phys) { live = uint32_t(pos); xf = pos ? xf : 0u; }
-    } else
-    {
-        const int physm = phys ? -1 : 0;
-        // All item loads have long arrived (the observation geometry ran in between); say so once.  Loads and stores share
-        // the in-order vmcnt on gfx9: without this the per-item waits the compiler derives (vmcnt(5), (4), ... (0)) end up
-        // waiting for the survivor STORES of earlier items to be acknowledged before a later item may start.
-        __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0); expcnt / lgkmcnt untouched
-#pragma unroll
-        for (int j = 0; j < NI; ++j)                                                // a tombstone (plane hit last call) is dropped
-            update_item(j, ien[j], ((j < cnt0 && bullet_age(ien[j].x) != int(TOMBSTONE_AGE)) ? -1 : 0) & physm);
-        // lists longer than NI: two more rounds when every agent fires every tick
-        for (int base = NI; __any(cnt0 > base); base += NI) {
-            uint2 re[NI];
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const bool has = base + j < cnt0;
-                re[j] = *(has ? &p.st.bent[size_t(base + j) * EAt + gt] : reinterpret_cast<const uint2*>(p.st.lut));
-            }
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-                update_item(base + j, re[j], ((base + j < cnt0 && bullet_age(re[j].x) != int(TOMBSTONE_AGE)) ? -1 : 0) & physm);
-        }
-        // this call's shot is the newest bullet: appended last
-        update_item(-1, make_uint2(pack_bullet(x0, y0, 0) | (nexact ? ENT_EXACT : 0u), ncode), (spawn ? -1 : 0) & physm);
-        if (N != 1 && nbase) __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)(&s_bhit[gl + team]), nbase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (phys) { live = uint32_t(pos); xf = pos ? xf : 0u; }
     }
     PSTAMP(5);
     // ---- ordered plane-hit resolve (battle_env.py:332-360 with sprites.py:348-350): creation order = oldest age
@@ -1452,13 +1333,13 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        // a bullet that hit a plane is gone: its list entry becomes a tombstone, dropped by the next call's compaction
-        // (packed pass: the survivor word was stored by ANOTHER lane of this wave; let it land before it is overwritten)
-        if (PACK && __any(consumed != 0u)) __builtin_amdgcn_s_waitcnt(0x0F70);
+        // a bullet that hit a plane is gone: its pool entry becomes a tombstone, dropped by the next call's compaction
+        // (the survivor entry was stored by ANOTHER lane of this wave; let it land before its first word is overwritten)
+        if (__any(consumed != 0u)) __builtin_amdgcn_s_waitcnt(0x0F70);
         while (consumed) {
             const int ag = __builtin_ctz(consumed);
             consumed &= consumed - 1u;
-            elem(p.st.bent, ix_t((posmap >> (4 * ag)) & 15u) * EAt + gt)->x = pack_bullet(0, 0, int(TOMBSTONE_AGE));
+            elem(p.st.bent, pool0 + ix_t(s_pp[tid * K + ag]))->x = pack_bullet(0, 0, int(TOMBSTONE_AGE)) | (uint32_t(lane) << ENT_OWNER_SHIFT);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1501,8 +1382,11 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     // ---- write back (MULTI: plane and game records travel in registers; memory gets them once, after the last tick)
     const bool last_tick = !MULTI || tk == p.T - 1;
     if (valid) {
-        if (MULTI ? last_tick : (mode == M_PHYS || mode == M_RESET))
-            st_store<NT_STATE>(elem(reinterpret_cast<v4u_t*>(p.st.plane), gt), as_v4u(pack_plane(x, y, live, hp, xf, dir)));
+        if (MULTI ? last_tick : (mode == M_PHYS || mode == M_RESET)) {
+            const uint2 pw = pack_plane(x, y, hp, dir, CONT);
+            st_store<NT_STATE>(reinterpret_cast<u32x2*>(elem(p.st.plane, gt)), u32x2{pw.x, pw.y});
+            if constexpr (CONT) st_store<NT_STATE>(elem(p.st.pdirf, gt), dir);   // continuous headings are fractional: the float64 beside the record
+        }
         out_store(elem(rew_t, gt), float(rew));
         out_store(elem(done_t, gt), er.done ? uint8_t(1) : uint8_t(alive ? 0 : 1));
     }
@@ -1588,10 +1472,20 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
     }
     if (valid) {
         if (a == 0) {
-            if (MULTI ? last_tick : (mode != M_INERT)) st_store<NT_STATE>(elem(reinterpret_cast<v4u_t*>(p.st.env), ix_t(e)), as_v4u(pack_env(er)));
-            if (cnt_delta.x) {                           // game over: the counters were loaded with the game record, no second round trip
-                cnt4.x += cnt_delta.x; cnt4.y += cnt_delta.y; cnt4.z += cnt_delta.z; cnt4.w += cnt_delta.w;
-                *elem(p.st.cnt, ix_t(e)) = cnt4;
+            if (MULTI ? last_tick : (mode != M_INERT)) {
+                // the game record: hit points, clock, flags and the episode number; the base positions only when the game was re-spawned
+                st_store<NT_STATE>(reinterpret_cast<u32x2*>(elem(p.st.envd, ix_t(e))), u32x2{pack_envd(er), games + uint32_t(cnt_delta.x)});
+                if (MULTI || mode == M_RESET) {
+                    const uint2 cw = pack_envc(er);
+                    st_store<NT_STATE>(reinterpret_cast<u32x2*>(elem(p.st.envc, ix_t(e))), u32x2{cw.x, cw.y});
+                }
+            }
+            if (cnt_delta.x) {                           // game over: the win / tie counters (nothing on the step path reads them: fire-and-forget atomics)
+                int* const c4 = elem(p.st.cnt, ix_t(e) * 4);
+                __hip_atomic_fetch_add(c4, cnt_delta.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cnt_delta.y) __hip_atomic_fetch_add(c4 + 1, cnt_delta.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cnt_delta.z) __hip_atomic_fetch_add(c4 + 2, cnt_delta.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cnt_delta.w) __hip_atomic_fetch_add(c4 + 3, cnt_delta.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (last_tick) {
                 if (p.env_done) *elem(p.env_done, ix_t(e)) = uint8_t(er.done);
@@ -1600,9 +1494,10 @@ void bsx_step_kernel(const int64_t E_, const EnvRec* const env_, const int4* con
             if (MULTI && p.env_done_t) p.env_done_t[int64_t(tk) * E_ + e] = uint8_t(er.done);
         }
     }
+    if (MULTI && last_tick && lane == 0) *elem(p.st.bcnt, ix_t(wblk)) = pc;   // the pool's length travelled in a register
     STAMP(7);
     if (MULTI) {
-        games += cnt_delta.x;
+        games += uint32_t(cnt_delta.x);
         // The only memory one tick hands to the next is what a LANE stored itself and reloads itself (its bullet rows; the
         // game counters' read-modify-write) plus this wave's LDS rows.  A wavefront's vector memory operations are performed
         // in order through the one L1 of its CU, so wavefront scope is enough: a compiler ordering point, no s_waitcnt -- this
@@ -1629,43 +1524,73 @@ __global__ __launch_bounds__(TPB) void bsx_reset_kernel(const ResetArgs p) {
     const size_t g = valid ? size_t(e) * A + a : 0;
     __shared__ volatile int s_x[TPB], s_y[TPB], s_hp[TPB];
 
-    EnvRec er; memset(&er, 0, sizeof(er));
-    PlaneRec pr; memset(&pr, 0, sizeof(pr));
-    if (env_ok) er = p.st.env[e];
-    if (valid) pr = p.st.plane[g];
+    EnvU er = {};
+    uint32_t games = 0;
+    int x = 0, y = 0, hp = 0;
+    double dir = 0.0;
+    bool frac = false;
+    if (env_ok) {
+        const uint2 dw = p.st.envd[e];
+        er = unpack_env(p.st.envc[e], dw.x);
+        games = dw.y;
+    }
+    if (valid) {
+        const uint2 pw = p.st.plane[g];
+        unpack_plane(pw, x, y, hp, dir);
+        frac = (pw.y & PLANE_FRAC) != 0u;
+        if (frac) dir = p.st.pdirf[g];
+    }
     const bool doit = env_ok && !p.observe_only && (!p.mask || p.mask[e]);
     if (doit) {
         const int64_t genv = p.env_offset + e;
         if (p.spawn) {
             const int32_t* s = p.spawn + size_t(e) * (4 + 3 * A);
-            er.brx = int16_t(s[0]); er.bry = int16_t(s[1]); er.bbx = int16_t(s[2]); er.bby = int16_t(s[3]);
-            if (valid) { pr.x = int16_t(s[4 + 3 * a]); pr.y = int16_t(s[5 + 3 * a]); pr.dir = double(s[6 + 3 * a]); }
+            er.brx = s[0]; er.bry = s[1]; er.bbx = s[2]; er.bby = s[3];
+            if (valid) { x = s[4 + 3 * a]; y = s[5 + 3 * a]; dir = double(s[6 + 3 * a]); }
         } else {
             spawn_bases(p.seed, genv, STREAM_RESET, uint32_t(p.nonce), er);
-            if (valid) {
-                int x, y; double d;
-                spawn_plane(p.seed, genv, STREAM_RESET, uint32_t(p.nonce), a, n, x, y, d);
-                pr.x = int16_t(x); pr.y = int16_t(y); pr.dir = d;
-            }
+            if (valid) spawn_plane(p.seed, genv, STREAM_RESET, uint32_t(p.nonce), a, n, x, y, dir);
         }
-        er.bhp_r = er.bhp_b = int16_t(5 * n);
+        er.bhp_r = er.bhp_b = 5 * n;
         er.tick = 0; er.done = 0; er.winner = BSX_WINNER_NONE;
-        pr.hp = PLANE_HP; pr.live = 0; pr.xf = 0;
-        if (valid) p.st.plane[g] = pr;
-        if (valid && a == 0) p.st.env[e] = er;
+        hp = PLANE_HP; frac = false;                         // spawn headings are whole degrees (sprites.py:85,91; injected spawns are int32)
+        if (valid) p.st.plane[g] = pack_plane(x, y, hp, dir, false);
+        if (valid && a == 0) { p.st.envc[e] = pack_envc(er); p.st.envd[e] = make_uint2(pack_envd(er), games); }   // the episode number stays
     }
-    s_x[tid] = pr.x; s_y[tid] = pr.y; s_hp[tid] = valid ? pr.hp : 0;
+    // the bullets of a game that is reset go (battle_env.py:268): every wavefront of this kernel covers exactly one wave block of the
+    // step kernels (64 lanes, the same lane <-> plane mapping), so it filters that block's pool: entries whose owner's game stays, stay
+    if (!p.observe_only) {
+        const int lane = tid & 63;
+        const int64_t wb = int64_t(blockIdx.x) * (TPB / 64) + (tid >> 6);
+        const unsigned long long resetting = __ballot(doit);
+        if (resetting != 0ull && wb < wave_blocks(p.E, n)) {     // wave-uniform
+            uint2* const pool = p.st.bent + size_t(wb) * POOL_CAP;
+            const int pc = int(p.st.bcnt[wb]);
+            int wpos = 0;
+            for (int base = 0; base < pc; base += 64) {
+                const int w = base + lane;
+                const uint2 en = pool[w < pc ? w : 0];
+                const bool stay = w < pc && ((resetting >> (en.x >> ENT_OWNER_SHIFT)) & 1ull) == 0ull;
+                const unsigned long long kb = __ballot(stay);
+                const int ps = wpos + __popcll(kb & ((1ull << lane) - 1ull));
+                if (stay) pool[ps] = en;                     // ps <= w: lands on an entry this or an earlier round has already read
+                wpos += __popcll(kb);
+            }
+            if (lane == 0) p.st.bcnt[wb] = uint32_t(wpos);
+        }
+    }
+    s_x[tid] = x; s_y[tid] = y; s_hp[tid] = valid ? hp : 0;
     __syncthreads();
     if (valid && p.obs) {
         const int team = a < n ? 0 : 1;
-        write_obs<0>(p.obs + g * size_t(3 * n + 2), n, pr.hp > 0, pr.x, pr.y, pr.dir, a,
+        write_obs<0>(p.obs + g * size_t(3 * n + 2), n, hp > 0, x, y, dir, a,
                      team == 0 ? er.bbx : er.brx, team == 0 ? er.bby : er.bry, gl, s_x, s_y, s_hp);
     }
 }
 
-__global__ void bsx_mark_done_kernel(EnvRec* env, int64_t E) {
+__global__ void bsx_mark_done_kernel(uint2* envd, int64_t E) {
     const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (e < E) { EnvRec r; memset(&r, 0, sizeof(r)); r.done = 1; env[e] = r; }
+    if (e < E) envd[e] = make_uint2(1u << 27, 0u);          // done = 1, everything else 0
 }
 
 struct ExportArgs { StatePtrs st; int64_t E; int n; BsxExport out; int tie_tick; };
@@ -1677,17 +1602,22 @@ __global__ __launch_bounds__(TPB) void bsx_export_kernel(const ExportArgs p) {
     if (g >= EA) return;
     const int64_t e = int64_t(g / A);
     const int a = int(g % A);
-    const PlaneRec pr = p.st.plane[g];
+    const uint2 pw = p.st.plane[g];
+    int x, y, hp;
+    double dir;
+    unpack_plane(pw, x, y, hp, dir);
+    if (pw.y & PLANE_FRAC) dir = p.st.pdirf[g];
     const BsxExport& o = p.out;
-    if (o.px) o.px[g] = pr.x;
-    if (o.py) o.py[g] = pr.y;
-    if (o.pdir) o.pdir[g] = pr.dir;
-    if (o.php) o.php[g] = pr.hp;
-    if (o.palive) o.palive[g] = pr.hp > 0;
-    // list entries -> the slot view of the export schema: slot = birth tick % 12, birth tick = (ticks on which bullets
+    if (o.px) o.px[g] = x;
+    if (o.py) o.py[g] = y;
+    if (o.pdir) o.pdir[g] = dir;
+    if (o.php) o.php[g] = hp;
+    if (o.palive) o.palive[g] = hp > 0;
+    // pool entries -> the slot view of the export schema: slot = birth tick % 12, birth tick = (ticks on which bullets
     // were updated) - age + 1; the time-limit tie call advances the clock but not the bullets (battle_env.py:316-323)
-    const EnvRec ev = p.st.env[e];
-    const int ptick = int(ev.tick) - ((ev.done && ev.winner == BSX_WINNER_TIE && int(ev.tick) >= p.tie_tick) ? 1 : 0);
+    const uint2 dw = p.st.envd[e];
+    const EnvU ev = unpack_env(p.st.envc[e], dw.x);
+    const int ptick = ev.tick - ((ev.done && ev.winner == BSX_WINNER_TIE && ev.tick >= p.tie_tick) ? 1 : 0);
     for (int k = 0; k < K; ++k) {
         const size_t i = g * K + k;
         if (o.bl_live) o.bl_live[i] = 0;
@@ -1695,11 +1625,16 @@ __global__ __launch_bounds__(TPB) void bsx_export_kernel(const ExportArgs p) {
         if (o.bl_y) o.bl_y[i] = 0;
         if (o.bl_dir) o.bl_dir[i] = 0.0;
     }
-    const int cnt = int(pr.live & 15u);
+    // my bullets are the entries of my wave block's pool that name my lane (debug / test path: a plain scan)
+    const int G = group_width(p.n), EPB = 64 / G;
+    const int64_t wb = e / EPB;
+    const uint32_t me = uint32_t(int(e % EPB) * G + a);
+    const uint2* const pool = p.st.bent + size_t(wb) * POOL_CAP;
+    const int cnt = int(p.st.bcnt[wb]);
     for (int j2 = 0; j2 < cnt; ++j2) {
-        const uint32_t w = p.st.bent[size_t(j2) * EA + g].x;
+        const uint32_t w = pool[j2].x;
         const int age = bullet_age(w);
-        if (age == int(TOMBSTONE_AGE)) continue;
+        if ((w >> ENT_OWNER_SHIFT) != me || age == int(TOMBSTONE_AGE)) continue;
         int slot = (ptick - age + 1) % K;
         if (slot < 0) slot += K;
         const size_t i = g * K + slot;
@@ -1709,15 +1644,14 @@ __global__ __launch_bounds__(TPB) void bsx_export_kernel(const ExportArgs p) {
         if (o.bl_dir) o.bl_dir[i] = p.st.bdir[size_t(slot) * EA + g];
     }
     if (a == 0) {
-        const EnvRec er = p.st.env[e];
-        if (o.base_xy) { o.base_xy[4 * e] = er.brx; o.base_xy[4 * e + 1] = er.bry; o.base_xy[4 * e + 2] = er.bbx; o.base_xy[4 * e + 3] = er.bby; }
-        if (o.bhp) { o.bhp[2 * e] = er.bhp_r; o.bhp[2 * e + 1] = er.bhp_b; }
-        if (o.tick) o.tick[e] = er.tick;
-        if (o.env_done) o.env_done[e] = er.done;
-        if (o.winner) o.winner[e] = er.winner;
+        if (o.base_xy) { o.base_xy[4 * e] = ev.brx; o.base_xy[4 * e + 1] = ev.bry; o.base_xy[4 * e + 2] = ev.bbx; o.base_xy[4 * e + 3] = ev.bby; }
+        if (o.bhp) { o.bhp[2 * e] = ev.bhp_r; o.bhp[2 * e + 1] = ev.bhp_b; }
+        if (o.tick) o.tick[e] = ev.tick;
+        if (o.env_done) o.env_done[e] = ev.done;
+        if (o.winner) o.winner[e] = ev.winner;
         if (o.counters) {
-            const int4 c4 = p.st.cnt[e];
-            o.counters[4 * e] = c4.x; o.counters[4 * e + 1] = c4.y; o.counters[4 * e + 2] = c4.z; o.counters[4 * e + 3] = c4.w;
+            const int* c4 = p.st.cnt + 4 * e;
+            o.counters[4 * e] = c4[0]; o.counters[4 * e + 1] = c4[1]; o.counters[4 * e + 2] = c4[2]; o.counters[4 * e + 3] = c4[3];
         }
     }
 }
@@ -1762,11 +1696,11 @@ inline int grid_for(int64_t E, int n, int tpb = TPB) {
 template <bool CONT, bool MULTI, bool LG, bool OFF32>
 void launch_for_n_w(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs& a, int64_t bound) {
     switch (n) {
-        case 1: hipLaunchKernelGGL((bsx_step_kernel<1, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, bound, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-        case 2: hipLaunchKernelGGL((bsx_step_kernel<2, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, bound, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-        case 3: hipLaunchKernelGGL((bsx_step_kernel<3, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, bound, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-        case 4: hipLaunchKernelGGL((bsx_step_kernel<4, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, bound, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-        default: hipLaunchKernelGGL((bsx_step_kernel<0, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, bound, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        case 1: hipLaunchKernelGGL((bsx_step_kernel<1, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, bound, a.st.envc, a.st.envd, a.st.plane, a.actions, a.st.bent, a.st.bcnt, a.action_kind, a); break;
+        case 2: hipLaunchKernelGGL((bsx_step_kernel<2, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, bound, a.st.envc, a.st.envd, a.st.plane, a.actions, a.st.bent, a.st.bcnt, a.action_kind, a); break;
+        case 3: hipLaunchKernelGGL((bsx_step_kernel<3, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, bound, a.st.envc, a.st.envd, a.st.plane, a.actions, a.st.bent, a.st.bcnt, a.action_kind, a); break;
+        case 4: hipLaunchKernelGGL((bsx_step_kernel<4, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, bound, a.st.envc, a.st.envd, a.st.plane, a.actions, a.st.bent, a.st.bcnt, a.action_kind, a); break;
+        default: hipLaunchKernelGGL((bsx_step_kernel<0, CONT, MULTI, false, LG, OFF32>), grid, block, 0, s, bound, a.st.envc, a.st.envd, a.st.plane, a.actions, a.st.bent, a.st.bcnt, a.action_kind, a); break;
     }
 }
 // 32-bit offsets when every array of the job stays below 4 GB: an observation row is at most 4 (3 * 16 + 2) = 200 bytes per agent,
@@ -1812,10 +1746,13 @@ int launch_step(void* state, int64_t E, int n, const void* actions, int action_k
     a.u_ts = EA;
     a.obs_ts = store_all ? EA * (3 * n + 2) : 0; a.rew_ts = store_all ? EA : 0; a.done_ts = store_all ? EA : 0;
     if (first) {
-        // Every array is indexed by game or by agent row (game * 2n + plane), the bullet arrays by entry * (E * 2n) + agent row with the stride
-        // taken from a.E: advancing each pointer to the range's first row turns the kernel's row r into row first + r of the full arrays.
+        // Every array is indexed by game, by agent row (game * 2n + plane) or by wave block (the bullet pools), the two birth-tick rings by
+        // slot * (E * 2n) + agent row with the stride taken from a.E: advancing each pointer to the range's first row turns the kernel's
+        // row r into row first + r of the full arrays.
         const int64_t fa = first * 2 * n;
-        a.st.env += first; a.st.cnt += first; a.st.plane += fa; a.st.bent += fa; a.st.bdir += fa; a.st.bd += fa;
+        const int64_t fb = first / (64 / group_width(n));     // the range's first wave block (first is a multiple of 256 games)
+        a.st.envc += first; a.st.envd += first; a.st.cnt += 4 * first; a.st.plane += fa; a.st.pdirf += fa;
+        a.st.bcnt += fb; a.st.bent += fb * POOL_CAP; a.st.bdir += fa; a.st.bd += fa;
         if (actions) a.actions = static_cast<const char*>(actions) + fa * (a.act_tb / EA);
         if (u) a.u += fa;
         a.obs += fa * (3 * n + 2); a.rew += fa; a.done += fa;
@@ -1889,7 +1826,7 @@ int bsx_state_init(void* state, int64_t E, int n, void* stream) {
     if (err != hipSuccess) return int(err);
     // every env starts finished (done = 1), so a step before the first reset is the inert call of battle_env.py:303-306
     hipLaunchKernelGGL(bsx_mark_done_kernel, dim3(unsigned((E + TPB - 1) / TPB)), dim3(TPB), 0, s,
-                       reinterpret_cast<EnvRec*>(static_cast<char*>(state) + L.env), E);
+                       reinterpret_cast<uint2*>(static_cast<char*>(state) + L.envd), E);
     return int(hipGetLastError());
 }
 
@@ -1953,10 +1890,10 @@ namespace {
 template <bool CONT, bool OFF32>
 void launch_rollout_w(int n, dim3 grid, hipStream_t s, const StepArgs& a) {
     switch (n) {
-        case 1: hipLaunchKernelGGL((bsx_step_kernel<1, CONT, true, true, false, OFF32>), grid, dim3(SPB * 1), 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-        case 2: hipLaunchKernelGGL((bsx_step_kernel<2, CONT, true, true, false, OFF32>), grid, dim3(SPB * 2), 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-        case 3: hipLaunchKernelGGL((bsx_step_kernel<3, CONT, true, true, false, OFF32>), grid, dim3(SPB * 4), 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
-        default: hipLaunchKernelGGL((bsx_step_kernel<4, CONT, true, true, false, OFF32>), grid, dim3(SPB * 4), 0, s, a.E, a.st.env, a.st.cnt, a.st.plane, a.actions, a.action_kind, a); break;
+        case 1: hipLaunchKernelGGL((bsx_step_kernel<1, CONT, true, true, false, OFF32>), grid, dim3(SPB * 1), 0, s, a.E, a.st.envc, a.st.envd, a.st.plane, a.actions, a.st.bent, a.st.bcnt, a.action_kind, a); break;
+        case 2: hipLaunchKernelGGL((bsx_step_kernel<2, CONT, true, true, false, OFF32>), grid, dim3(SPB * 2), 0, s, a.E, a.st.envc, a.st.envd, a.st.plane, a.actions, a.st.bent, a.st.bcnt, a.action_kind, a); break;
+        case 3: hipLaunchKernelGGL((bsx_step_kernel<3, CONT, true, true, false, OFF32>), grid, dim3(SPB * 4), 0, s, a.E, a.st.envc, a.st.envd, a.st.plane, a.actions, a.st.bent, a.st.bcnt, a.action_kind, a); break;
+        default: hipLaunchKernelGGL((bsx_step_kernel<4, CONT, true, true, false, OFF32>), grid, dim3(SPB * 4), 0, s, a.E, a.st.envc, a.st.envd, a.st.plane, a.actions, a.st.bent, a.st.bcnt, a.action_kind, a); break;
     }
 }
 template <bool CONT>

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BSX_ABI_VERSION 13
+#define BSX_ABI_VERSION 14
 #define BSX_BULLET_SLOTS 12 /* a bullet is removed at the latest on its 12th update (sprites.py:334-337: 12*45 >= 500) */
 #define BSX_MAX_N 16
 #define BSX_MAX_E (INT64_C(1) << 30)   /* games per call: keeps every grid below 2^31 workgroups; 2^30 games of 1v1 is ~0.8 TB of state */

@@ -157,8 +157,8 @@ def test_bench_measures_the_headline_hbm_traffic_live():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     r = d["roofline"]
-    assert r["traffic_detail"] is not None and r["traffic_source"].startswith("measured by this run"), r["traffic_source"]
-    assert 8e6 < r["traffic"] < r["algorithmic_bytes_per_launch"]          # sparse bullets: less than the 12-slot algorithmic count
+    assert r["traffic_detail"] is not None and r["traffic_source"].startswith("this run"), r["traffic_source"]
+    assert 5e6 < r["traffic"] < r["algorithmic_bytes_per_launch"]          # sparse bullets: less than the 12-slot algorithmic count
     assert abs(r["traffic"] - (2 * r["traffic_detail"]["fetch_size_kib_raw"] + r["traffic_detail"]["write_size_kib_raw"]) * 1024) < 2048
     assert abs(r["frac_on_traffic"] - r["traffic"] / (r["avg_launch_us"] * 1e-6) / 1e9 / r["peak"]) < 1e-3 and r["frac_on_traffic"] < r["frac"]
     assert r["frac_claimed"] == r["frac_on_traffic"]

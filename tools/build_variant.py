@@ -7,7 +7,7 @@
     BSX_LIB_PATH=deep-rl-battlespace_amd/csrc/variants/lib_<name>.so [BSX_ALLOW_DIAG=1] python bench.py ...
 
 Same sources and base flags as deep-rl-battlespace_amd/build.py; the extra flags select what differs (-DBSX_DIAG=<bits>,
--DBSX_STAMPS, -DBSX_X_NOPACK -- see csrc/bsx_diag.h, which only these builds include --, -mllvm ...).  A variant whose results are not the reference's reports that through
+-DBSX_STAMPS -- see csrc/bsx_diag.h, which only these builds include --, -mllvm ...).  A variant whose results are not the reference's reports that through
 bsx_build_flags() and the binding refuses it without BSX_ALLOW_DIAG=1.  hipcc cross-compiles without a GPU, so variants
 are built in the build container and travel to the GPU box with the snapshot (csrc/variants/*.so is git-ignored)."""
 import importlib.util
