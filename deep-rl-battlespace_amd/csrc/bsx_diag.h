@@ -45,6 +45,12 @@ constexpr bool X_CORNERS_ALL = false;
 #endif
 constexpr int X_DEPHASE = BSX_X_DEPHASE;
 
+// -DBSX_X_MIN_WAVES=<k>: the per-step kernels of teams >= 2 are compiled for at least k waves per SIMD (same results)
+#ifndef BSX_X_MIN_WAVES
+#define BSX_X_MIN_WAVES 1
+#endif
+constexpr int X_MIN_WAVES = BSX_X_MIN_WAVES;
+
 #ifdef BSX_STAMPS
 constexpr int BUILD_FLAGS = int(DIAG & 0xFFu) | 0x100;
 __device__ unsigned long long* g_stamps = nullptr;

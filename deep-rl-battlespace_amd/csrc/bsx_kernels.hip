@@ -14,12 +14,14 @@
 //     independent loads go out in one batch as raw 16-byte words (clamped indices, no per-lane branches); the dependent loads
 //     (heading-table entry, bullet entries) are covered by the shot's Philox + sincos and the fp64 observation math; predicates
 //     are integer sign masks, not SGPR lane masks.
-//   * an agent's bullets are a dense creation-ordered list (row j = j-th bullet of every agent) of 8-byte entries: position and
-//     age in one word, the per-update step as an INTEGER code in the other (written once by the shot; exactly the reference's
-//     float64 add-then-truncate, see step_code).  For team sizes 1 .. 4 the bullets of ALL lanes of a wave are updated in WORK
-//     SLOTS packed across the wavefront (entry-major, so a round's lanes read and write along rows): under sparse play one
-//     round of 64 slots instead of ~7 mostly-empty per-lane rounds; the outcome returns to the owner through one LDS add per
-//     slot, survivors are stored straight to their compacted position (4 bytes in place, 8 when the entry moves).
+//   * bullets live in one POOL per wave block (the 64 lanes a wavefront owns): a dense, unordered array of 8-byte entries -- position,
+//     age and owner lane in one word, the per-update step as an INTEGER code in the other (written once by the shot; exactly the
+//     reference's float64 add-then-truncate, see step_code).  The wave reads its pool with fully coalesced loads, the first 64 entries
+//     in the first batch of loads (nothing on the common path waits for a dependent load but the heading-table entry), updates the
+//     bullets of ALL its lanes in WORK SLOTS (slot = pool entry; this call's shots queue up behind them) -- under sparse play one round
+//     of 64 slots -- and writes the survivors back compacted by a wave-wide prefix count.  What a slot needs from its bullet's owner is
+//     staged per lane in LDS; the outcome returns to the owner through one LDS add per bullet that ended.  The order in which the
+//     reference resolves plane hits (creation order) is the bullets' AGE, which the entries carry.
 //   * post-move plane poses and hit points are handed to the other planes of the game by cross-lane moves (1v1) or wave-private
 //     LDS (larger teams); the all-pairs range / angle-off geometry of a team pair is computed once per pair; observation rows
 //     leave straight from registers with the non-temporal hint (the fused rollout keeps them in LDS for the actor's MFMAs).
@@ -49,6 +51,7 @@ constexpr int BUILD_FLAGS = 0;
 constexpr int OBS_FORM = 0;
 constexpr bool X_CHEAP_ALL = false, X_CORNERS_ALL = false;
 constexpr int X_DEPHASE = 0;
+constexpr int X_MIN_WAVES = 1;
 #define STAMP(i) do { } while (0)
 #define FSTAMP(i) do { } while (0)
 #define PSTAMP(i) do { } while (0)
@@ -67,9 +70,6 @@ constexpr int WPB = 1;     // wavefronts per workgroup of the per-step / multi-t
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 template <class T> __device__ inline void out_store(T* p, T v) { __builtin_nontemporal_store(v, p); }
 
-// Bullets are updated in WORK SLOTS packed across the wavefront (see "wave-packed bullet pass" in the step kernel) for the
-// compile-time team sizes 1..4 (PACK_BULLETS; the runtime-n kernel keeps the per-lane item walk, which a variant build can select
-// for every team size).
 #define BSX_LDS(T, arr) ((__attribute__((address_space(3))) T*)(uintptr_t)(arr))
 
 // The per-step kernel's STATE stores (plane / game records, bullet entries) can leave non-temporal as well -- the next launch
@@ -334,9 +334,10 @@ __device__ inline uint32_t rotl12(uint32_t v, int s) {  // rotate a 12-bit mask 
 __device__ inline int sx16(uint32_t w) { return int(int16_t(w & 0xFFFFu)); }
 __device__ inline int sy16(uint32_t w) { return int(int16_t(w >> 16)); }
 __device__ inline uint32_t pack_xy(int x, int y) { return (uint32_t(x) & 0xFFFFu) | (uint32_t(y) << 16); }
-// Bullet list entry, two words.  .x = x (11 bits) | age << 11 (4 bits: updates so far, 15 = tombstone) | exact-path flag << 15 |
-// y << 16: a stored bullet is inside the field (0..1200, 0..800), and the two coordinates sit in the two 16-bit halves so that the
-// move and every rectangle test below work on both at once (v_pk_*_i16).  .y = the per-update step as two signed 16-bit halves.
+// Pool entry, two words.  .x = x (11 bits) | age << 11 (4 bits: updates so far, 15 = tombstone) | exact-path flag << 15 |
+// y << 16 (10 bits) | owner lane << 26: a stored bullet is inside the field (0..1200, 0..800), and the two coordinates sit in the two
+// 16-bit halves so that the move and every rectangle test below work on both at once (v_pk_*_i16).  .y = the per-update step as two
+// signed 16-bit halves.
 constexpr uint32_t TOMBSTONE_AGE = 15;
 constexpr uint32_t ENT_XY = 0x03FF07FFu, ENT_AGE = 0x7800u, ENT_EXACT = 0x8000u;
 constexpr int ENT_OWNER_SHIFT = 26;                     // bits 26..31: the owner's lane in its wave block
@@ -362,7 +363,7 @@ __device__ inline int pk_any_negative(uint32_t t) { return int(t | (t << 16)) >>
 // The shot decides in float32, with a wider guard: |float(d) - d| <= 2^-19 for |d| < 64, so a float32 fraction in
 // [2^-17, 1 - 2^-17] puts d itself at least 2^-18 from every integer -- floor(float(d)) is floor(d) and r is far inside the band.
 // The flag is then set for one shot in ~30 000 (and for headings on an axis: scripted tests); the float64 path it selects is a
-// 16-byte load and two adds behind a branch that a wave takes only if one of its agents says it owns such a bullet (PlaneRec.xf).
+// 16-byte load and two adds behind a branch that a wave takes only if one of the entries it is about to update carries the flag.
 constexpr float STEP_GUARD = 0x1p-17f;
 __device__ inline uint32_t step_code(double dx, double dy, bool& exact) {
     const float dxf = float(dx), dyf = float(dy);
@@ -567,7 +568,7 @@ template <class T> __device__ inline T* elem(T* base, uint32_t i) {
 }
 template <class T> __device__ inline T* elem(T* base, size_t i) { return base + i; }
 template <int N, bool CONT, bool MULTI, bool ACTOR = false, bool LG = false, bool OFF32 = false>
-__global__ __launch_bounds__(SPB * (ACTOR ? group_width(N > 0 ? N : 1) / 2 : WPB)) __attribute__((amdgpu_waves_per_eu((ACTOR && N > 1) ? 2 : 1)))
+__global__ __launch_bounds__(SPB * (ACTOR ? group_width(N > 0 ? N : 1) / 2 : WPB)) __attribute__((amdgpu_waves_per_eu((ACTOR && N > 1) ? 2 : ((!ACTOR && !MULTI && N >= 2) ? X_MIN_WAVES : 1))))
 void bsx_step_kernel(const int64_t E_, const uint2* const envc_, const uint2* const envd_, const uint2* const plane_, const void* const act_,
                      const uint2* const bent_, const uint32_t* const bcnt_, const int kind_, const StepArgs p_) {
     const StepArgs& p = p_;                              // (the tick loop of the multi-tick forms shadows this name: see there)

@@ -257,6 +257,16 @@ class PolicyRollout:
         # chains > 1 (graph form, fused actor, no scripted opponent): the games as that many ranges, each its own chain of
         # (actor -> step) launch pairs on a branch of the graph (battle_env.capture_steps(chains=)): one range's matrix-core actor
         # pass runs under another range's step kernel.  Same transitions bit for bit.
+        # one_launch beyond 4v4 (an MFMA tile per plane id and a workgroup of 32 games stop fitting: the fused kernels exist for 1v1 ... 4v4):
+        # the rollout falls through to the graph of (actor -> step) pairs, as chains over game ranges where those pay -- the same
+        # transitions; `form_note` says so
+        self.form_note = None
+        if one_launch and fused and env.n_agents > 4:
+            one_launch = False
+            if chains == 1 and opponent is None:
+                chains = "auto"
+            self.form_note = (f"one_launch asked for {env.n_agents}v{env.n_agents}: the fused kernels cover 1v1 ... 4v4, "
+                              "this rollout runs as the two-kernel graph (chains over game ranges where they pay)")
         if chains == "auto":                           # two chains where they were measured to pay: 2v2 and larger, from ~260 k agents per tick
             chains = 2 if (env.n_agents >= 2 and env.n_envs * 2 * env.n_agents >= (1 << 18) and not one_launch and fused and opponent is None) else 1
         self.chains = int(chains)

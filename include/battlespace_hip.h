@@ -72,7 +72,9 @@ int bsx_build_flags(void);
 
 /* Size in bytes of the opaque per-job state block for E envs of n-per-team (256-byte aligned base required).
  * Holds what parallel_env holds between calls (battle_env.py:165-184,254-276): planes, bases, bullets, time, flags,
- * win/tie counters, plus the 361-entry discrete-heading displacement table. */
+ * win/tie counters, plus the 361-entry discrete-heading displacement table.  Layout (ABI 14): 8-byte plane and game records, the
+ * base positions in an array of their own, and one dense bullet pool per block of 64 lanes (= 64 / G games, G = the next power of two
+ * >= 2n): what a step() moves is what the game holds, not the 12 bullet slots per plane the reference's objects reserve. */
 int bsx_state_bytes(int64_t E, int n, size_t* bytes);
 
 /* One-time initialisation of a state block: zeroes it and uploads the heading table
@@ -101,7 +103,11 @@ int bsx_step_discrete(void* state, int64_t E, int n, const void* actions, int ac
                       float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner,
                       const BsxRewards* cfg, uint32_t flags, uint64_t seed, int64_t env_offset, void* stream);
 
-/* parallel_env.step, continuous actions (battle_env.py:295-297, :418-424). */
+/* parallel_env.step, continuous actions (battle_env.py:295-297, :418-424).
+ * A state block belongs to ONE action mode for its life, as a parallel_env does (battle_env.py:73 `continuous_actions`): the discrete
+ * kernels keep headings as whole degrees inside the 8-byte plane record (reset spawns and the 15-degree turns are whole degrees), the
+ * continuous kernels keep them as float64 beside it.  bsx_reset may be followed by either family; stepping a state the other family
+ * has advanced is undefined (it reads the heading truncated to whole degrees). */
 int bsx_step_continuous(void* state, int64_t E, int n, const void* actions, int action_kind, const double* u,
                         float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner,
                         const BsxRewards* cfg, uint32_t flags, uint64_t seed, int64_t env_offset, void* stream);

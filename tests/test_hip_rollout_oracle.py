@@ -462,6 +462,34 @@ def test_chained_rollout_records_the_same_transitions(n, cont, chains, heads):
     assert PolicyRollout(one.env, actor, T, chains="auto").chains == 1 and PolicyRollout(one.env, actor, T, chains="auto", one_launch=n <= 4).chains == 1   # a batch this small: one chain
 
 
+@pytest.mark.parametrize("n", [6, 8])
+def test_one_launch_beyond_4v4_falls_through_to_the_graph(n):
+    """f-1 beyond 4v4 (main.py:177-181 with larger teams): the fused one-launch kernels cover 1v1 ... 4v4; asked for more,
+    PolicyRollout(one_launch=True) runs the two-kernel graph instead of refusing, says so in `form_note`, and plays exactly the
+    transitions of the graph form asked for directly."""
+    from deep_rl_battlespace_amd.rollout import PolicyRollout, StackedActor
+    E, T = 1100, 24
+    torch.manual_seed(21)
+    actor = StackedActor(2 * n, 3 * n + 2, 4, device="cuda")
+    with torch.no_grad():
+        actor.w3.mul_(80.0)
+    ros = []
+    for one in (True, False):
+        env = _env(n_agents=n, n_envs=E, seed=9, auto_reset=True); env.reset()
+        ro = PolicyRollout(env, actor, T, seed=4, noise_std=0.3, one_launch=one); ro.start(); ro.capture()
+        ros.append(ro)
+    a, b = ros
+    assert a.one_launch is False and "two-kernel graph" in a.form_note and b.form_note is None
+    for rep in range(13):                                   # past the time-limit ties (221 / 261 ticks at 6v6 / 8v8) and the re-spawns behind them
+        a.run(); b.run()
+        torch.cuda.synchronize()
+        for name in ("obs", "scores", "rew", "done", "env_done"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (name, rep)
+    sa, sb = a.env.export_state(), b.env.export_state()
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)
+    assert int(a.env.counters()[:, 0].sum()) >= E
+
+
 def test_exported_game_state_renders_what_the_oracle_holds(tmp_path):
     """f-4 (battle_env.py:498-560 draws planes, bases and bullets of ONE game): the state block of a running batch is exported,
     one game of it equals the oracle's game field by field, and its host-side image shows every live sprite where the state
