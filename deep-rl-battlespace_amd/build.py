@@ -34,8 +34,9 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [src for src, _ in SOURCES] + [os.path.join(CSRC, "bsx_actor_core.h"), os.path.join(INCLUDE, "battlespace_hip.h"),
-                                          os.path.abspath(__file__)]
+    import glob
+    deps = [src for src, _ in SOURCES] + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inl")) + \
+        [os.path.join(INCLUDE, "battlespace_hip.h"), os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

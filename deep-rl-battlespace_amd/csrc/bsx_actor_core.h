@@ -46,7 +46,9 @@ __device__ inline uint4 philox4x32_10(uint4 ctr, uint2 key) {
         // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a mul_hi + mul_lo pair: both are quarter rate
         const uint64_t p0 = uint64_t(0xD2511F53u) * ctr.x, p1 = uint64_t(0xCD9E8D57u) * ctr.z;
         const uint32_t hi0 = uint32_t(p0 >> 32), lo0 = uint32_t(p0), hi1 = uint32_t(p1 >> 32), lo1 = uint32_t(p1);
-        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+        // (the three-input XORs as ONE v_bitop3_b32 each: left to itself the compiler issues two v_xor_b32 -- 20 vector instructions
+        //  per block where the instruction count is what the step is bound by)
+        ctr = make_uint4(__builtin_amdgcn_bitop3_b32(hi1, ctr.y, key.x, 0x96), lo1, __builtin_amdgcn_bitop3_b32(hi0, ctr.w, key.y, 0x96), lo0);
         key.x += 0x9E3779B9u; key.y += 0xBB67AE85u;
     }
     return ctr;

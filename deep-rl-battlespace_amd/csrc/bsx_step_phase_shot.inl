@@ -1,0 +1,99 @@
+// bsx_step_phase_shot.inl -- a PHASE of bsx_step_kernel's tick (bsx_step_kernel.h includes it inside the kernel body, in tick order; it shares the
+// kernel's locals, so this is a textual unit for reading and review, not a function): heading-table gather, call classification (inert / auto-reset / tie / physics), the shot (Bullet.__init__, sprites.py:293-318) and part 1 of
+// the wave-packed bullet pass (shots queued in LDS behind the pool).  Reads: the T0 records (x, y, hp, dir, er, games, act / a0..a2, pc).  Writes: mode,
+// tick, spawn, phys, ks, dl, dir_rot, slots, pool_pass, shot_exact, nd / nbdir / ncode / nexact, s_agg, s_eb, s_fl, s_new, bdir ring.
+    // ================= T1: the heading-table entry -- the one dependent load of the common path =====================
+    // The heading table (361 x 16 B, read by every wave of every launch) stays hot in each CU's L1: the entry for the
+    // post-rotation heading is gathered as soon as the action is known, so the plane can move while the shot is prepared.
+    double dir_rot = dir;
+    if (!CONT) dir_rot = rotate_dir(dir, act == 2 ? 15.0 : (act == 3 ? -15.0 : 0.0));   // one straight-line rotate (+0 leaves any heading in [0, 360] as it is)
+    double2 dl = make_double2(0.0, 0.0);
+    if (!CONT) dl = p.st.lut[min(max(int(dir_rot), 0), 360)];   // 21.5*cos(-radians(d)), 21.5*sin(-radians(d)) from host libm
+    if (MULTI && !ACTOR && tk + 1 < p.T) load_inputs(tk + 1, rin_next);   // behind this tick's own loads: nothing waits for it before the tick ends
+    const bool alive0 = valid && hp > 0;
+    STAMP(1);
+
+    // "no agents left" (battle_env.py:309): group ballot over the alive flags
+    const unsigned long long bal = __ballot(alive0);
+    const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << (lane & ~(G - 1)));
+    const bool any_alive = (bal & gmask) != 0ull;
+
+    // ---- what kind of call is this for my env (battle_env.py:303-323)
+    int mode;
+    int tick = er.tick;
+    if (er.done) mode = (p.flags & BSX_F_AUTO_RESET) ? M_RESET : M_INERT;
+    else if ((p.flags & BSX_F_EMPTY_CALL) || !any_alive) mode = M_TIE;
+    else {
+        tick += 1;
+        mode = (tick >= tie_tick) ? M_TIE : M_PHYS;
+    }
+    if (!env_ok) mode = M_INERT;
+
+    int4 cnt_delta = make_int4(0, 0, 0, 0);              // games, ties, red wins, blue wins
+    const double d0 = dir;
+    const int64_t genv = env_offset_t + ec;
+    // does this call fire? (battle_env.py:404-406 / :423; the shot leaves from the PRE-move pose, so it is prepared first:
+    // its Philox draw and sincos run while the heading-table entry of the move below is still on its way from the L2)
+    if (CONT) a2 = fmin(fmax(a2, -1.0), 1.0);
+    bool spawn = (mode == M_PHYS) && alive0 && !(DIAG & 2u) && (CONT ? (a2 > 0.0) : (act == 1));
+    // ---- Bullet.__init__ (sprites.py:293-318) for this call's shot: heading = pre-move heading + (u*8 - 4)
+    const bool phys = (mode == M_PHYS) && valid && !(DIAG & 2u);
+    const int ks = tick % K;                             // birth-tick ring slot of this call's shot (heading, export only)
+    // ---- wave-packed bullet pass, part 1.  The wave's bullets ARE a packed array -- its pool, pc entries in memory -- and this call's
+    // shots queue up behind them in LDS by shot rank: slot w < pc is pool entry w, slot pc + r the r-th shooter's new bullet; slot w is
+    // served by lane w % 64 in round w / 64.  Under uniform play a plane holds 0.6 bullets and fires every fourth call: ~37 + 16 slots,
+    // ONE round.  What a slot needs from its bullet's owner (named by the entry) is staged per owner lane in LDS.
+    FSTAMP(3);
+    const unsigned long long shb = __ballot(spawn);
+    const int srank = int(__builtin_amdgcn_mbcnt_hi(uint32_t(shb >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(shb), 0u)));
+    const int slots = int(pc) + __popcll(shb);           // wave-uniform
+    s_agg[tid] = 0u;
+    s_eb[tid] = make_rect(pack_xy(team == 0 ? er.bbx : er.brx, team == 0 ? er.bby : er.bry), true, 33, 32, 33, 31);
+    s_fl[tid] = uint32_t(ks) | (phys ? OWN_PHYS : 0u) | ((mode == M_RESET && valid) ? OWN_DROP : 0u);
+    // does this call touch the pool at all?  (not if no game of the wave is in its physics call or being re-spawned: entries stay as they are)
+    const bool pool_pass = __any(phys || (mode == M_RESET && valid));
+    FSTAMP(4);
+    FSTAMP(5);
+    // 1v1 discrete: the shot's step from the heading table by angle addition instead of a float64 sincos (below).  Larger teams keep
+    // the sincos: there the shorter shot measured SLOWER (4v4 23.3 -> 25.3 us, two runs each) -- the table entry it needs arrives
+    // later than the ~110 instructions of the sincos take, and nothing else is left to cover it.
+    constexpr bool CHEAP_SHOT = !CONT && (N == 1 || (X_CHEAP_ALL && N > 0));
+    double2 nd = make_double2(0.0, 0.0);                 // this call's shot: float64 step (CHEAP_SHOT: to ~1e-8 unless flagged exact), step code, heading
+    double nbdir = 0.0;
+    uint32_t ncode = 0u;
+    bool nexact = false;
+    if (spawn) {
+        double uu = uu_in;
+        if (!u_t && !(DIAG & 8u)) {
+            const uint4 r = draw4(seed_t, genv, STREAM_JITTER, games, (uint32_t(tick) << 8) | uint32_t(a));
+            uu = uniform53(r.x, r.y);
+        }
+        const double jit = uu * 8.0 - 4.0;
+        nbdir = d0 + jit;
+        if constexpr (CHEAP_SHOT) {
+            // Discrete headings are whole degrees and a shooter does not turn, so (21.5 cos d0, -21.5 sin d0) is the heading-table
+            // entry `dl` this lane gathered for its move; the jitter is at most 4 degrees.  The integer step code only needs the
+            // step to ~2^-18 (step_code's guard is wider than any error here), so the common path takes it from the angle-addition
+            // formulas with two-term series for the jitter -- |error| < 1e-8 on 45 cos -- instead of a float64 sincos of ~110
+            // instructions.  A shot the code flags as not provably exact (one in ~30 000) gets the library sincos below, behind the
+            // wave-uniform branch of the exact path; every other shot's integer moves are those of the exact step (same floor, the
+            // fraction far from 0 and 1), so the results do not change.
+            const double jr = jit * DEG2RAD, t = jr * jr;
+            const double cj = __builtin_fma(t, __builtin_fma(t, 1.0 / 24.0, -0.5), 1.0);
+            const double sj = jr * __builtin_fma(t, __builtin_fma(t, 1.0 / 120.0, -1.0 / 6.0), 1.0);
+            constexpr double K45 = BULLET_STEP / 21.5;
+            nd = make_double2(K45 * __builtin_fma(dl.x, cj, dl.y * sj), K45 * __builtin_fma(dl.y, cj, -(dl.x * sj)));
+        } else {
+            double sn, cs;
+            sincos(-(nbdir * DEG2RAD), &sn, &cs);
+            nd = make_double2(BULLET_STEP * cs, BULLET_STEP * sn);
+        }
+        ncode = step_code(nd.x, nd.y, nexact);
+        st_store<NT_STATE>(elem(p.st.bdir, ix_t(ks) * EAt + gt), nbdir);      // ring by birth tick: never moves, read only by bsx_export_state
+        // the shot as a pool entry, queued by shot rank: age 0, the PRE-move pose, my lane as its owner
+        s_new[srank] = u32x2{pack_bullet(x, y, 0) | (nexact ? ENT_EXACT : 0u) | (uint32_t(lane) << ENT_OWNER_SHIFT), ncode};
+    }
+    // rare (step_code): a shot that moves by the float64 sum.  Asked once per wave, here, long before anything branches on it
+    const bool shot_exact = __any(spawn && nexact);
+    FSTAMP(6);
+
