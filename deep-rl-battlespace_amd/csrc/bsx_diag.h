@@ -50,6 +50,11 @@ constexpr int X_DEPHASE = BSX_X_DEPHASE;
 #define BSX_X_MIN_WAVES 1
 #endif
 constexpr int X_MIN_WAVES = BSX_X_MIN_WAVES;
+// -DBSX_X_OBS_PLAIN_FROM=<n>: the observation rows of teams >= n leave as ordinary stores instead of non-temporal ones (same results)
+#ifndef BSX_X_OBS_PLAIN_FROM
+#define BSX_X_OBS_PLAIN_FROM 99
+#endif
+constexpr int X_OBS_PLAIN_FROM = BSX_X_OBS_PLAIN_FROM;
 
 #ifdef BSX_STAMPS
 constexpr int BUILD_FLAGS = int(DIAG & 0xFFu) | 0x100;

@@ -52,6 +52,7 @@ constexpr int OBS_FORM = 0;
 constexpr bool X_CHEAP_ALL = false, X_CORNERS_ALL = false;
 constexpr int X_DEPHASE = 0;
 constexpr int X_MIN_WAVES = 1;
+constexpr int X_OBS_PLAIN_FROM = 99;
 #define STAMP(i) do { } while (0)
 #define FSTAMP(i) do { } while (0)
 #define PSTAMP(i) do { } while (0)
@@ -95,16 +96,24 @@ __global__ __launch_bounds__(TPB) void bsx_reset_kernel(const ResetArgs p) {
         if (frac) dir = p.st.pdirf[g];
     }
     const bool doit = env_ok && !p.observe_only && (!p.mask || p.mask[e]);
-    if (doit) {
-        const int64_t genv = p.env_offset + e;
-        if (p.spawn) {
+    if (p.spawn) {                                           // injected spawn states
+        if (doit) {
             const int32_t* s = p.spawn + size_t(e) * (4 + 3 * A);
             er.brx = s[0]; er.bry = s[1]; er.bbx = s[2]; er.bby = s[3];
             if (valid) { x = s[4 + 3 * a]; y = s[5 + 3 * a]; dir = double(s[6 + 3 * a]); }
-        } else {
-            spawn_bases(p.seed, genv, STREAM_RESET, uint32_t(p.nonce), er);
-            if (valid) spawn_plane(p.seed, genv, STREAM_RESET, uint32_t(p.nonce), a, n, x, y, dir);
         }
+    } else if (!p.observe_only) {                            // Philox spawns: one block per plane, the two bases handed round the game's lanes
+        const int64_t genv = p.env_offset + (env_ok ? e : p.E - 1);
+        const int ac = a < A ? a : A - 1;
+        const SpawnDraw sd = spawn_from_words(draw4(p.seed, genv, STREAM_RESET, uint32_t(p.nonce), uint32_t(ac)), ac, n);
+        const int lane0 = (tid & 63) & ~(G - 1);             // (every lane takes part in the exchange; only the games being reset use it)
+        const int rbx = __shfl(sd.bx, lane0), rby = __shfl(sd.by, lane0), bbx = __shfl(sd.bx, lane0 + n), bby = __shfl(sd.by, lane0 + n);
+        if (doit) {
+            er.brx = rbx; er.bry = rby; er.bbx = bbx; er.bby = bby;
+            if (valid) { x = sd.x; y = sd.y; dir = double(sd.dir); }
+        }
+    }
+    if (doit) {
         er.bhp_r = er.bhp_b = 5 * n;
         er.tick = 0; er.done = 0; er.winner = BSX_WINNER_NONE;
         hp = PLANE_HP; frac = false;                         // spawn headings are whole degrees (sprites.py:85,91; injected spawns are int32)

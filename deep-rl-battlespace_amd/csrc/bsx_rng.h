@@ -19,27 +19,25 @@ __device__ inline double uniform53(uint32_t a, uint32_t b) {
     return (double(a >> 5) * 67108864.0 + double(b >> 6)) * (1.0 / 9007199254740992.0);
 }
 
-// Spawn draws (sprites.py:74-91,238-252).  Every lane of an env computes the same base draws.
-template <class ENV>
-__device__ inline void spawn_bases(uint64_t seed, int64_t genv, uint32_t stream, uint32_t seq, ENV& er) {
-    const uint4 r = draw4(seed, genv, stream, seq, 0xFFFFu);
-    er.brx = randint(r.x, 62, 379);     // randint(w, (W-w)//3)
-    er.bry = randint(r.y, 62, 738);
-    er.bbx = randint(r.z, 758, 1138);   // randint((W-w)//3*2, W-w)
-    er.bby = randint(r.w, 62, 738);
-}
-__device__ inline void spawn_plane(uint64_t seed, int64_t genv, uint32_t stream, uint32_t seq, int a, int n,
-                                   int& x, int& y, double& dir) {
-    const uint4 r = draw4(seed, genv, stream, seq, uint32_t(a));
-    if (a < n) {
-        x = randint(r.x, 50, 383); y = randint(r.y, 48, 752);
-        int d = randint(r.z, 270, 450);
-        if (d >= 360) d -= 360;
-        dir = double(d);
-    } else {
-        x = randint(r.x, 766, 1150); y = randint(r.y, 48, 752);
-        dir = double(randint(r.z, 90, 270));
-    }
+// Spawn draws (sprites.py:74-91,238-252): ONE Philox block per plane -- counter (stream, episode, who = plane id) -- yields the plane's pose
+// and, for the first plane of each team, its team's base; the game's lanes then exchange the two base positions.  x and the heading come
+// from one word as a mixed-radix pair (the product's high word, then the low word scaled again: together one multiply-shift onto range x 181
+// cells, bias < 2e-5), y and the base coordinates from a word each, all inclusive ranges as the reference draws them:
+//   red plane   x randint(50, 383)   y randint(48, 752)   heading randint(270, 450) - 360 if >= 360      (sprites.py:82-87)
+//   blue plane  x randint(766, 1150) y randint(48, 752)   heading randint(90, 270)                       (sprites.py:88-91)
+//   red base    x randint(62, 379)   y randint(62, 738);   blue base  x randint(758, 1138)  y randint(62, 738)   (sprites.py:246-252)
+struct SpawnDraw { int x, y, dir, bx, by; };
+__device__ inline SpawnDraw spawn_from_words(const uint4 r, int a, int n) {
+    const bool red = a < n;
+    const uint64_t p = uint64_t(r.x) * uint32_t(red ? 334 : 385);
+    SpawnDraw s;
+    s.x = (red ? 50 : 766) + int(uint32_t(p >> 32));
+    int d = (red ? 270 : 90) + int(__umulhi(uint32_t(p), 181u));
+    s.dir = d >= 360 ? d - 360 : d;
+    s.y = 48 + int(__umulhi(r.y, 705u));
+    s.bx = (red ? 62 : 758) + int(__umulhi(r.z, red ? 318u : 381u));
+    s.by = 62 + int(__umulhi(r.w, 677u));
+    return s;
 }
 
 }  // namespace

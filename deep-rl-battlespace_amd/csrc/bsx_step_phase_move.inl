@@ -4,12 +4,21 @@
 // nx_, ny_, nhp_ (1v1), s_x, s_y, s_hp, s_bhit, s_pq.
     STAMP(2);
     if (mode == M_RESET) {
-        // re-spawn in place of the inert call; episode id = games played so far
-        spawn_bases(seed_t, genv, STREAM_AUTORESET, games, er);
+        // re-spawn in place of the inert call; episode id = games played so far.  My block holds my pose and (first plane of a team) my
+        // team's base; the two bases travel to every lane of the game (all lanes of a game are here together)
+        const SpawnDraw sd = spawn_from_words(rw, a < A ? a : A - 1, n);
+        if constexpr (N == 1) {
+            const int ox = lane_xor1(sd.bx), oy = lane_xor1(sd.by);
+            er.brx = team == 0 ? sd.bx : ox; er.bry = team == 0 ? sd.by : oy;
+            er.bbx = team == 0 ? ox : sd.bx; er.bby = team == 0 ? oy : sd.by;
+        } else {
+            er.brx = __shfl(sd.bx, gl); er.bry = __shfl(sd.by, gl);
+            er.bbx = __shfl(sd.bx, gl + n); er.bby = __shfl(sd.by, gl + n);
+        }
         er.bhp_r = er.bhp_b = 5 * n;
         er.tick = 0; er.done = 0; er.winner = BSX_WINNER_NONE;
         tick = 0;
-        spawn_plane(seed_t, genv, STREAM_AUTORESET, games, a < A ? a : A - 1, n, x, y, dir);
+        x = sd.x; y = sd.y; dir = double(sd.dir);
         hp = PLANE_HP;
     } else if (mode == M_PHYS && alive0) {
         // ---- process_action (battle_env.py:383-424)

@@ -62,12 +62,16 @@
     double nbdir = 0.0;
     uint32_t ncode = 0u;
     bool nexact = false;
+    // ONE Philox block per lane and call serves whichever of the two a lane needs -- they exclude each other: the jitter of this call's shot
+    // (stream JITTER, counter (episode, tick | plane)), or the pose of a plane whose game this call re-spawns (stream AUTORESET, counter
+    // (episode, plane); the first plane of each team also draws its base)
+    const bool respawn = mode == M_RESET;
+    uint4 rw = make_uint4(0u, 0u, 0u, 0u);
+    if ((spawn && !u_t && !(DIAG & 8u)) || respawn)
+        rw = draw4(seed_t, genv, respawn ? STREAM_AUTORESET : STREAM_JITTER, games, respawn ? uint32_t(a < A ? a : A - 1) : ((uint32_t(tick) << 8) | uint32_t(a)));
     if (spawn) {
         double uu = uu_in;
-        if (!u_t && !(DIAG & 8u)) {
-            const uint4 r = draw4(seed_t, genv, STREAM_JITTER, games, (uint32_t(tick) << 8) | uint32_t(a));
-            uu = uniform53(r.x, r.y);
-        }
+        if (!u_t && !(DIAG & 8u)) uu = uniform53(rw.x, rw.y);
         const double jit = uu * 8.0 - 4.0;
         nbdir = d0 + jit;
         if constexpr (CHEAP_SHOT) {

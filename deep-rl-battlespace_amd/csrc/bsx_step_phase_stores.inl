@@ -34,11 +34,12 @@
         }
         if (valid) {
             float* out = elem(obs_t, gt * ix_t(D));
+            auto row_store = [](auto* q, auto v) { if constexpr (N >= X_OBS_PLAIN_FROM) *q = v; else out_store(q, v); };
 #pragma unroll
-            for (int i = 0; i + 4 <= D; i += 4) out_store(reinterpret_cast<v4f_t*>(out + i), v4f_t{row[i], row[i + 1], row[i + 2], row[i + 3]});
+            for (int i = 0; i + 4 <= D; i += 4) row_store(reinterpret_cast<v4f_t*>(out + i), v4f_t{row[i], row[i + 1], row[i + 2], row[i + 3]});
             typedef float v2f_t __attribute__((ext_vector_type(2)));
-            if constexpr ((D & 3) >= 2) out_store(reinterpret_cast<v2f_t*>(out + (D & ~3)), v2f_t{row[D & ~3], row[(D & ~3) + 1]});
-            if constexpr ((D & 1) != 0) out_store(out + D - 1, row[D - 1]);
+            if constexpr ((D & 3) >= 2) row_store(reinterpret_cast<v2f_t*>(out + (D & ~3)), v2f_t{row[D & ~3], row[(D & ~3) + 1]});
+            if constexpr ((D & 1) != 0) row_store(out + D - 1, row[D - 1]);
         }
     } else
     {
