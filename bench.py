@@ -73,14 +73,15 @@ def b_io(n, continuous=False):
 
 
 def b_live(n, live, shots, continuous=False):
-    """What THIS build's layout has to move per agent-step when an agent holds `live` bullets and fires `shots` per call (the
-    contract formula b_alg charges all 12 slots of a canonical layout, however few are in flight): read plane 13 + game record
-    13/A + list length 2 + action 4 + 8 per live bullet (its 8-byte list entry: position, age, integer step code); written plane
-    13 + game record 5/A + 4 per live bullet (its position word) + 16 per shot (the new entry and its heading in the export ring) +
-    the outputs the API mandates (observation row, reward, done).  Compaction moves (a further 4 bytes per entry behind a bullet
-    that died) are not counted."""
+    """What THIS build's layout (v2, ABI 14) has to move per agent-step when an agent holds `live` bullets and fires `shots` per call (the
+    contract formula b_alg charges all 12 slots of a canonical layout, however few are in flight): read plane record 8 (+ 8: the float64
+    heading, continuous) + the game's two records 16/A + action 4 + 8 per live bullet (its pool entry: position, age, owner, integer
+    step code); written plane 8 (+ 8) + the game's dynamic record 8/A + 8 per surviving bullet (entries are rewritten whole, compacted)
+    + 8 per shot (its heading in the export ring) + the outputs the API mandates (observation row, reward, done).  Not counted: the
+    first 64 pool entries of a wave are read whether or not they exist (512 bytes per wave = 8 per agent at most)."""
     A = 2 * n
-    return (13 + 13 / A + 2 + 4 + 8 * live) + (13 + 5 / A + 4 * live + 16 * shots) + (4 * (3 * n + 2) + 4 + 1) + (8 if continuous else 0)
+    c = 8 if continuous else 0
+    return (8 + c + 16 / A + 4 + 8 * live) + (8 + c + 8 / A + 8 * live + 8 * shots) + (4 * (3 * n + 2) + 4 + 1) + c
 
 
 def claim(frac, frac_on_traffic):
