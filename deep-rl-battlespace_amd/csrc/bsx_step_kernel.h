@@ -99,8 +99,10 @@ template <class T> __device__ inline T* elem(T* base, uint32_t i) {
     return reinterpret_cast<T*>(reinterpret_cast<byte_t*>(base) + uint32_t(i * uint32_t(sizeof(T))));
 }
 template <class T> __device__ inline T* elem(T* base, size_t i) { return base + i; }
+// (the multi-tick 2v2 kernels are compiled for four waves per SIMD: 65 536 games are 4 096 of their waves = four per SIMD, and at 129 ... 135
+//  registers -- three resident waves -- the launch ran as two rounds: 6.9 us per tick against 6.2 for round 3's 125-register kernel)
 template <int N, bool CONT, bool MULTI, bool ACTOR = false, bool LG = false, bool OFF32 = false>
-__global__ __launch_bounds__(SPB * (ACTOR ? group_width(N > 0 ? N : 1) / 2 : WPB)) __attribute__((amdgpu_waves_per_eu((ACTOR && N > 1) ? 2 : ((!ACTOR && !MULTI && N >= 2) ? X_MIN_WAVES : 1))))
+__global__ __launch_bounds__(SPB * (ACTOR ? group_width(N > 0 ? N : 1) / 2 : WPB)) __attribute__((amdgpu_waves_per_eu((ACTOR && N > 1) ? 2 : ((!ACTOR && MULTI && N == 2) ? 4 : ((!ACTOR && !MULTI && N >= 2) ? X_MIN_WAVES : 1)))))
 void bsx_step_kernel(const int64_t E_, const uint2* const envc_, const uint2* const envd_, const uint2* const plane_, const void* const act_,
                      const uint2* const bent_, const uint32_t* const bcnt_, const int kind_, const StepArgs p_) {
     const StepArgs& p = p_;                              // (the tick loop of the multi-tick forms shadows this name: see there)

@@ -34,7 +34,11 @@
         }
         if (valid) {
             float* out = elem(obs_t, gt * ix_t(D));
-            auto row_store = [](auto* q, auto v) { if constexpr (N >= X_OBS_PLAIN_FROM) *q = v; else out_store(q, v); };
+            // (rows leave non-temporal, except in the multi-tick 4v4 discrete kernel: there ordinary stores -- the L2 merges a row's pieces --
+            //  measured 16.5 ... 16.9 us per tick, stable, against 19 ... 23 with the non-temporal hint; every other kernel is faster or equal
+            //  with the hint, profiles/r04_experiments.json)
+            constexpr bool ROW_PLAIN = N >= X_OBS_PLAIN_FROM || (MULTI && N == 4 && !CONT);
+            auto row_store = [](auto* q, auto v) { if constexpr (ROW_PLAIN) *q = v; else out_store(q, v); };
 #pragma unroll
             for (int i = 0; i + 4 <= D; i += 4) row_store(reinterpret_cast<v4f_t*>(out + i), v4f_t{row[i], row[i + 1], row[i + 2], row[i + 3]});
             typedef float v2f_t __attribute__((ext_vector_type(2)));
