@@ -250,5 +250,5 @@ def test_roofline_claim_and_live_aware_bytes():
     for n in (1, 4):
         lo, hi = bench.b_io(n), bench.b_alg(n)
         assert lo < bench.b_live(n, 0.57, 0.25) < hi
-        assert abs(bench.b_live(n, 1.0, 0.0) - bench.b_live(n, 0.0, 0.0) - 12.0) < 1e-9      # 8 B read + 4 B written per live bullet
+        assert abs(bench.b_live(n, 1.0, 0.0) - bench.b_live(n, 0.0, 0.0) - 16.0) < 1e-9      # layout v2: a pool entry is read and rewritten whole, 8 B each way
     assert abs(bench.b_alg(1) - 260.0) < 1e-9 and abs(bench.b_alg(4) - 289.25) < 1e-9      # (SURVEY.md section 8d rounds it to 289.3)
