@@ -74,6 +74,22 @@ def test_shoot_heavy_play_bit_exact_vs_c_oracle(n):
     _compare_with_c_oracle(4096, n, 190 + 20 * n, seed=5 + n, p_shoot=0.8, check_every=50)
 
 
+@pytest.mark.parametrize("n,G", [(1, 2), (3, 8), (4, 8), (8, 16)])
+def test_bullet_pools_run_over_several_rounds_and_stay_exact(n, G):
+    """Layout v2 keeps a wavefront's bullets as ONE pool (64 / G games): under keep-shooting play a pool holds several times the 64
+    entries of a round, entries move at every compaction, games end and re-spawn next to running ones (their entries are dropped,
+    the neighbours' stay).  The state must equal the C oracle's all the same -- and the test says that it really got there: the
+    fullest pool of the final state spans at least three rounds (five at 1v1)."""
+    E = 2048
+    _compare_with_c_oracle(E, n, 150, seed=40 + n, p_shoot=0.9, check_every=25)              # through deaths, game ends and re-spawns
+    env = _compare_with_c_oracle(E, n, 25, seed=60 + n, p_shoot=0.9, check_every=5)          # ... and the moment the pools are fullest
+    live = env.export_state(("bl_live",))["bl_live"].cpu().numpy().astype(np.int64)          # [E, A, 12]
+    epb = 64 // G
+    per_pool = live.reshape(E // epb, -1).sum(1)
+    assert per_pool.max() > (256 if n == 1 else 128), per_pool.max()
+    assert per_pool.max() <= 64 * 12
+
+
 def test_deterministic_and_shard_invariant():
     """Same seed -> same games; and a job split into shards (env_offset) plays the same games as one batch:
     the in-kernel generator is keyed by the GLOBAL env index (what makes the 8-GPU layout a pure partition)."""
