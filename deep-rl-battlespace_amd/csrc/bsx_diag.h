@@ -7,7 +7,7 @@
 //                       loop, 4 = skip the ordered resolve, 8 = no Philox draw for the shot's jitter, 16 = the per-game counters are not loaded
 //   -DBSX_STAMPS        lane 0 of every wave stores s_memtime at 10 points into a debug buffer (bsx_debug_set_stamps) that nothing
 //                       else reads; a stamped build is for reading SHARES, not run time
-//   -DBSX_STAMPS -DBSX_STAMPS_FINE   stamps 3..6 move INSIDE the shot phase (after the slot table / the Philox draw / sincos / the
+//   -DBSX_STAMPS -DBSX_STAMPS_FINE   stamps 3..6 move INSIDE the shot phase (after the shot ballot / the Philox draw / sincos / the
 //                       first slot fetch); FSTAMP stores from every active lane (it sits in divergent code), the phase stamps 3..6 are off
 //   -DBSX_X_OBS=<0|1|2> the store form of the observation rows (below; same results)
 #pragma once

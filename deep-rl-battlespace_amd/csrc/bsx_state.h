@@ -56,7 +56,7 @@ constexpr double TIME_STEP = 0.1;
 //            in no particular order, at `bent[block * POOL_CAP ...]`; an entry names its owner lane.  The wave reads its pool with
 //            fully coalesced loads whatever the bullets' distribution over the planes (the first 64 entries unconditionally, in the
 //            first batch of loads: no dependent round trip) and writes the survivors back compacted.
-constexpr int POOL_CAP = 64 * BSX_BULLET_SLOTS;   // every lane of a wave block with a full list (11 older bullets + this call's shot)
+constexpr int POOL_CAP = 64 * BSX_BULLET_SLOTS;   // every lane of a wave block holding 11 older bullets + this call's shot
 struct Layout { size_t lut, envc, envd, cnt, plane, pdirf, bcnt, bent, bdir, bd, total; };
 
 __host__ __device__ inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
@@ -133,7 +133,7 @@ __device__ inline int pk_any_negative(uint32_t t) { return int(t | (t << 16)) >>
 // min(r, 1 - r) from an integer and the binary64 sum fl(x + d) is at most 2^-43 away from s (|s| < 2048), so whenever r stays
 // 2^-40 away from 0 and 1 the rounded sum lies strictly between the same two integers n = x + f and n + 1 as s, and int() of it
 // is n for n >= 0 and n + 1 for n < 0 (truncation toward zero: x = 3, d = -3.5 -> 0) -- integer arithmetic, exactly the
-// reference's result.  So the list carries f for both axes (|d| <= 45) and, for the other case, a flag: such a shot also stores its
+// reference's result.  So a pool entry carries f for both axes (|d| <= 45) and, for the other case, a flag: such a shot also stores its
 // float64 step (ring `bd`) and its updates take the float64 sum, as every bullet did before round 3.
 // The shot decides in float32, with a wider guard: |float(d) - d| <= 2^-19 for |d| < 64, so a float32 fraction in
 // [2^-17, 1 - 2^-17] puts d itself at least 2^-18 from every integer -- floor(float(d)) is floor(d) and r is far inside the band.

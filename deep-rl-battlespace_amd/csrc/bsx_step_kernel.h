@@ -236,9 +236,9 @@ void bsx_step_kernel(const int64_t E_, const uint2* const envc_, const uint2* co
         if (ut) r.uu = ut[g];                            // uniform branch
     };
     // MULTI: what one call hands to the next stays in REGISTERS -- my plane, my game's record and episode count (every
-    // lane of a game computes the same record) -- so a later tick starts with its bullet loads instead of a state round
-    // trip, and the inputs of tick t+1 are fetched while tick t computes.  Bullet lists and counters go to memory every
-    // tick, the plane and game records once, after the last one.
+    // lane of a game computes the same record), the pool's length -- so a later tick starts with its pool loads instead of a
+    // state round trip, and the inputs of tick t+1 are fetched while tick t computes.  Pool entries go to memory every tick
+    // (and the win / tie counters at a game's end), the plane and game records and the pool's length once, after the last one.
     int x = 0, y = 0, hp = 0;
     uint32_t games = 0;                                  // games my slot has finished = episode number of the random streams (travels in the game record)
     double dir = 0.0;
@@ -379,10 +379,10 @@ void bsx_step_kernel(const int64_t E_, const uint2* const envc_, const uint2* co
     STAMP(7);
     if (MULTI) {
         games += uint32_t(cnt_delta.x);
-        // The only memory one tick hands to the next is what a LANE stored itself and reloads itself (its bullet rows; the
-        // game counters' read-modify-write) plus this wave's LDS rows.  A wavefront's vector memory operations are performed
-        // in order through the one L1 of its CU, so wavefront scope is enough: a compiler ordering point, no s_waitcnt -- this
-        // tick's stores (observation rows included) drain while the next tick computes.
+        // The only memory one tick hands to the next is this WAVE's own: its pool entries (stored by one lane, loaded by another of the
+        // same wave next tick) plus its LDS rows.  A wavefront's vector memory operations are performed in order through the one L1 of
+        // its CU, whatever the lane, so wavefront scope is enough: a compiler ordering point, no s_waitcnt -- this tick's stores
+        // (observation rows included) drain while the next tick computes.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
