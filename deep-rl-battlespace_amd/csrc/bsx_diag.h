@@ -26,12 +26,7 @@ constexpr unsigned DIAG = BSX_DIAG;
 #endif
 constexpr int OBS_FORM = BSX_X_OBS;
 
-// round 3's 4v4 experiments (same results): the table shot / the corner-form rectangle tests for every team size
-#ifdef BSX_X_CHEAP_ALL
-constexpr bool X_CHEAP_ALL = true;
-#else
-constexpr bool X_CHEAP_ALL = false;
-#endif
+// -DBSX_X_CORNERS_ALL: the corner-form rectangle tests for every team size (the product: 1v1 ... 3v3; same results)
 #ifdef BSX_X_CORNERS_ALL
 constexpr bool X_CORNERS_ALL = true;
 #else

@@ -49,7 +49,7 @@
 constexpr unsigned DIAG = 0;
 constexpr int BUILD_FLAGS = 0;
 constexpr int OBS_FORM = 0;
-constexpr bool X_CHEAP_ALL = false, X_CORNERS_ALL = false;
+constexpr bool X_CORNERS_ALL = false;
 constexpr int X_DEPHASE = 0;
 constexpr int X_MIN_WAVES = 1;
 constexpr int X_OBS_PLAIN_FROM = 99;

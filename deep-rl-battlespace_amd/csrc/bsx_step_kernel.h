@@ -155,9 +155,10 @@ void bsx_step_kernel(const int64_t E_, const uint2* const envc_, const uint2* co
     // 1v1: as (lower corner, upper corner) pairs of packed (x, y) halves BIASED by +64, so that no half is ever negative and the
     // corners are plain 32-bit adds of packed literals: a bullet at b overlaps <=> no half of (b - lower) | (upper - b) is negative
     // (C2 7.33 -> 7.20 us against the centre form: ~15 instructions fewer per round where the instruction count is the bound).
-    // Larger teams: the centre (x | alive << 15 | y << 16) and the margins as constants in the slot -- measured faster there
-    // (4v4 23.1 us against 24.7 with corners; the same launches, four runs each).
-    constexpr bool CORNERS = N == 1 || X_CORNERS_ALL;
+    // 4v4 and the runtime-n kernel: the centre (x | alive << 15 | y << 16) and the margins as constants in the slot -- measured faster there
+    // (round 3: 4v4 23.1 us against 24.7 with corners; round 4, with the table shot: 20.5 against 20.8).  2v2 / 3v3 take the corner form
+    // since round 4 (with the table shot 10.22 -> 9.67 and 17.97 -> 17.05 us; profiles/r04_experiments.json).
+    constexpr bool CORNERS = (N >= 1 && N <= 3) || X_CORNERS_ALL;
     typedef typename std::conditional<CORNERS, u32x2, uint32_t>::type rect_t;
     __shared__ __attribute__((aligned(8))) rect_t s_eb_all[WAVES * SPB];        // per owner: the enemy base, dx in [-33, 33], dy in [-32, 31]
     __shared__ __attribute__((aligned(8))) rect_t s_pq_all[WAVES * SPB];        // per plane: its post-move sprite, dx in [-27, 27], dy in [-25, 24]; dead: never hit

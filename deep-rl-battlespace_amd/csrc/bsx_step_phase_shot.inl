@@ -54,10 +54,12 @@
     const bool pool_pass = __any(phys || (mode == M_RESET && valid));
     FSTAMP(4);
     FSTAMP(5);
-    // 1v1 discrete: the shot's step from the heading table by angle addition instead of a float64 sincos (below).  Larger teams keep
-    // the sincos: there the shorter shot measured SLOWER (4v4 23.3 -> 25.3 us, two runs each) -- the table entry it needs arrives
-    // later than the ~110 instructions of the sincos take, and nothing else is left to cover it.
-    constexpr bool CHEAP_SHOT = !CONT && (N == 1 || (X_CHEAP_ALL && N > 0));
+    // Discrete actions, compile-time team sizes: the shot's step from the heading table by angle addition instead of a float64 sincos
+    // (below).  Round 3 had it at 1v1 only -- for larger teams the shorter shot measured SLOWER then (the table entry arrived later than
+    // the sincos took).  With layout v2 every load of the step leaves in the first batch and the table shot pays at 2v2 and 3v3 (-3.6 % /
+    // -4.1 %; with the corner-form tests -5 %); at 4v4 it pays only together with ordinary observation-row stores (bsx_step_phase_stores.inl:
+    // 20.5 us, stable; with non-temporal rows a 4v4 kernel that reaches its stores sooner runs SLOWER: 24.5).
+    constexpr bool CHEAP_SHOT = !CONT && N >= 1 && (N <= 3 || (N == 4 && (!MULTI || ACTOR)));   // (not the multi-tick 4v4 kernel: 15.8 -> 17.3 us per tick with it)
     double2 nd = make_double2(0.0, 0.0);                 // this call's shot: float64 step (CHEAP_SHOT: to ~1e-8 unless flagged exact), step code, heading
     double nbdir = 0.0;
     uint32_t ncode = 0u;

@@ -34,10 +34,11 @@
         }
         if (valid) {
             float* out = elem(obs_t, gt * ix_t(D));
-            // (rows leave non-temporal, except in the multi-tick 4v4 discrete kernel: there ordinary stores -- the L2 merges a row's pieces --
-            //  measured 16.5 ... 16.9 us per tick, stable, against 19 ... 23 with the non-temporal hint; every other kernel is faster or equal
-            //  with the hint, profiles/r04_experiments.json)
-            constexpr bool ROW_PLAIN = N >= X_OBS_PLAIN_FROM || (MULTI && N == 4 && !CONT);
+            // (rows leave non-temporal, except in the 4v4 discrete kernels: there ordinary stores -- the L2 merges a row's pieces.  With the
+            //  hint the per-step 4v4 kernel has two modes by process, ~20.3 and ~22.4 us, and any cut of its instruction count makes it SLOWER
+            //  (the table shot: 24.5); with ordinary stores + the table shot it runs 20.5, stable; the multi-tick form 15.7 against 19 ... 23.
+            //  Every other kernel is faster or equal with the hint; profiles/r04_experiments.json)
+            constexpr bool ROW_PLAIN = N >= X_OBS_PLAIN_FROM || (N == 4 && !CONT);
             auto row_store = [](auto* q, auto v) { if constexpr (ROW_PLAIN) *q = v; else out_store(q, v); };
 #pragma unroll
             for (int i = 0; i + 4 <= D; i += 4) row_store(reinterpret_cast<v4f_t*>(out + i), v4f_t{row[i], row[i + 1], row[i + 2], row[i + 3]});
