@@ -119,6 +119,8 @@ def init_timing_group(backend, device, timeout_s=180.0, probe_wait_s=90.0, poll_
 
     def attempt():
         try:
+            if device.type == "cuda":
+                torch.cuda.set_device(device)               # (the current device is per thread)
             _rccl_preflight(device)
             box["group"] = _rccl_probe(device, world, timeout_s)
         except BaseException as exc:                        # noqa: BLE001 -- whatever RCCL raised, the fallback is the same

@@ -76,6 +76,20 @@ def test_bench_under_torch_distributed_run_uses_the_ranks_it_is_given():
     assert d["roofline"]["traffic_source"] is None or "profiles/traffic.json" in d["roofline"]["traffic_source"]     # no live PMC passes at N > 1
 
 
+def test_rccl_refused_on_one_card_moves_both_ranks_to_gloo_together():
+    """The RCCL leg on real hardware, as far as one card goes: two ranks that share cuda:0 ASK for the nccl backend.  RCCL refuses two
+    ranks on one device ("invalid usage"), on both ranks, inside the collective probe -- the setup of sharding.init_timing_group must
+    bring both ranks out on gloo within seconds (not RCCL's timeout), say why in the line, and the measurement must go through."""
+    import time
+    t0 = time.time()
+    d = _bench(["--gpus", "2", "--rehearse-on-device0", "--backend", "nccl", "--steps", "50", "--warmup", "5", "--repeats", "2", "--ramp-ms", "0",
+                "--no-cpu-baseline", "--no-other-workloads", "--no-live-traffic"], timeout=300)
+    assert time.time() - t0 < 120
+    assert d["n_gpus"] == 2 and d["config"]["process_group"] == "gloo"
+    assert "nccl (RCCL) did not come up on every rank" in d["config"]["process_group_note"]
+    assert len(d["per_rank"]["ms_per_step"]) == 2 and d["value"] > 1e9
+
+
 @pytest.mark.skipif(__import__("torch").cuda.device_count() < 2, reason="needs two GPUs: the RCCL leg of bench.py --gpus N on distinct devices")
 def test_two_ranks_on_two_devices_come_up_on_rccl():
     """`python bench.py --gpus 2` on a node with at least two cards: one rank per GPU, the process group on the nccl backend (= RCCL
