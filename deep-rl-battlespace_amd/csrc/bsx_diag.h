@@ -51,6 +51,12 @@ constexpr int X_MIN_WAVES = BSX_X_MIN_WAVES;
 #endif
 constexpr int X_OBS_PLAIN_FROM = BSX_X_OBS_PLAIN_FROM;
 
+// -DBSX_X_ATAN_TABLE_MAX_K=<k>: atan2's coefficients from constant memory for up to k lockstep evaluations (product: 2; same results)
+#ifndef BSX_X_ATAN_TABLE_MAX_K
+#define BSX_X_ATAN_TABLE_MAX_K 2
+#endif
+constexpr int X_ATAN_TABLE_MAX_K = BSX_X_ATAN_TABLE_MAX_K;
+
 #ifdef BSX_STAMPS
 constexpr int BUILD_FLAGS = int(DIAG & 0xFFu) | 0x100;
 __device__ unsigned long long* g_stamps = nullptr;

@@ -53,6 +53,7 @@ constexpr bool X_CORNERS_ALL = false;
 constexpr int X_DEPHASE = 0;
 constexpr int X_MIN_WAVES = 1;
 constexpr int X_OBS_PLAIN_FROM = 99;
+constexpr int X_ATAN_TABLE_MAX_K = 2;
 #define STAMP(i) do { } while (0)
 #define FSTAMP(i) do { } while (0)
 #define PSTAMP(i) do { } while (0)
