@@ -59,9 +59,9 @@ if True:
         d = np.diff(s, axis=1)
         tot[:7] += d.mean(0); reps += 1
         span.append(((s[:, 7].max() - s[:, 0].min()), (s[:, 7] - s[:, 0]).mean(), (s[:, 0].max() - s[:, 0].min())))
-    names = ["T0 loads -> plane record, heading-table request", "classify, slot table, shot (philox, sincos), first slot fetch", "move (or re-spawn), pose hand-off, staging", "obs geometry", "bullet rounds (packed pass, part 2)", "resolve + rewards / game end", "stores"]
+    names = ["T0 loads -> plane record, heading-table request", "classify, shot (ballot, philox, table step / sincos), staging", "move (or re-spawn), pose hand-off, staging", "obs geometry", "bullet rounds (packed pass, part 2)", "resolve + rewards / game end", "stores"]
     if FINE:
-        names = ["T0 loads -> plane record, heading-table request", "group ballot, call mode", "slot table (one ballot + LDS write per list index)", "LDS init, wave barrier",
+        names = ["T0 loads -> plane record, heading-table request", "group ballot, call mode", "shot ballot, owner flags staged", "LDS init, wave barrier",
                  "shot (Philox, sincos, ring store), first slot fetch", "move (or re-spawn) -> hand-off [phase stamps 3..6 are off]", "everything else up to the stores' end"]
     tot /= reps
     print(f"E={E} n={n} waves={waves}; s_memtime ticks, mean over waves (divide the printed value by 10 for shader cycles)")
