@@ -101,6 +101,10 @@ inline StatePtrs state_ptrs(void* base, int64_t E, int n) {
                      reinterpret_cast<double2*>(b + L.bd)};
 }
 
+// Wave votes on a BOOL: the builtin takes the lane mask as it stands.  HIP's __ballot / __any take an int -- the compiler materialises the
+// predicate as 0 / 1 in a VGPR and compares it with zero again: two vector instructions per vote, ~10 votes on the step's hot path.
+__device__ inline unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ inline bool any64(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 // the value of the lane next door (lane ^ 1): one DPP move (quad_perm [1,0,3,2]); __shfl_xor compiles to an LDS permute with its index math
 __device__ inline int lane_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
 __device__ inline uint32_t rotl12(uint32_t v, int s) {  // rotate a 12-bit mask left by s in [0, 12)

@@ -68,7 +68,7 @@
             // Everything from here to the outcome works on (x, y) PAIRS in the two 16-bit halves of a register: the move, and every
             // rectangle test as "some lower or upper margin is negative" = a sign bit in either half.
             uint32_t bpk = step_pk(en.x & ENT_XY, en.y);
-            if (__any(lvm != 0 && (en.x & ENT_EXACT) != 0u)) {                  // wave-uniform and rare: the float64 move of flagged entries
+            if (any64(lvm != 0 && (en.x & ENT_EXACT) != 0u)) {                  // wave-uniform and rare: the float64 move of flagged entries
                 if constexpr (N == 1) asm volatile("");   // (1v1: keeps this a scalar branch on the common path)
                 if (lvm != 0 && (en.x & ENT_EXACT) != 0u) {                     // (this call's shot left its step in LDS, older ones in the ring by birth tick)
                     const ix_t go = gb0 + ix_t(o / G) * ix_t(A) + ix_t(o & (G - 1));
@@ -106,12 +106,12 @@
             // not in their physics call (finished and waiting, or tied by this call); the entries of a game this call re-spawns go.
             const bool asis = on && !ophys && (c.fl & OWN_DROP) == 0u;
             const bool stay = keepm != 0 || asis;
-            const unsigned long long kb = __ballot(stay);
+            const unsigned long long kb = ballot64(stay);
             const int ps = wpos + int(__builtin_amdgcn_mbcnt_hi(uint32_t(kb >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(kb), 0u)));
             wpos += __popcll(kb);
             st_on = stay; st_ps = ps;
             st_w = make_uint2(asis ? en.x : (((en.x & ~ENT_XY) | bpk) + 0x800u), en.y);   // the new position, age + 1; flag and owner as they were
-            if (__any(m != 0u)) {                        // wave-uniform and rare: a bullet overlaps a live enemy plane
+            if (any64(m != 0u)) {                        // wave-uniform and rare: a bullet overlaps a live enemy plane
                 any_hit = true;
                 if (m != 0u) {
                     if constexpr (OW == 1) __hip_atomic_fetch_or(&s_ov[o], (unsigned long long)(m) << (age * FW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -146,7 +146,7 @@
     uint64_t any_ovl = 0;
 #pragma unroll
     for (int q = 0; q < OW; ++q) any_ovl |= ovl[q];
-    if (__ballot(any_ovl != 0ull) != 0ull && !(DIAG & 4u)) {   // wave-uniform: most waves have no candidate at all
+    if (ballot64(any_ovl != 0ull) != 0ull && !(DIAG & 4u)) {   // wave-uniform: most waves have no candidate at all
         uint32_t consumed = 0;                                 // by age
         if constexpr (N == 1) {
             // one shooter per target: my candidates, oldest first, hit until the enemy's hit points run out; the rest fly on
@@ -160,7 +160,7 @@
             uint64_t wsel = ovl[0];
             if (OW == 3) wsel = ((ag >> 2) == 0) ? ovl[0] : (((ag >> 2) == 1) ? ovl[OW > 1 ? 1 : 0] : ovl[OW > 2 ? 2 : 0]);
             const uint32_t m = uint32_t(wsel >> (OW == 1 ? ag * FW : (ag & 3) * 16)) & ((1u << FW) - 1u);
-            if (__ballot(m != 0) == 0ull) continue;            // wave-uniform: nobody has a candidate of this age
+            if (ballot64(m != 0) == 0ull) continue;            // wave-uniform: nobody has a candidate of this age
             for (int i = 0; i < n; ++i) {
                 if (m != 0 && (a - (team ? n : 0)) == i) {
                     for (int j = 0; j < n; ++j) {
@@ -177,7 +177,7 @@
         }
         // a bullet that hit a plane is gone: its pool entry becomes a tombstone, dropped by the next call's compaction
         // (the survivor entry was stored by ANOTHER lane of this wave; let it land before its first word is overwritten)
-        if (__any(consumed != 0u)) __builtin_amdgcn_s_waitcnt(0x0F70);
+        if (any64(consumed != 0u)) __builtin_amdgcn_s_waitcnt(0x0F70);
         while (consumed) {
             const int ag = __builtin_ctz(consumed);
             consumed &= consumed - 1u;

@@ -14,7 +14,7 @@
     STAMP(1);
 
     // "no agents left" (battle_env.py:309): group ballot over the alive flags
-    const unsigned long long bal = __ballot(alive0);
+    const unsigned long long bal = ballot64(alive0);
     const unsigned long long gmask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << (lane & ~(G - 1)));
     const bool any_alive = (bal & gmask) != 0ull;
 
@@ -44,14 +44,14 @@
     // served by lane w % 64 in round w / 64.  Under uniform play a plane holds 0.6 bullets and fires every fourth call: ~37 + 16 slots,
     // ONE round.  What a slot needs from its bullet's owner (named by the entry) is staged per owner lane in LDS.
     FSTAMP(3);
-    const unsigned long long shb = __ballot(spawn);
+    const unsigned long long shb = ballot64(spawn);
     const int srank = int(__builtin_amdgcn_mbcnt_hi(uint32_t(shb >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(shb), 0u)));
     const int slots = int(pc) + __popcll(shb);           // wave-uniform
     s_agg[tid] = 0u;
     s_eb[tid] = make_rect(pack_xy(team == 0 ? er.bbx : er.brx, team == 0 ? er.bby : er.bry), true, 33, 32, 33, 31);
     s_fl[tid] = uint32_t(ks) | (phys ? OWN_PHYS : 0u) | ((mode == M_RESET && valid) ? OWN_DROP : 0u);
     // does this call touch the pool at all?  (not if no game of the wave is in its physics call or being re-spawned: entries stay as they are)
-    const bool pool_pass = __any(phys || (mode == M_RESET && valid));
+    const bool pool_pass = any64(phys || (mode == M_RESET && valid));
     FSTAMP(4);
     FSTAMP(5);
     // Discrete actions, compile-time team sizes: the shot's step from the heading table by angle addition instead of a float64 sincos
@@ -100,6 +100,6 @@
         s_new[srank] = u32x2{pack_bullet(x, y, 0) | (nexact ? ENT_EXACT : 0u) | (uint32_t(lane) << ENT_OWNER_SHIFT), ncode};
     }
     // rare (step_code): a shot that moves by the float64 sum.  Asked once per wave, here, long before anything branches on it
-    const bool shot_exact = __any(spawn && nexact);
+    const bool shot_exact = any64(spawn && nexact);
     FSTAMP(6);
 
