@@ -370,6 +370,15 @@ void bsx_step_kernel(const int64_t E_, const uint2* const envc_, const uint2* co
     const DecIn din = MULTI ? din_next : decode(rin);
     int act = din.act;
     double a0 = din.a0, a1 = din.a1, a2 = din.a2, uu_in = din.uu;
+    // ---- the tick, phase by phase (each file opens with what it reads and writes; they share the locals above and each other's):
+    //   actor     fused rollout only: this tick's actions from the actors' MFMA pass over the wave's LDS observation rows
+    //   shot      heading-table gather; call mode per game (inert / re-spawn / tie / physics); ONE Philox block (jitter or re-spawn); the shot
+    //             as a pool entry queued in LDS; owner flags and the enemy base staged for the work slots
+    //   move      re-spawn or process_action's move; post-move poses to the game's other planes (DPP / LDS); sprites staged as rectangles
+    //   geometry  range / angle-off to the enemy base and planes in binary64 (the observation row's values)
+    //   bullets   Bullet.update for every work slot (pool entries + queued shots), pool compaction, ordered plane-hit resolve
+    //   outcome   rewards, deaths, base hit points, win / tie
+    //   stores    plane / game records, reward, done, observation row, counters, pool length
 #include "bsx_step_phase_actor.inl"
 #include "bsx_step_phase_shot.inl"
 #include "bsx_step_phase_move.inl"

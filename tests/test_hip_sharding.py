@@ -84,7 +84,7 @@ def test_rccl_refused_on_one_card_moves_both_ranks_to_gloo_together():
     t0 = time.time()
     d = _bench(["--gpus", "2", "--rehearse-on-device0", "--backend", "nccl", "--steps", "50", "--warmup", "5", "--repeats", "2", "--ramp-ms", "0",
                 "--no-cpu-baseline", "--no-other-workloads", "--no-live-traffic"], timeout=300)
-    assert time.time() - t0 < 120
+    assert time.time() - t0 < 240                            # (seconds when RCCL refuses at once, as it does; the probe wait bounds it otherwise)
     assert d["n_gpus"] == 2 and d["config"]["process_group"] == "gloo"
     assert "nccl (RCCL) did not come up on every rank" in d["config"]["process_group_note"]
     assert len(d["per_rank"]["ms_per_step"]) == 2 and d["value"] > 1e9
