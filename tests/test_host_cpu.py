@@ -259,6 +259,35 @@ def test_rccl_probe_passing_everywhere_hands_out_the_probed_group(tmp_path):
     assert all(r["backend"] == "nccl" and r["clean"] and r["note"] == "None" for r in res.values()), res
 
 
+def test_state_block_size_follows_the_documented_layout():
+    """bsx_state_bytes (a host function: no GPU needed) against DESIGN.md section 3 / include/battlespace_hip.h, layout v2 (ABI 14):
+    heading table, 8-byte game records (constant + dynamic), 16-byte counters, 8-byte plane records + the float64 headings of the
+    continuous kernels, one pool per wave block of 64 lanes (a count + 768 entries of 8 bytes), the two birth-tick rings."""
+    import ctypes
+    from deep_rl_battlespace_amd import _lib
+    lib = _lib.load()
+    assert lib.bsx_abi_version() == 14
+
+    def expect(E, n):
+        al = lambda v: (v + 255) & ~255
+        A = 2 * n
+        G = 2
+        while G < A:
+            G *= 2
+        NB = -(-E // (64 // G))
+        EA = E * A
+        o = 0
+        for nbytes in (361 * 16, E * 8, E * 8, E * 16, EA * 8, EA * 8, NB * 4, NB * 768 * 8, 12 * EA * 8, 12 * EA * 16):
+            o = al(o + nbytes)
+        return o
+    for E, n in ((1, 1), (31, 1), (65536, 1), (65536, 4), (1000, 3), (7, 16), (1 << 20, 1), (33, 5)):
+        got = ctypes.c_size_t()
+        assert lib.bsx_state_bytes(E, n, ctypes.byref(got)) == 0
+        assert got.value == expect(E, n), (E, n, got.value, expect(E, n))
+    assert lib.bsx_state_bytes(0, 1, ctypes.byref(got)) == -1 and lib.bsx_state_bytes(8, 17, ctypes.byref(got)) == -1
+    assert [lib.bsx_tie_tick(n) for n in (1, 2, 3, 4, 16)] == [121, 141, 161, 181, 421] or lib.bsx_tie_tick(16) < 512
+
+
 def test_render_frame_from_exported_state(tmp_path):
     """f-4: one game's exported state rasterised on the host (no pygame): shapes, colours, dead plane hollow."""
     from deep_rl_battlespace_amd import render
