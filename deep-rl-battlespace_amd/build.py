@@ -45,14 +45,18 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
-    for src, extra in SOURCES:
+    from concurrent.futures import ThreadPoolExecutor
+
+    def compile_one(item):                                  # the translation units compile side by side (two hipcc processes)
+        src, extra = item
         obj = os.path.splitext(src)[0] + ".o"
         cmd = [hipcc, *COMMON, *extra, "-I", INCLUDE, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-        objs.append(obj)
+        return obj
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
