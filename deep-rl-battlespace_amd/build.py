@@ -25,8 +25,13 @@ COMMON = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-
 # the default puts them in AGPRs and pays a v_accvgpr_read per value the LayerNorm / head then touches (11 % of the actor).
 # -amdgpu-kernarg-preload-count=15: the step kernels' eight leading arguments (game count and the pointers of a wave's first
 # loads) arrive in SGPRs with the dispatch instead of through a cold scalar-cache fetch at the start of every wave.
-SOURCES = [(os.path.join(CSRC, "bsx_kernels.hip"), ["-ffp-contract=off", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-mfma-vgpr-form",
-                                                    "-mllvm", "-amdgpu-kernarg-preload-count=15"]),
+STEP_FLAGS = ["-ffp-contract=off", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-mfma-vgpr-form", "-mllvm", "-amdgpu-kernarg-preload-count=15"]
+# bsx_kernels.hip: reset / export / scripted-opponent kernels, launchers, C ABI; the 76 step-kernel instances are three more translation
+# units (bsx_step_instances.h), compiled side by side: the build is as long as the largest of them instead of their sum
+SOURCES = [(os.path.join(CSRC, "bsx_kernels.hip"), STEP_FLAGS),
+           (os.path.join(CSRC, "bsx_step_per_call.hip"), STEP_FLAGS),
+           (os.path.join(CSRC, "bsx_step_multi_tick.hip"), STEP_FLAGS),
+           (os.path.join(CSRC, "bsx_step_rollout.hip"), STEP_FLAGS),
            (os.path.join(CSRC, "bsx_actor.hip"), ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form"])]
 
 

@@ -1,0 +1,31 @@
+// bsx_config.h -- what every translation unit of the step() path starts from: the HIP / C headers, the C ABI, the actor's shared code, and
+// the build's switches (the product constants, or csrc/bsx_diag.h in a diagnostic VARIANT build).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "battlespace_hip.h"
+#include "bsx_actor_core.h"
+
+// Diagnostic builds (tools/build_variant.py compiles this file with -DBSX_VARIANT): timing-only ablations (DIAG bits; results are
+// WRONG with any bit set) and in-kernel phase stamps live in bsx_diag.h.  The product build sees the constants below: no
+// ablation, stamps compile to nothing, bsx_build_flags() == 0.
+#ifdef BSX_VARIANT
+#include "bsx_diag.h"
+#else
+constexpr unsigned DIAG = 0;
+constexpr int BUILD_FLAGS = 0;
+constexpr int OBS_FORM = 0;
+constexpr bool X_CORNERS_ALL = false;
+constexpr int X_DEPHASE = 0;
+constexpr int X_MIN_WAVES = 1;
+constexpr int X_OBS_PLAIN_FROM = 99;
+constexpr int X_ATAN_TABLE_MAX_K = 2;
+#define STAMP(i) do { } while (0)
+#define FSTAMP(i) do { } while (0)
+#define PSTAMP(i) do { } while (0)
+#endif

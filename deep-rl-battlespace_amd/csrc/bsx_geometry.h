@@ -1,9 +1,9 @@
 // bsx_geometry.h -- plane kinematics helpers and the observation geometry (range, angle-off) in binary64: atan2 / sqrt on integer pixel differences
 // Part of the step() path of libbattlespace_hip.so (included by bsx_kernels.hip, in this order: bsx_state.h, bsx_rng.h, bsx_geometry.h,
-// bsx_instinct.h, bsx_step_kernel.h); everything lives in the translation unit's anonymous namespace.
+// bsx_instinct.h, bsx_step_kernel.h) and by the three translation units that instantiate the step kernels; namespace bsxk.
 #pragma once
 
-namespace {
+namespace bsxk {
 
 // ---------------------------------------------------------------------------------------------- game arithmetic
 // Plane.forward clamp on the un-rotated 50x48 rect (sprites.py:134-141)
@@ -37,7 +37,7 @@ __device__ inline double fma_k(double a, double b, double c) {
 // compares it with the library on every argument pair).
 // K independent evaluations in lockstep: with two waves per SIMD nothing else fills the ~8 cycles a dependent float64 operation
 // waits for its predecessor, so K chains advance together, stage by stage, and every coefficient is materialised once for all K.
-__constant__ double ATAN2_COEF[20] = {
+static __constant__ double ATAN2_COEF[20] = {   // (one copy per translation unit: no device linking)
     0x1.ba404b5e68a13p-17, -0x1.3e260bd3237f4p-13, 0x1.b2bb069efb384p-11, -0x1.7952daf56de9bp-9, 0x1.d6d43a595c56fp-8,
     -0x1.c6ea4a57d9582p-7, 0x1.67e295f08b19fp-6, -0x1.e9ae6fc27006ap-6, 0x1.2c15b5711927ap-5, -0x1.59976e82d3ff0p-5,
     0x1.82d5d6ef28734p-5, -0x1.ae5ce6a214619p-5, 0x1.e1bb48427b883p-5, -0x1.110e48b207f05p-4, 0x1.3b13657b87036p-4,
@@ -172,4 +172,4 @@ __device__ inline void obs_pair(int x, int y, double dir, int tx, int ty, float&
     oa = obs_angle(x, y, dir, tx, ty);
 }
 
-}  // namespace
+}  // namespace bsxk

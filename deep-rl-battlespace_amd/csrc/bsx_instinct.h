@@ -1,9 +1,9 @@
 // bsx_instinct.h -- the scripted 'instinct' opponent's action from one observation row (instinct/agent.py:10-62)
 // Part of the step() path of libbattlespace_hip.so (included by bsx_kernels.hip, in this order: bsx_state.h, bsx_rng.h, bsx_geometry.h,
-// bsx_instinct.h, bsx_step_kernel.h); everything lives in the translation unit's anonymous namespace.
+// bsx_instinct.h, bsx_step_kernel.h) and by the three translation units that instantiate the step kernels; namespace bsxk.
 #pragma once
 
-namespace {
+namespace bsxk {
 
 // The scripted opponent's target choice and discrete action (instinct/agent.py:10-39,56-62) from one observation row,
 // ob(k) = value k of the row: score every target by dist * |angle| (base first, strict '<' keeps the first minimum, a dead
@@ -45,4 +45,4 @@ __device__ inline float4 one_hot_scores(int act) {               // what the sco
     return make_float4(act == 0 ? 1.f : -1.f, act == 1 ? 1.f : -1.f, act == 2 ? 1.f : -1.f, act == 3 ? 1.f : -1.f);
 }
 
-}  // namespace
+}  // namespace bsxk

@@ -31,38 +31,22 @@
 // Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off   (no FMA contraction: positions are float64 add-then-
 // truncate in the reference, sprites.py:130-131,332-333, and must round exactly as CPython rounds them).
 
-#include <hip/hip_runtime.h>
-#include <type_traits>
-#include <math.h>
-#include <stdint.h>
-#include <string.h>
-
-#include "battlespace_hip.h"
-#include "bsx_actor_core.h"
-
-// Diagnostic builds (tools/build_variant.py compiles this file with -DBSX_VARIANT): timing-only ablations (DIAG bits; results are
-// WRONG with any bit set) and in-kernel phase stamps live in bsx_diag.h.  The product build sees the constants below: no
-// ablation, stamps compile to nothing, bsx_build_flags() == 0.
-#ifdef BSX_VARIANT
-#include "bsx_diag.h"
-#else
-constexpr unsigned DIAG = 0;
-constexpr int BUILD_FLAGS = 0;
-constexpr int OBS_FORM = 0;
-constexpr bool X_CORNERS_ALL = false;
-constexpr int X_DEPHASE = 0;
-constexpr int X_MIN_WAVES = 1;
-constexpr int X_OBS_PLAIN_FROM = 99;
-constexpr int X_ATAN_TABLE_MAX_K = 2;
-#define STAMP(i) do { } while (0)
-#define FSTAMP(i) do { } while (0)
-#define PSTAMP(i) do { } while (0)
-#endif
+#include "bsx_config.h"
 #include "bsx_state.h"
 #include "bsx_rng.h"
 #include "bsx_geometry.h"
 #include "bsx_instinct.h"
 #include "bsx_step_kernel.h"
+#define BSX_INST_PER_CALL
+#define BSX_INST_MULTI_TICK
+#define BSX_INST_ROLLOUT
+#ifdef BSX_VARIANT
+#define BSX_INST_KW
+#else
+#define BSX_INST_KW extern
+#endif
+#include "bsx_step_instances.h"
+using namespace bsxk;
 
 namespace {
 

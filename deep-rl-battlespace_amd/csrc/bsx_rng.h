@@ -1,9 +1,9 @@
 // bsx_rng.h -- the in-kernel random draws: Philox4x32-10 keyed by (seed, global game, stream, episode, tick | agent); spawn draws with the reference's ranges
 // Part of the step() path of libbattlespace_hip.so (included by bsx_kernels.hip, in this order: bsx_state.h, bsx_rng.h, bsx_geometry.h,
-// bsx_instinct.h, bsx_step_kernel.h); everything lives in the translation unit's anonymous namespace.
+// bsx_instinct.h, bsx_step_kernel.h) and by the three translation units that instantiate the step kernels; namespace bsxk.
 #pragma once
 
-namespace {
+namespace bsxk {
 
 // ---------------------------------------------------------------------------------------------- Philox4x32-10
 using bsx_actor::philox4x32_10;   // one definition, shared with the actor's exploration noise (bsx_actor_core.h)
@@ -40,4 +40,4 @@ __device__ inline SpawnDraw spawn_from_words(const uint4 r, int a, int n) {
     return s;
 }
 
-}  // namespace
+}  // namespace bsxk

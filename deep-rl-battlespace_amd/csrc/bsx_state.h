@@ -1,9 +1,9 @@
 // bsx_state.h -- constants of the game, the state block's layout (ABI 14), record and pool-entry formats, the integer bullet step
 // Part of the step() path of libbattlespace_hip.so (included by bsx_kernels.hip, in this order: bsx_state.h, bsx_rng.h, bsx_geometry.h,
-// bsx_instinct.h, bsx_step_kernel.h); everything lives in the translation unit's anonymous namespace.
+// bsx_instinct.h, bsx_step_kernel.h) and by the three translation units that instantiate the step kernels; namespace bsxk.
 #pragma once
 
-namespace {
+namespace bsxk {
 
 
 constexpr int K = BSX_BULLET_SLOTS;
@@ -182,4 +182,4 @@ __device__ inline uint32_t pack_envd(const EnvU& e) {
 }
 static_assert(5 * BSX_MAX_N < 256 && 12 * BSX_MAX_N < 256, "base hit points (start 5n, at most 12n hits in one call) fit 9 signed bits");
 
-}  // namespace
+}  // namespace bsxk

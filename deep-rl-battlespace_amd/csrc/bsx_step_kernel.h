@@ -1,9 +1,9 @@
 // bsx_step_kernel.h -- bsx_step_kernel: ONE fused launch per step() (and its multi-tick / fused-rollout forms)
 // Part of the step() path of libbattlespace_hip.so (included by bsx_kernels.hip, in this order: bsx_state.h, bsx_rng.h, bsx_geometry.h,
-// bsx_instinct.h, bsx_step_kernel.h); everything lives in the translation unit's anonymous namespace.
+// bsx_instinct.h, bsx_step_kernel.h) and by the three translation units that instantiate the step kernels; namespace bsxk.
 #pragma once
 
-namespace {
+namespace bsxk {
 
 // np.argmax over four scores (battle_env.py:327-328): the first maximum; a NaN compares as the maximum.  The running maximum is a
 // register, not v[arg]: a dynamically indexed local array lives in scratch memory.
@@ -401,4 +401,4 @@ void bsx_step_kernel(const int64_t E_, const uint2* const envc_, const uint2* co
     }   // tick loop
 }
 
-}  // namespace
+}  // namespace bsxk

@@ -5,7 +5,7 @@ container: hipcc cross-compiles without a GPU).
     python tools/isa_meta.py                 # compiles csrc/bsx_kernels.hip and csrc/bsx_actor.hip with the product flags
     python tools/isa_meta.py --json out.json # ... and writes the table as JSON (profiles/rNN_isa_meta.json)
     python tools/isa_meta.py file.s ...      # reads existing assembly files (hipcc --save-temps)
-    python tools/isa_meta.py --diff a.s b.s  # are two builds the same kernel bits? (instruction streams compared per kernel)
+    python tools/isa_meta.py --diff a.s b.s  # are two builds the same kernel bits? (instruction streams compared per kernel; a.s / b.s may be comma-separated lists)
 
 Columns: VGPRs, spilled VGPRs, SGPRs, spilled SGPRs, scratch bytes per lane, LDS bytes per workgroup.  The step kernel's
 template arguments are shown as <N, CONT, MULTI, ACTOR, LG, OFF32> with T/F for the booleans."""
@@ -22,7 +22,7 @@ KEYS = (".vgpr_count", ".vgpr_spill_count", ".sgpr_count", ".sgpr_spill_count", 
 
 
 def short_name(mangled):
-    m = re.match(r"_ZN12_GLOBAL__N_115bsx_step_kernelILi(\d+)ELb([01])ELb([01])ELb([01])ELb([01])ELb([01])E", mangled)
+    m = re.match(r"_ZN(?:12_GLOBAL__N_1|4bsxk)15bsx_step_kernelILi(\d+)ELb([01])ELb([01])ELb([01])ELb([01])ELb([01])E", mangled)
     if m:
         return "bsx_step_kernel<%s,%s>" % (m.group(1), ",".join("FT"[int(b)] for b in m.groups()[1:]))
     m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", mangled)
@@ -87,12 +87,21 @@ def compile_product(tmp):
 
 def main(argv):
     if argv and argv[0] == "--diff":
-        a, b = parse_streams(argv[1]), parse_streams(argv[2])
+        def norm(streams):                                   # kernels by readable name; symbol spellings of the two namespaces made equal
+            def line(i):                                     # (block labels carry the function's index in ITS translation unit; a static's name an L)
+                i = re.sub(r"_ZN(?:12_GLOBAL__N_1|4bsxk)L?", "_ZN#", i)
+                return re.sub(r"\.LBB\d+_", ".LBB#_", i)
+            return {short_name(k): [line(i) for i in v] for k, v in streams.items()}
+        a, b = {}, {}
+        for f in argv[1].split(","):
+            a.update(norm(parse_streams(f)))
+        for f in argv[2].split(","):
+            b.update(norm(parse_streams(f)))
         bad = 0
         for k in sorted(set(a) | set(b)):
             if a.get(k) != b.get(k):
                 bad += 1
-                print("DIFFERS" if k in a and k in b else "ONLY IN " + ("A" if k in a else "B"), short_name(k), len(a.get(k, [])), len(b.get(k, [])))
+                print("DIFFERS" if k in a and k in b else "ONLY IN " + ("A" if k in a else "B"), k, len(a.get(k, [])), len(b.get(k, [])))
         print(f"{len(set(a) & set(b))} kernels in both, {bad} differ")
         return 1 if bad else 0
     js = None
