@@ -42,7 +42,15 @@ chained_graphs (not the headline; `--chains P` runs any workload that way): the 
 independent chains over game ranges (parallel_env.capture_steps(chains=P), bsx_step_*_range): per step the whole batch still
 advances one tick -- as P launches that wait only for their own range's previous launch.  Same games bit for bit.
 cpu_baseline: the CPU oracle (oracle/battlespace_ref.py, the scalar Python restatement of the reference's step()) on
-configs[0] -- 1 game of 1v1, the same uniform random actions, reset on done -- timed on one host core of this box.
+configs[0] -- 1 game of 1v1, the same uniform random actions, reset on done -- one process PINNED to one host core of this box
+(BASELINE.md section 3); beside it the same port at 4v4 (`port_4v4`, the same-run CPU figure for configs[2]) and, as context, the C
+port on all cores and the reference's own survey-time figures.
+roofline.bound: "hbm" only where the measured traffic runs at half of the peak or more, else "issue/latency" (65 536 x 1v1 sits at
+the floor of its form: kernel boundary + first loads + instruction issue at two waves per SIMD).
+baseline_configs: the line's LAST key, numbers only (< 1 200 characters): agent-steps/s, us and frac_claimed of every BASELINE.json
+config this run measured -- it survives a record that keeps only the tail of the line.
+N > 1: gloo control group first, the RCCL probe beside it, and the ranks agree on the timing backend before anyone proceeds
+(sharding.init_timing_group); `per_rank` carries every rank's own medians.
 """
 import argparse
 import json
