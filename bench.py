@@ -47,10 +47,15 @@ configs[0] -- 1 game of 1v1, the same uniform random actions, reset on done -- o
 port on all cores and the reference's own survey-time figures.
 roofline.bound: "hbm" only where the measured traffic runs at half of the peak or more, else "issue/latency" (65 536 x 1v1 sits at
 the floor of its form: kernel boundary + first loads + instruction issue at two waves per SIMD).
-baseline_configs: the line's LAST key, numbers only (< 1 200 characters): agent-steps/s, us and frac_claimed of every BASELINE.json
+baseline_configs: the line's LAST key, numbers only (< 1 800 characters: the driver keeps the last 2 000): agent-steps/s, us and frac_claimed of every BASELINE.json
 config this run measured -- it survives a record that keeps only the tail of the line.
-N > 1: gloo control group first, the RCCL probe beside it, and the ranks agree on the timing backend before anyone proceeds
-(sharding.init_timing_group); `per_rank` carries every rank's own medians.
+N > 1: every rank pins itself to its own block of host cores (its card's NUMA node when sysfs names it) before its first GPU call;
+gloo control group first, the RCCL probe beside it, and the ranks agree on the timing backend before anyone proceeds
+(sharding.init_timing_group).  Before the barriered blocks every rank times the same block R times ALONE (the ranks take turns, the
+other cards idle): rank 0's is the same-run single-shard reference.  The line then carries, beside `value` (all ranks' agent-steps over
+the MAX over ranks of the wall-clock block): `value_device` (sum over ranks of E*A / the rank's median kernel time: immune to host
+jitter), `scaling_efficiency` = value / (N x the single-shard reference) and `scaling_efficiency_device`, `per_rank` (every rank's
+medians, min / median / max), `process_group`, `rccl_version`.  R: --repeats, else 5, else 25 when a block is shorter than 2 ms.
 """
 import argparse
 import json
@@ -289,7 +294,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--repeats", type=int, default=5, help="the K-step block is timed this many times; medians are reported")
+    ap.add_argument("--repeats", type=int, default=None,
+                    help="the K-step block is timed this many times; medians are reported.  Default: 5, and 25 when one block is shorter "
+                         "than 2 ms (the driver's --steps 20 is ~0.14 ms: more samples instead of a median of five)")
     ap.add_argument("--ramp-ms", type=float, default=150.0, help="untimed device ramp before the first timed block (clock ramp-up)")
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--n-agents", type=int, default=1, help="planes per team (1 = configs[1], 4 = configs[2])")
@@ -380,6 +387,10 @@ def main():
     rank, world, local_rank = sharding.rank_world()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # N > 1: every rank on its own block of host cores (its card's NUMA node when sysfs says which), BEFORE the first GPU call, so that
+    # the runtime's threads inherit it: eight ranks' launch / sync loops must not migrate over each other (a 142 us timed block is
+    # booked MAX over ranks: one descheduled rank is a scaling loss).  Nothing is re-executed; a rank that cannot pin says so.
+    pinned = sharding.pin_rank_to_its_cores(local_rank, world, same_card_for_all=args.rehearse_on_device0)
     dev_index = 0 if args.rehearse_on_device0 else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -438,6 +449,36 @@ def main():
             torch.cuda.synchronize(dev)
             kms.append(ev0.elapsed_time(ev1) / Kb)
         return max_over_ranks(walls, tag and tag + "walls"), max_over_ranks(kms, tag and tag + "kms")
+
+    def solo_blocks(run, K, R, run_b, Kb):
+        """The same K-step block, R times, WITHOUT the group: the ranks take turns (the others wait in a gloo barrier, their cards idle),
+        so each rank's figure is what its shard does when it has the node's host side to itself -- the same-run N = 1 reference that
+        `scaling_efficiency` divides by.  Every rank plays the same number of steps here, so the shards stay the games of the unsplit
+        job.  -> (wall seconds per repeat, kernel ms per launch per repeat) of THIS rank."""
+        walls, kms = [], []
+        for turn in range(world):
+            if world > 1:
+                torch.cuda.synchronize(dev)
+                dist.barrier()                              # the gloo control group: no kernel on anybody's card while a rank measures
+            if turn != rank:
+                continue
+            for _ in range(R):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                run(K)
+                torch.cuda.synchronize(dev)
+                walls.append(time.perf_counter() - t0)
+                run_b(Kb)
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                run_b(Kb)
+                ev1.record()
+                torch.cuda.synchronize(dev)
+                kms.append(ev0.elapsed_time(ev1) / Kb)
+        if world > 1:
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+        return walls, kms
 
     def ramp(run, ms, K):
         torch.cuda.synchronize(dev)
@@ -559,10 +600,25 @@ def main():
             ramp(run, args.ramp_ms, K)
         else:
             ramp(lambda k: (restore(), graph.replay()), args.ramp_ms, K)
+        if R is None:                                       # no --repeats: 5 blocks, 25 when a block is shorter than 2 ms (decided by all ranks together)
+            R = 5
+            if not restore:
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                run(K)
+                torch.cuda.synchronize(dev)
+                if max_over_ranks([time.perf_counter() - t0])[0] < 2e-3:
+                    R = 25
+        solo = None
+        if tag and not restore:                             # the headline: each rank's own un-barriered blocks first (the same-run N = 1 reference)
+            solo = solo_blocks(run, K, R, run_b or run, Kb or K)
+            if world > 1:
+                max_over_ranks(solo[0], tag + "solo_walls")
+                max_over_ranks(solo[1], tag + "solo_kms")
         walls, kms = timed_blocks(run, K, R, restore, run_b, Kb, tag)
         if live is None and E * A <= (1 << 22):
             live = round(float(env.export_state(("bl_live",))["bl_live"].float().sum()) / (E * A), 3)
-        return dict(env=env, walls=walls, kms=kms, G=G, live=live, Kb=Kb or K)
+        return dict(env=env, walls=walls, kms=kms, G=G, live=live, Kb=Kb or K, solo=solo)
 
     def kernel_name(n, continuous, many, E):
         narrow = E * 2 * n * 200 <= 0xFFFFFFFF            # csrc narrow_offsets_ok(): 32-bit offsets while every array stays below 4 GB
@@ -743,11 +799,12 @@ def main():
             "games_finished": int(games[0]), "ties": int(games[1]), "red_wins": int(games[2]), "blue_wins": int(games[3]),
             "tie_tick": head_env_tie_tick,
         }
+        if head.get("solo"):
+            out["timing"]["unbarriered_ms_per_step"] = round(statistics.median(head["solo"][0]) / K * 1e3, 6)
+            out["timing"]["unbarriered_avg_launch_us"] = round(statistics.median(head["solo"][1]) * 1e3, 3)
+        out["host"] = {"cores_of_rank0": _ranges(pinned.get("cores")), "numa_node_of_rank0": pinned.get("numa_node"), "pinning": pinned.get("how")}
         if world > 1:
-            # every rank's own medians: placement (which XCDs a shard's workgroups land on) is the one thing that could bend the
-            # scaling curve of independent shards, and it would show here as one rank slower than the others
-            out["per_rank"] = {"ms_per_step": [round(statistics.median(v) / K * 1e3, 6) for v in per_rank.get("head_walls", [])],
-                               "avg_launch_us": [round(statistics.median(v) * 1e3, 3) for v in per_rank.get("head_kms", [])]}
+            out.update(multi_rank_fields(per_rank, world, E, A, K, out["value"], args.backend))
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         out["other_workloads"] = others
@@ -757,7 +814,10 @@ def main():
         out["policy_rollouts"] = rollouts
         out["drop_in_one_game"] = dropin
         # LAST key, numbers only: every BASELINE.json config in a form that survives a truncated record of this line
-        out["baseline_configs"] = baseline_summary(out, n, E, world, km, frac_claimed)
+        try:
+            out["baseline_configs"] = baseline_summary(out, n, E, world, km, frac_claimed)
+        except Exception as exc:                            # noqa: BLE001 -- the summary is a convenience: it must never cost the line
+            out["baseline_configs"] = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()                                      # the gloo control group: every rank is done
@@ -766,6 +826,59 @@ def main():
         else:                                               # a probe thread is still blocked inside RCCL: no destructors, no joins
             sys.stdout.flush()
             os._exit(0)
+
+
+def _ranges(cores):
+    """[0,1,2,3,8,9] -> '0-3,8-9' (a rank's core block in the line, short)."""
+    if not cores:
+        return None
+    cores, parts, a = sorted(cores), [], None
+    for i, c in enumerate(cores):
+        if a is None:
+            a = c
+        if i + 1 == len(cores) or cores[i + 1] != c + 1:
+            parts.append(str(a) if a == c else f"{a}-{c}")
+            a = None
+    return ",".join(parts)
+
+
+def _mmm(vals):
+    return {"min": round(min(vals), 6), "median": round(statistics.median(vals), 6), "max": round(max(vals), 6)} if vals else None
+
+
+def multi_rank_fields(per_rank, world, E, A, K, value, backend):
+    """What the N > 1 line says beyond `value` (= all ranks' agent-steps over the MAX over ranks of the wall-clock block, as the bench
+    contract words it), from every rank's own samples (per_rank[name] = [world][R]):
+      value_device       = sum over ranks of E*A / that rank's median kernel time per launch (HIP events on the launch stream: device
+                           time only -- host jitter on one of N ranks, which the MAX books as a scaling loss, does not enter);
+      scaling_efficiency = value / (N x rank 0's own un-barriered figure, measured in this run while the other ranks' cards were idle);
+                           `_device` the same on kernel time; the denominator is printed (`single_shard_reference`);
+      per_rank           = every rank's medians (barriered block, kernel time, solo block) + min / median / max over ranks: placement
+                           (which card, which NUMA node) is the one thing that could bend a curve of independent shards."""
+    med = lambda name: [statistics.median(v) for v in per_rank.get(name, [])]     # noqa: E731
+    walls, kms, swalls, skms = med("head_walls"), med("head_kms"), med("head_solo_walls"), med("head_solo_kms")
+    out = {"per_rank": {"ms_per_step": [round(w / K * 1e3, 6) for w in walls], "avg_launch_us": [round(k * 1e3, 3) for k in kms],
+                        "solo_ms_per_step": [round(w / K * 1e3, 6) for w in swalls], "solo_avg_launch_us": [round(k * 1e3, 3) for k in skms],
+                        "ms_per_step_min_median_max": _mmm([w / K * 1e3 for w in walls]),
+                        "avg_launch_us_min_median_max": _mmm([k * 1e3 for k in kms])}}
+    if kms and all(k > 0 for k in kms):
+        out["value_device"] = round(sum(E * A / (k * 1e-3) for k in kms), 1)
+    if swalls and swalls[0] > 0:
+        ref = E * A * K / swalls[0]
+        out["single_shard_reference"] = {"agent_steps_per_s": round(ref, 1), "ms_per_step": round(swalls[0] / K * 1e3, 6),
+                                         "avg_launch_us": round(skms[0] * 1e3, 3) if skms else None,
+                                         "what": "rank 0's shard alone, un-barriered, the other ranks' cards idle, same run"}
+        out["scaling_efficiency"] = round(value / (world * ref), 4)
+        if skms and skms[0] > 0 and "value_device" in out:
+            out["scaling_efficiency_device"] = round(out["value_device"] / (world * E * A / (skms[0] * 1e-3)), 4)
+    try:
+        import torch
+        v = torch.cuda.nccl.version()
+        out["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as exc:                                # noqa: BLE001
+        out["rccl_version"] = f"unavailable ({type(exc).__name__})"
+    out["process_group"] = backend
+    return out
 
 
 def baseline_summary(out, n, E, world, km, frac_claimed):
@@ -785,7 +898,20 @@ def baseline_summary(out, n, E, world, km, frac_claimed):
         r = {"agent_steps_per_s": round(d["agent_steps_per_s"]), "us": d.get(us)}
         if d.get("frac_claimed") is not None:
             r["frac_claimed"] = round(d["frac_claimed"], 3)
+        rf = d.get("roofline")
+        if isinstance(rf, dict) and rf.get("frac_mfma") is not None:      # the rollouts: matrix-core fraction (and the HBM one when PMC bytes exist)
+            r["frac"] = round(rf["frac_mfma"], 3)
+            if rf.get("frac_hbm") is not None:
+                r["frac_hbm"] = round(rf["frac_hbm"], 3)
         return r
+    def eval_line(ev):                                      # (a variant that failed is recorded as {"error": ...}: then null, not a crash)
+        l = line(ev, "us_per_tick")
+        if l is None:
+            return None
+        for k_out, k_in in (("red_win_rate", "win_rate_red"), ("red_win_rate_stale_first_obs", "win_rate_red_stale_first_obs")):
+            if isinstance(ev.get(k_in), (int, float)):
+                l[k_out] = round(ev[k_in], 4)
+        return l
     head = {"agent_steps_per_s": round(out["value"]), "us": round(km * 1e3, 3), "frac_claimed": frac_claimed and round(frac_claimed, 3)}
     ow, ro, ch = out.get("other_workloads") or {}, pick(out, "policy_rollouts", "variants") or {}, out.get("chained_graphs") or {}
     cb = out.get("cpu_baseline") or {}
@@ -801,12 +927,43 @@ def baseline_summary(out, n, E, world, km, frac_claimed):
          "C5_one_launch": line(by(ro, "one launch for all ticks, both"), "us_per_tick"),
          "C5_one_launch_bf16x6": line(by(ro, "six bf16"), "us_per_tick"),
          "C5_ppo_one_launch": line(by(ro, "PPO-shaped rollout, one launch: "), "us_per_tick"),
-         "eval_2v2": ev and {**line(ev, "us_per_tick"), "red_win_rate": round(ev["win_rate_red"], 4)},
+         "eval_2v2": eval_line(ev),
          "1M_1v1": line(by(ow, "1048576")),
          "multi_tick_C2": line(out.get("multi_tick_launch"), "us_per_tick")}
     if world > 1 and s["C4"] is None:
         s[f"N{world}_x_{E}_{n}v{n}"] = head
     return s
+
+
+MFMA_PEAK_F32_TFLOPS = 157.3                          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, f32 in / f32 accumulate (= the vector peak)
+MFMA_PEAK_BF16_TFLOPS = 2500.0                        # MI355X_MICROARCH.md: dense bf16 matrix peak
+
+
+def rollout_roofline(us_per_tick, rows, obs, n_out, precision="f32", heads=1, traffic_key=None):
+    """Roofline of one rollout tick (actor -> step): the actor is the one GEMM-shaped op on this path (maddpg/networks.py:54-85:
+    obs -> 64 -> LayerNorm -> 64 -> LayerNorm -> n_out per plane), so it has a flops figure; the step has the bytes.
+      flops_per_tick   algorithmic: rows x heads x 2 x (obs*64 + 64*64 + 64*n_out), rows = planes acting through a network
+      frac_mfma        the time the matrix cores need for it at their dense peaks / the tick: f32 layers against 157.3 TFLOP/s; in the
+                       split-bf16 forms the 64 x 64 layer runs as 3 / 6 bf16 products, priced as executed against 2 500 TFLOP/s
+      bytes_per_tick   HBM bytes per tick by PMC (profiles/traffic.json[rollout_*], tools/rollout_traffic.py), frac_hbm against 8 TB/s
+      bound            "mfma" / "hbm" where that fraction is at least one half, else "issue/latency"; frac = the larger fraction."""
+    edge, mid = 2.0 * rows * heads * (obs * 64 + 64 * n_out), 2.0 * rows * heads * 64 * 64
+    k = {"f32": 0, "bf16x3": 3, "bf16x6": 6}[precision]
+    t_mfma = ((edge + mid) if k == 0 else edge) / (MFMA_PEAK_F32_TFLOPS * 1e12) + (k * mid / (MFMA_PEAK_BF16_TFLOPS * 1e12) if k else 0.0)
+    t = us_per_tick * 1e-6
+    r = {"flops_per_tick": round(edge + mid), "mfma_peak_tflops": MFMA_PEAK_F32_TFLOPS if k == 0 else {"f32_layers": MFMA_PEAK_F32_TFLOPS, "bf16_64x64": MFMA_PEAK_BF16_TFLOPS},
+         "achieved_tflops": round((edge + mid) / t / 1e12, 2), "frac_mfma": round(t_mfma / t, 4), "bytes_per_tick": None, "frac_hbm": None}
+    try:
+        te = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(traffic_key) if traffic_key else None
+    except Exception:                                       # noqa: BLE001
+        te = None
+    if te and te.get("hbm_bytes_per_tick"):
+        r.update(bytes_per_tick=te["hbm_bytes_per_tick"], frac_hbm=round(te["hbm_bytes_per_tick"] / t / 1e9 / HBM_PEAK_GBS, 4),
+                 traffic_source=f"profiles/traffic.json[{traffic_key}] (series {te.get('series')})")
+    fh = r["frac_hbm"] or 0.0
+    r["frac"] = max(r["frac_mfma"], fh)
+    r["bound"] = "mfma" if (r["frac_mfma"] >= 0.5 and r["frac_mfma"] >= fh) else ("hbm" if fh >= 0.5 else "issue/latency")
+    return r
 
 
 def rollout_lines(dev, E, K):
@@ -820,6 +977,7 @@ def rollout_lines(dev, E, K):
     from deep_rl_battlespace_amd.rollout import PolicyRollout, StackedActor
     T = 32
     out = {}
+    tkeys = {0: "rollout_graph", 1: "rollout_one_launch", 2: "rollout_one_launch_bf16x6", 3: "rollout_one_launch_bf16x3", 4: "rollout_scripted_blue"}
     variants = [("graph of 2 kernels per tick, both teams on actors", dict(), False, False),
                 ("one launch for all ticks, both teams on actors", dict(one_launch=True), False, False),
                 ("one launch, 64x64 layer as six bf16 matrix products of three-term splits (float32-class accuracy)", dict(one_launch=True, precision="bf16x6"), False, False),
@@ -830,7 +988,7 @@ def rollout_lines(dev, E, K):
                 ("PPO-shaped rollout, one launch, both MLPs' 64x64 layers as three bf16 matrix products of two-term splits", dict(one_launch=True, sample="categorical", value=True, precision="bf16x3"), False, False),
                 ("continuous actions: graph of 2 kernels per tick", dict(), False, True),
                 ("continuous actions: one launch for all ticks", dict(one_launch=True), False, True)]
-    for tag, kw, scripted, cont in variants:
+    for vi, (tag, kw, scripted, cont) in enumerate(variants):
         try:
             env = bsx.parallel_env(n_agents=1, n_envs=E, auto_reset=True, seed=1234, device=dev, continuous_actions=cont)
             env.reset()
@@ -840,6 +998,7 @@ def rollout_lines(dev, E, K):
                 actor.w3.mul_(100.0)                        # random init leaves the head near 0: spread the scores so that play is varied
             opp = instinct.Team(env.possible_blue, env.possible_red, env) if scripted else None
             kw = dict(kw)
+            heads = 2 if kw.get("value") else 1
             if kw.pop("value", False):                      # a value head: a second MLP of the actor's shape with one output per plane
                 critic = StackedActor(2, 5, 1, device=dev)
                 with torch.no_grad():
@@ -860,7 +1019,9 @@ def rollout_lines(dev, E, K):
             dt = statistics.median(samples)
             c = env.counters().sum(0)
             out[tag] = {"agent_steps_per_s": round(E * 2 / dt, 1), "us_per_tick": round(dt * 1e6, 3), "ticks_per_launch_or_graph": T,
-                        "ticks_timed": reps * T, "repeats": 3, "games_finished": int(c[0]), "ties": int(c[1]), "red_wins": int(c[2]), "blue_wins": int(c[3])}
+                        "ticks_timed": reps * T, "repeats": 3, "games_finished": int(c[0]), "ties": int(c[1]), "red_wins": int(c[2]), "blue_wins": int(c[3]),
+                        # (a value head is a second MLP with ONE output: priced with the actor's n_out, < 4 % more flops than it has)
+                        "roofline": rollout_roofline(dt * 1e6, E * (1 if scripted else 2), 5, 3 if cont else 4, kw.get("precision", "f32"), heads, tkeys.get(vi))}
             del ro, env, actor
         except Exception as exc:                            # a variant this build does not offer is reported, not hidden
             out[tag] = {"error": f"{type(exc).__name__}: {str(exc)[:160]}"}
@@ -902,6 +1063,7 @@ def evaluation_line(dev, E, precision="f32"):
     dt = statistics.median(samples)
     ref = {k: int(g12[k]) for k in ("games", "ties", "red_wins", "blue_wins")}
     return {**res, "agent_steps_per_s": round(E * 2 * n / dt, 1), "us_per_tick": round(dt * 1e6, 3), "games_per_s": round(res["games"] / (res["ticks"] * dt), 1),
+            "roofline": rollout_roofline(dt * 1e6, E * n, 3 * n + 2, 4, precision),
             "envs": E, "n_agents_per_team": n, "ticks_per_launch": 32,
             "reference_tally_evaluate_py": {**ref, "win_rate_red": round(ref["red_wins"] / ref["games"], 4),
                                             "source": "tests/golden/g12_evaluation.npz: evaluate.main() unmodified, run in the build container"},

@@ -120,4 +120,7 @@ def check(rc, what):
         raise ValueError(f"{what}: invalid argument (BSX_E_ARG)")
     if rc == -2:
         raise ValueError(f"{what}: misaligned pointer (BSX_E_ALIGN)")
+    if rc == -3:
+        raise ValueError(f"{what}: this state block was advanced by the other action family (BSX_E_FAMILY): a block is discrete or "
+                         f"continuous from its first step until every game is reset")
     raise RuntimeError(f"{what}: HIP error {rc}")

@@ -31,6 +31,9 @@
 // Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off   (no FMA contraction: positions are float64 add-then-
 // truncate in the reference, sprites.py:130-131,332-333, and must round exactly as CPython rounds them).
 
+#include <mutex>
+#include <unordered_map>
+
 #include "bsx_config.h"
 #include "bsx_state.h"
 #include "bsx_rng.h"
@@ -236,6 +239,24 @@ __global__ __launch_bounds__(TPB) void bsx_instinct_kernel(const InstinctArgs p)
 }
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+// Which action family has advanced a state block (ABI 14: the discrete kernels keep headings as whole degrees in the plane record, the
+// continuous ones as float64 beside it -- a parallel_env has one mode for its life, battle_env.py:73).  Kept on the HOST, per state
+// address: nothing on the step path reads or writes device memory for it.  bsx_state_init and a bsx_reset of ALL games forget the
+// family (every heading is a whole degree again); the first step / rollout call after that claims it; a call of the other family is
+// refused with BSX_E_FAMILY instead of silently reading headings truncated to whole degrees.
+std::mutex g_family_mu;
+std::unordered_map<const void*, int> g_family;                // state -> 1 discrete, 2 continuous
+inline void family_forget(const void* state) {
+    std::lock_guard<std::mutex> lk(g_family_mu);
+    g_family.erase(state);
+}
+inline bool family_claim(const void* state, bool cont) {
+    std::lock_guard<std::mutex> lk(g_family_mu);
+    int& f = g_family[state];
+    if (f == 0) f = cont ? 2 : 1;
+    return f == (cont ? 2 : 1);
+}
 inline int grid_for(int64_t E, int n, int tpb = TPB) {
     const int epb = tpb / group_width(n);
     return int((E + epb - 1) / epb);
@@ -280,6 +301,7 @@ int launch_step(void* state, int64_t E, int n, const void* actions, int action_k
     if (!CONT && action_kind != BSX_ACT_I32 && action_kind != BSX_ACT_LOGITS_F32) return BSX_E_ARG;
     if (CONT && action_kind != BSX_ACT_F32 && action_kind != BSX_ACT_F64 && action_kind != BSX_ACT_F32X4) return BSX_E_ARG;
     if (CONT && action_kind == BSX_ACT_F32X4 && !aligned(actions, 16)) return BSX_E_ALIGN;
+    if (!family_claim(state, CONT)) return BSX_E_FAMILY;
     StepArgs a;
     a.st = state_ptrs(state, E, n);
     a.E = E; a.n = n; a.actions = actions; a.action_kind = action_kind; a.u = u;
@@ -359,6 +381,7 @@ int bsx_state_init(void* state, int64_t E, int n, void* stream) {
     if (!state || E <= 0 || E > BSX_MAX_E || n < 1 || n > BSX_MAX_N) return BSX_E_ARG;
     if (!aligned(state, 256)) return BSX_E_ALIGN;
     const Layout L = make_layout(E, n);
+    family_forget(state);
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t err = hipMemsetAsync(state, 0, L.total, s);
     if (err != hipSuccess) return int(err);
@@ -382,6 +405,7 @@ int bsx_reset(void* state, int64_t E, int n, const uint8_t* reset_mask, const in
               uint64_t nonce, int64_t env_offset, float* obs, void* stream) {
     if (!state || E <= 0 || E > BSX_MAX_E || n < 1 || n > BSX_MAX_N) return BSX_E_ARG;
     if (!aligned(state, 256) || (spawn && !aligned(spawn, 4)) || (obs && !aligned(obs, 4))) return BSX_E_ALIGN;
+    if (!reset_mask) family_forget(state);                  // every game re-spawned: whole-degree headings, either family may follow
     ResetArgs a{state_ptrs(state, E, n), E, n, reset_mask, spawn, seed, nonce, env_offset, obs, 0};
     hipLaunchKernelGGL(bsx_reset_kernel, dim3(grid_for(E, n)), dim3(TPB), 0, static_cast<hipStream_t>(stream), a);
     return int(hipGetLastError());
@@ -461,6 +485,7 @@ int launch_rollout(void* state, int64_t E, int n, int T, const float* weights, i
     if (nz.sample_mode != 0 && (nz.sample_mode != 1 || !(nz.temperature > 0.f) || CONT)) return BSX_E_ARG;   // a categorical head belongs to discrete actions
     if ((nz.logp && !aligned(nz.logp, 4)) || (nz.value_weights && !aligned(nz.value_weights, 16))) return BSX_E_ALIGN;
     if (nz.value_weights && (n != 1 || !nz.value || !aligned(nz.value, 4))) return BSX_E_ARG;          // the value head rides in the 1v1 kernel only
+    if (!family_claim(state, CONT)) return BSX_E_FAMILY;
     const int64_t EA = E * 2 * n, D = 3 * n + 2;
     StepArgs a;
     a.st = state_ptrs(state, E, n);

@@ -267,6 +267,8 @@ class PolicyRollout:
                 chains = "auto"
             self.form_note = (f"one_launch asked for {env.n_agents}v{env.n_agents}: the fused kernels cover 1v1 ... 4v4, "
                               "this rollout runs as the two-kernel graph (chains over game ranges where they pay)")
+            import warnings
+            warnings.warn(self.form_note, RuntimeWarning, stacklevel=2)      # the caller asked for a form that is not the one running
         if chains == "auto":                           # two chains where they were measured to pay: 2v2 and larger, from ~260 k agents per tick
             chains = 2 if (env.n_agents >= 2 and env.n_envs * 2 * env.n_agents >= (1 << 18) and not one_launch and fused and opponent is None) else 1
         self.chains = int(chains)
@@ -294,8 +296,8 @@ class PolicyRollout:
         # graph: observation rows stay in LDS between the step and the actor, game state in registers / L2.  Up to 4v4; discrete: a
         # scripted opponent (instinct.Team of one side) is played in-kernel and its actor is skipped; same transitions, bit for bit.
         self.one_launch = bool(one_launch)
-        if self.one_launch and (not fused or env.n_agents > 4):
-            raise ValueError("one_launch needs the fused actor and an env of 1v1 ... 4v4")
+        if self.one_launch and not fused:                  # (with the fused actor, teams beyond 4v4 fell through to the graph above)
+            raise ValueError("one_launch needs the fused actor")
         if self.one_launch and opponent is not None and getattr(opponent, "team", None) not in (0, 1):
             raise ValueError("one_launch plays a scripted opponent in-kernel: it must be an instinct.Team of one side")
         self._seq_base = torch.zeros(1, dtype=torch.int64, device=env.device)

@@ -65,6 +65,101 @@ def local_counter_sums(env):
     return c.to(torch.int64).sum(0)
 
 
+# ---------------------------------------------------------------------------------------------- host cores of a multi-rank job
+def _parse_cpulist(text):
+    """'0-3,8,10-11' (sysfs cpulist) -> sorted list of ints."""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return sorted(set(out))
+
+
+def card_numa_nodes(sysfs="/sys"):
+    """NUMA node of every AMD card, in PCI-address order (the order the runtime numbers its devices in when no *_VISIBLE_DEVICES
+    variable re-orders them), read from /sys/class/drm/card*/device/numa_node WITHOUT touching the GPU; [] when not readable.
+    A card whose node reads -1 (no affinity reported) is listed as None."""
+    import glob
+    cards = {}
+    for d in glob.glob(os.path.join(sysfs, "class", "drm", "card[0-9]*", "device")):
+        try:
+            if open(os.path.join(d, "vendor")).read().strip() != "0x1002":
+                continue
+            node = int(open(os.path.join(d, "numa_node")).read().strip())
+            cards[os.path.basename(os.path.realpath(d))] = node if node >= 0 else None
+        except (OSError, ValueError):
+            continue
+    return [cards[k] for k in sorted(cards)]
+
+
+def affinity_blocks(world_size, allowed, card_nodes=None, node_cpus=None):
+    """Disjoint blocks of host cores, one per local rank -> ([sorted core list] * world_size, "numa" | "plain").
+
+    With the cards' NUMA nodes known (card_nodes[r] = node of rank r's card, node_cpus[node] = that node's cores) the ranks whose cards
+    share a node split THAT node's allowed cores evenly, in rank order; otherwise -- nothing readable, a card without a node, a node
+    with fewer allowed cores than ranks on it -- the allowed cores are cut into world_size consecutive blocks of
+    len(allowed) // world_size.  A pure function of its arguments: every rank computes the same table, so the blocks are disjoint
+    without any communication.  Fewer allowed cores than ranks: every rank keeps all of them (nothing to separate)."""
+    allowed = sorted(set(allowed))
+    W = int(world_size)
+    if W < 1:
+        raise ValueError("world_size < 1")
+    if len(allowed) < W:
+        return [list(allowed) for _ in range(W)], "plain"
+    plain = [allowed[r * (len(allowed) // W):(r + 1) * (len(allowed) // W)] for r in range(W)], "plain"
+    if not card_nodes or not node_cpus or len(card_nodes) < W or any(card_nodes[r] is None for r in range(W)):
+        return plain
+    out = [None] * W
+    for node in sorted(set(card_nodes[:W])):
+        ranks = [r for r in range(W) if card_nodes[r] == node]
+        cores = [c for c in node_cpus.get(node, []) if c in set(allowed)]
+        per = len(cores) // len(ranks)
+        if per < 1:
+            return plain
+        for i, r in enumerate(ranks):
+            out[r] = cores[i * per:(i + 1) * per]
+    return out, "numa"
+
+
+def pin_rank_to_its_cores(local_rank, world_size, same_card_for_all=False, sysfs="/sys"):
+    """Pin THIS process (and every thread it starts afterwards: the HIP runtime's, torch's) to its block of host cores.  To be called
+    before the first GPU call of a rank.  -> dict(cores=[...], numa_node=int|None, how="numa"|"plain"|"unpinned: <why>").
+    world_size 1: the process keeps what it had (cores = all allowed)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError) as exc:
+        return {"cores": None, "numa_node": None, "how": f"unpinned: {type(exc).__name__}"}
+    if world_size <= 1:
+        return {"cores": allowed, "numa_node": None, "how": "unpinned: one rank keeps the cores it was given"}
+    nodes = card_numa_nodes(sysfs)
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):     # a visible-devices list re-numbers the cards
+        v = os.environ.get(var)
+        if v:
+            try:
+                nodes = [nodes[int(t)] for t in v.split(",")]
+            except (ValueError, IndexError):
+                nodes = []
+            break
+    if same_card_for_all and nodes:
+        nodes = [nodes[0]] * world_size
+    node_cpus = {}
+    for nd in set(x for x in nodes if x is not None):
+        try:
+            node_cpus[nd] = _parse_cpulist(open(os.path.join(sysfs, "devices", "system", "node", f"node{nd}", "cpulist")).read())
+        except (OSError, ValueError):
+            nodes = []
+            break
+    blocks, how = affinity_blocks(world_size, allowed, nodes, node_cpus)
+    mine = blocks[local_rank]
+    try:
+        os.sched_setaffinity(0, set(mine))
+    except OSError as exc:
+        return {"cores": allowed, "numa_node": None, "how": f"unpinned: {exc}"}
+    return {"cores": mine, "numa_node": nodes[local_rank] if how == "numa" else None, "how": how}
+
+
 # ---------------------------------------------------------------------------------------------- the timing group of a multi-rank job
 def _rccl_probe(device, world_size, timeout_s):
     """Create the RCCL (backend "nccl") group next to the gloo control group and prove it with one all-reduce.  Blocking and
@@ -100,8 +195,9 @@ def init_timing_group(backend, device, timeout_s=180.0, probe_wait_s=90.0, poll_
     anyone proceeds: a rank that fails says so through the store at once, every rank that sees a failure (its own, a peer's, or
     no result within probe_wait_s) stops waiting, and a MIN all-reduce over gloo makes the decision the same everywhere -- all
     ranks time over RCCL, or all fall back to gloo together within seconds; never a mixture (the ranks that succeeded would sit
-    in their next RCCL collective until its timeout).  clean = False says a probe thread was left behind blocked inside RCCL:
-    the caller must leave through os._exit() once its line is printed."""
+    in their next RCCL collective until its timeout).  clean = False says that something of RCCL was left behind in this process -- a
+    probe thread blocked inside it, or a communicator this rank created that the job does not adopt: the caller must leave through
+    os._exit() once its line is printed (no destructors, no joins)."""
     import datetime
     import threading
     import time
@@ -122,7 +218,9 @@ def init_timing_group(backend, device, timeout_s=180.0, probe_wait_s=90.0, poll_
             if device.type == "cuda":
                 torch.cuda.set_device(device)               # (the current device is per thread)
             _rccl_preflight(device)
-            box["group"] = _rccl_probe(device, world, timeout_s)
+            # (the probe group's own timeout is no longer than the wait below: a probe that is abandoned resolves -- RCCL's watchdog
+            # gives up on it -- before a measurement of the fallback path could be cut short by that watchdog's process abort)
+            box["group"] = _rccl_probe(device, world, min(timeout_s, probe_wait_s))
         except BaseException as exc:                        # noqa: BLE001 -- whatever RCCL raised, the fallback is the same
             box["error"] = f"{type(exc).__name__}: {str(exc)[:160]}"
             if store is not None:
@@ -151,4 +249,6 @@ def init_timing_group(backend, device, timeout_s=180.0, probe_wait_s=90.0, poll_
     why = box.get("error") or ("a peer rank reported a failure" if seen_peer_failure else
                                ("this rank's probe passed, another rank's did not" if mine_ok else f"no result within {probe_wait_s:.0f} s"))
     note = f"nccl (RCCL) did not come up on every rank ({why}); all ranks use gloo"
-    return None, "gloo", note[:200], not th.is_alive()
+    # clean only if nothing of RCCL is left in this process: no probe thread blocked inside it, and no communicator that was created
+    # here but is not going to be used (its peers failed: tearing it down at exit could wait for them)
+    return None, "gloo", note[:200], (not th.is_alive()) and "group" not in box

@@ -34,6 +34,7 @@ extern "C" {
 
 #define BSX_E_ARG (-1)     /* null pointer / bad size / unsupported n */
 #define BSX_E_ALIGN (-2)   /* a pointer is not aligned as documented */
+#define BSX_E_FAMILY (-3)  /* a discrete call on a state the continuous kernels have advanced, or the reverse (see bsx_step_continuous) */
 
 /* winner codes (battle_env.py:254,474,490: 'none' | 'red' | 'blue' | 'tie') */
 #define BSX_WINNER_NONE 0
@@ -106,8 +107,10 @@ int bsx_step_discrete(void* state, int64_t E, int n, const void* actions, int ac
 /* parallel_env.step, continuous actions (battle_env.py:295-297, :418-424).
  * A state block belongs to ONE action mode for its life, as a parallel_env does (battle_env.py:73 `continuous_actions`): the discrete
  * kernels keep headings as whole degrees inside the 8-byte plane record (reset spawns and the 15-degree turns are whole degrees), the
- * continuous kernels keep them as float64 beside it.  bsx_reset may be followed by either family; stepping a state the other family
- * has advanced is undefined (it reads the heading truncated to whole degrees). */
+ * continuous kernels keep them as float64 beside it.  bsx_state_init and a bsx_reset of ALL games (reset_mask == NULL) may be followed
+ * by either family; the first step / rollout call after that claims the block for its family, and a call of the OTHER family on it is
+ * refused with BSX_E_FAMILY (it would read headings truncated to whole degrees).  The claim is kept on the host per state address --
+ * nothing on the step path touches device memory for it; a block whose bytes the caller copied elsewhere is unclaimed there. */
 int bsx_step_continuous(void* state, int64_t E, int n, const void* actions, int action_kind, const double* u,
                         float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner,
                         const BsxRewards* cfg, uint32_t flags, uint64_t seed, int64_t env_offset, void* stream);

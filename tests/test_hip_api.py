@@ -137,7 +137,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert r["bound"] == ("hbm" if (r["frac_on_traffic"] or 0) >= 0.5 else "issue/latency")
     # the LAST key is the compact numeric summary of every BASELINE.json config (it must survive a truncated record of the line)
     assert list(d)[-1] == "baseline_configs" and d["baseline_configs"]["C2"]["agent_steps_per_s"] == round(d["value"])
-    assert len(json.dumps(d["baseline_configs"])) < 1200
+    assert len(json.dumps(d["baseline_configs"])) < 1800                       # (the driver keeps the last 2 000 characters of the line)
     # the figure to quote is the smaller of the contract fraction and the one on measured traffic; no fraction above 1 anywhere
     assert r["frac_claimed"] == min(v for v in (r["frac"], r["frac_on_traffic"]) if v is not None) and r["frac_claimed"] <= 1.0
     assert r["live_aware_bytes_per_launch"] < r["algorithmic_bytes_per_launch"]
@@ -220,3 +220,34 @@ def test_dropin_masked_reset_and_auto_reset_contract():
         _env(n_agents=1, auto_reset=True, rng="philox")
     with pytest.raises(ValueError):
         env.step_many(torch.zeros((2, 1, 2), dtype=torch.int32, device="cuda"))
+
+
+def test_a_state_block_belongs_to_one_action_family_and_the_abi_says_so():
+    """ABI 14 keeps discrete headings as whole degrees inside the plane record and continuous ones as float64 beside it: a discrete
+    call on a block the continuous kernels advanced would read truncated headings.  The C ABI refuses it (BSX_E_FAMILY, host-side, no
+    device work) until every game has been reset (battle_env.py:73: a parallel_env has one action mode for its life)."""
+    from deep_rl_battlespace_amd import _lib
+    E = 128
+    env = _env(n_agents=1, n_envs=E, seed=5, continuous_actions=True); env.reset()
+    act = torch.rand((E, 2, 3), device="cuda") * 2 - 1
+    env.step_batch(act)                                                      # the block is now a continuous one
+    lib = _lib.load()
+    ia = torch.zeros((E, 2), dtype=torch.int32, device="cuda")
+
+    def discrete_call():
+        return lib.bsx_step_discrete(env._p_state, E, 1, ia.data_ptr(), 0, None, env._p_obs, env._p_rew, env._p_done, env._p_env_done,
+                                     env._p_winner, env._cfg_ref, env._base_flags, env.seed, env.env_offset, env._stream())
+    before = env.state_dict()["state"].clone()
+    assert discrete_call() == -3                                             # BSX_E_FAMILY
+    with pytest.raises(ValueError, match="BSX_E_FAMILY"):
+        _lib.check(-3, "bsx_step_discrete")
+    torch.cuda.synchronize()
+    assert torch.equal(env.state_dict()["state"], before)                    # refused before any launch
+    env.step_batch(act)                                                      # its own family goes on
+    env.reset(mask=torch.arange(E, device="cuda") < 5)                       # a PARTIAL reset leaves fractional headings elsewhere
+    assert discrete_call() == -3
+    env.reset()                                                              # every game re-spawned: whole degrees, either family may follow
+    assert discrete_call() == 0
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="BSX_E_FAMILY"):                    # ... and now the block is a discrete one
+        env.step_batch(act)

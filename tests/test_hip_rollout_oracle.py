@@ -476,7 +476,12 @@ def test_one_launch_beyond_4v4_falls_through_to_the_graph(n):
     ros = []
     for one in (True, False):
         env = _env(n_agents=n, n_envs=E, seed=9, auto_reset=True); env.reset()
-        ro = PolicyRollout(env, actor, T, seed=4, noise_std=0.3, one_launch=one); ro.start(); ro.capture()
+        if one:                                             # the form asked for is not the one that runs: the constructor warns
+            with pytest.warns(RuntimeWarning, match="two-kernel graph"):
+                ro = PolicyRollout(env, actor, T, seed=4, noise_std=0.3, one_launch=True)
+        else:
+            ro = PolicyRollout(env, actor, T, seed=4, noise_std=0.3, one_launch=False)
+        ro.start(); ro.capture()
         ros.append(ro)
     a, b = ros
     assert a.one_launch is False and "two-kernel graph" in a.form_note and b.form_note is None

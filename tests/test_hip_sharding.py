@@ -37,6 +37,20 @@ def test_multi_rank_job_equals_the_single_process_job(tmp_path, world, per_rank)
     # every rank's own medians travel in the line (imbalance between shards would show here); the job's figure is not below any of them
     pr = two["per_rank"]
     assert len(pr["ms_per_step"]) == world and len(pr["avg_launch_us"]) == world and all(v > 0 for v in pr["ms_per_step"] + pr["avg_launch_us"])
+    # the N > 1 line beyond `value`: a device-time aggregate, the same-run single-shard reference and the efficiency
+    # against it, every rank's solo figures, min / median / max, the process group and the RCCL version.  On ONE card the ranks share
+    # the device, so the efficiency's VALUE says nothing here (it is ~1/N of a card each): only that it is there and consistent.
+    assert len(pr["solo_ms_per_step"]) == world and len(pr["solo_avg_launch_us"]) == world and all(v > 0 for v in pr["solo_ms_per_step"])
+    mmm = pr["ms_per_step_min_median_max"]
+    assert mmm["min"] <= mmm["median"] <= mmm["max"] and abs(mmm["max"] - max(pr["ms_per_step"])) < 1e-5
+    assert two["value_device"] > 0 and two["process_group"] == "gloo" and isinstance(two["rccl_version"], str)
+    ref = two["single_shard_reference"]
+    assert abs(ref["agent_steps_per_s"] - per_rank * 2 / (ref["ms_per_step"] * 1e-3)) / ref["agent_steps_per_s"] < 1e-3
+    assert abs(two["scaling_efficiency"] - two["value"] / (world * ref["agent_steps_per_s"])) < 2e-3 and 0 < two["scaling_efficiency"] < 1.5
+    assert two["scaling_efficiency_device"] > 0
+    assert two["host"]["pinning"] in ("numa", "plain") and two["host"]["cores_of_rank0"]           # rank 0 sits on its own block of cores
+    assert "scaling_efficiency" not in one and "value_device" not in one and one["host"]["pinning"].startswith("unpinned")
+    assert one["timing"]["unbarriered_ms_per_step"] > 0
     assert "per_rank" not in one and two["baseline_configs"][f"N{world}_x_{per_rank}_1v1"]["agent_steps_per_s"] == round(two["value"])
     metas = [json.load(open(os.path.join(d2, f"rank{r}.json"))) for r in range(world)]
     assert [m["env_offset"] for m in metas] == [r * per_rank for r in range(world)] and all(m["n_envs"] == per_rank and m["world"] == world for m in metas)

@@ -2,6 +2,7 @@
 validation happens before any device work, host-side draw order equals the reference's, sharding partitions exactly,
 and the multi-rank path (world_size 2, gloo) reduces counters correctly.  No kernel is launched here."""
 import ctypes
+import json
 import os
 import random
 import re
@@ -251,7 +252,8 @@ def test_rccl_probe_that_never_returns_is_bounded_and_agreed(tmp_path):
     res = _run_probe_case(tmp_path, "one_rank_hangs", wait_s=5)
     assert {r["backend"] for r in res.values()} == {"gloo"}, res
     assert "no result within" in res[1]["note"] and not res[1]["clean"]
-    assert all("another rank" in res[r]["note"] and res[r]["clean"] for r in (0, 2)), res
+    # (the ranks whose probe passed hold a group nobody will use: they too leave without tearing it down -- clean is False)
+    assert all("another rank" in res[r]["note"] and not res[r]["clean"] for r in (0, 2)), res
 
 
 def test_rccl_probe_passing_everywhere_hands_out_the_probed_group(tmp_path):
@@ -348,3 +350,79 @@ def test_bench_multi_gpu_launch_without_gpus_fails_loudly():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"],
                        capture_output=True, text=True, timeout=300, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE")})
     assert r.returncode != 0 and "--rehearse-on-device0" in (r.stderr + r.stdout)
+
+
+def test_rank_affinity_blocks_are_disjoint_and_follow_the_cards_numa_nodes(tmp_path):
+    """bench.py --gpus N pins every rank to its own host cores before its first GPU call (sharding.pin_rank_to_its_cores): the table
+    is a pure function of (world, allowed cores, the cards' NUMA nodes), so the ranks agree on it without talking."""
+    from deep_rl_battlespace_amd import sharding
+    allowed = list(range(256))
+    blocks, how = sharding.affinity_blocks(8, allowed)
+    assert how == "plain" and [len(b) for b in blocks] == [32] * 8 and blocks[3] == list(range(96, 128))
+    assert len(set().union(*map(set, blocks))) == 256                                     # disjoint and complete
+    # two sockets: cards 0-3 on node 0 (cores 0-63 + SMT siblings 128-191), cards 4-7 on node 1
+    node_cpus = {0: list(range(0, 64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}
+    blocks, how = sharding.affinity_blocks(8, allowed, [0, 0, 0, 0, 1, 1, 1, 1], node_cpus)
+    assert how == "numa" and all(len(b) == 32 for b in blocks)
+    assert all(set(blocks[r]) <= set(node_cpus[0 if r < 4 else 1]) for r in range(8))
+    assert sum(len(b) for b in blocks) == len(set().union(*map(set, blocks))) == 256
+    # interleaved card order, an uneven node, a restricted allowed set (a container's cpuset): still disjoint, still inside the node
+    blocks, how = sharding.affinity_blocks(5, range(10, 90), [1, 0, 1, 0, 0], {0: list(range(0, 48)), 1: list(range(48, 96))})
+    assert how == "numa" and sum(len(b) for b in blocks) == len(set().union(*map(set, blocks)))
+    assert set(blocks[0]) | set(blocks[2]) <= set(range(48, 90)) and set(blocks[1]) | set(blocks[3]) | set(blocks[4]) <= set(range(10, 48))
+    # a card without a node, or a node with fewer cores than ranks on it: the plain split
+    assert sharding.affinity_blocks(4, allowed, [0, None, 0, 0], node_cpus)[1] == "plain"
+    assert sharding.affinity_blocks(4, range(8), [0, 0, 0, 0], {0: [0, 1]})[1] == "plain"
+    # fewer cores than ranks: nothing to separate
+    assert sharding.affinity_blocks(8, range(4))[0] == [[0, 1, 2, 3]] * 8
+    assert sharding._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    # the sysfs reader, on a fake tree: two AMD cards (PCI order decides the rank) and a foreign one
+    for i, (pci, vendor, node) in enumerate((("0000:c1:00.0", "0x1002", 1), ("0000:05:00.0", "0x1002", 0), ("0000:03:00.0", "0x1a03", 0))):
+        d = tmp_path / "devices" / pci
+        d.mkdir(parents=True)
+        (d / "vendor").write_text(vendor + "\n"); (d / "numa_node").write_text(f"{node}\n")
+        c = tmp_path / "class" / "drm" / f"card{i}"
+        c.mkdir(parents=True)
+        os.symlink(d, c / "device")
+    assert sharding.card_numa_nodes(str(tmp_path)) == [0, 1]
+    # and the pinning itself, in child processes (this process keeps its cores): two ranks of a 2-rank job end up on disjoint sets
+    code = ("import os, sys, json; sys.path.insert(0, %r); from deep_rl_battlespace_amd import sharding; "
+            "r = sharding.pin_rank_to_its_cores(int(sys.argv[1]), 2, sysfs=%r); "
+            "print(json.dumps([r, sorted(os.sched_getaffinity(0))]))" % (ROOT, str(tmp_path / "nothing_here")))
+    got = [json.loads(subprocess.run([sys.executable, "-c", code, str(r)], capture_output=True, text=True, timeout=120, check=True).stdout) for r in range(2)]
+    if len(os.sched_getaffinity(0)) >= 2:
+        assert all(g[0]["cores"] == g[1] and g[0]["how"] == "plain" for g in got) and not set(got[0][1]) & set(got[1][1])
+
+
+def test_bench_line_helpers_survive_failed_variants_and_describe_a_multi_rank_job():
+    """(1) ADVICE r4: a rollout variant that failed is recorded as {"error": ...}; the compact summary (the line's last key) must turn
+    it into null instead of raising -- the line must always be printed.  (2) the N > 1 fields computed from per-rank samples."""
+    sys.path.insert(0, ROOT)
+    import bench
+    ev_tag = "reference evaluation workload (evaluate.py:32-76): 2v2, shipped checkpoints vs scripted instinct team"
+    out = {"value": 1.8e10, "policy_rollouts": {"variants": {ev_tag: {"error": "RuntimeError: boom"},
+                                                              "graph of 2 kernels per tick, both teams on actors": {"error": "x"},
+                                                              "one launch for all ticks, both teams on actors": {"agent_steps_per_s": 6.4e9, "us_per_tick": 20.3,
+                                                                                                                 "roofline": {"frac_mfma": 0.38, "bound": "mfma"}}}},
+           "other_workloads": {"configs[2] 65536 x 4v4": {"error": "y"}}, "multi_tick_launch": None, "cpu_baseline": None, "drop_in_one_game": {"error": "z"}}
+    s = bench.baseline_summary(out, 1, 65536, 1, 6.1e-3, 0.22)
+    assert s["eval_2v2"] is None and s["C5_graph"] is None and s["C3"] is None and s["C2"]["us"] == 6.1
+    assert s["C5_one_launch"]["agent_steps_per_s"] == 6400000000 and s["C5_one_launch"]["frac"] == 0.38
+    json.dumps(s)
+    ok = dict(out["policy_rollouts"]["variants"])
+    ok[ev_tag] = {"agent_steps_per_s": 7e9, "us_per_tick": 37.4, "win_rate_red": 0.84612, "win_rate_red_stale_first_obs": 0.8301}
+    out["policy_rollouts"]["variants"] = ok
+    s = bench.baseline_summary(out, 1, 65536, 1, 6.1e-3, 0.22)
+    assert s["eval_2v2"] == {"agent_steps_per_s": 7000000000, "us": 37.4, "red_win_rate": 0.8461, "red_win_rate_stale_first_obs": 0.8301}
+    # (2) four ranks, five samples each: rank 2's host was descheduled in its barriered blocks -- value pays, value_device does not
+    E, A, K = 65536, 2, 20
+    wall = lambda us: [us * K * 1e-6] * 5                                                    # noqa: E731
+    per_rank = {"head_walls": [wall(7.0), wall(7.1), wall(12.0), wall(7.0)], "head_kms": [[6.1e-3] * 5] * 4,
+                "head_solo_walls": [wall(7.0)] * 4, "head_solo_kms": [[6.1e-3] * 5] * 4}
+    value = 4 * E * A * K / (12.0 * K * 1e-6)
+    f = bench.multi_rank_fields(per_rank, 4, E, A, K, value, "gloo")
+    assert f["per_rank"]["ms_per_step"] == [0.007, 0.0071, 0.012, 0.007] and f["per_rank"]["ms_per_step_min_median_max"]["max"] == 0.012
+    assert abs(f["value_device"] - 4 * E * A / 6.1e-6) < 1 and f["process_group"] == "gloo" and "rccl_version" in f
+    assert abs(f["scaling_efficiency"] - 7.0 / 12.0) < 1e-3 and f["scaling_efficiency_device"] == 1.0
+    assert f["single_shard_reference"]["ms_per_step"] == 0.007
+    assert bench._ranges([0, 1, 2, 3, 8, 9, 11]) == "0-3,8-9,11" and bench._ranges(None) is None

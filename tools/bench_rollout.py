@@ -14,6 +14,7 @@ ap.add_argument("--T", type=int, default=32); ap.add_argument("--reps", type=int
 ap.add_argument("--noise", type=float, default=0.1); ap.add_argument("--torch-actor", action="store_true")
 ap.add_argument("--one-launch", action="store_true", help="all T ticks in one kernel (bsx_rollout_discrete; 1v1)")
 ap.add_argument("--precision", default="f32", choices=("f32", "bf16x3", "bf16x6"), help="the actor's 64 x 64 layer")
+ap.add_argument("--rollout-only", action="store_true", help="skip the env-alone and actor-alone graphs (counter passes: only the rollout's kernels run)")
 ap.add_argument("--scripted-blue", action="store_true", help="blue is the scripted opponent (instinct.Team), red the actor: main.py:119-122")
 args = ap.parse_args()
 E, n, T = args.envs, args.n_agents, args.T
@@ -44,6 +45,9 @@ def timed(fn, reps):
 
 
 t_roll = timed(ro.run, args.reps) / T
+if args.rollout_only:
+    print(json.dumps({"rollout_us_per_tick": round(t_roll * 1e6, 2), "rollout_agent_steps_per_s": round(E * A / t_roll, 1)}))
+    sys.exit(0)
 # env alone (same score-vector input path), actor alone
 g_env, _ = env.capture_steps(ro.scores)
 t_env = timed(g_env.replay, args.reps) / T
