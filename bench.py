@@ -1062,6 +1062,20 @@ def evaluation_line(dev, E, precision="f32"):
         samples.append((time.perf_counter() - t0) / (8 * 32))
     dt = statistics.median(samples)
     ref = {k: int(g12[k]) for k in ("games", "ties", "red_wins", "blue_wins")}
+    # the same workload WITH the script's quirk (evaluate.py:53-66: a game's first tick sees the observations of a discarded reset),
+    # tick by tick; and how far each tally is from the reference's own, in standard deviations of ITS sample (3 018 games)
+    p_ref = ref["red_wins"] / ref["games"]
+    sigma = (p_ref * (1 - p_ref) / ref["games"]) ** 0.5
+    stale = None
+    if precision == "f32":
+        del ro
+        env2 = bsx.parallel_env(n_agents=n, n_envs=E, auto_reset=True, seed=1234, device=dev, **cf)
+        stale = play_reference_evaluation(env2, actor, games=3 * E, T=32, seed=12, precision=precision, first_tick_stale_obs=True)
+        stale.pop("rollout")
+        stale["sigmas_from_reference_tally"] = round((stale["win_rate_red"] - p_ref) / sigma, 2)
+        res["win_rate_red_stale_first_obs"] = round(stale["win_rate_red"], 5)
+    res["sigmas_from_reference_tally"] = round((res["win_rate_red"] - p_ref) / sigma, 2)
+    res["with_the_scripts_stale_first_observation"] = stale
     return {**res, "agent_steps_per_s": round(E * 2 * n / dt, 1), "us_per_tick": round(dt * 1e6, 3), "games_per_s": round(res["games"] / (res["ticks"] * dt), 1),
             "roofline": rollout_roofline(dt * 1e6, E * n, 3 * n + 2, 4, precision),
             "envs": E, "n_agents_per_team": n, "ticks_per_launch": 32,

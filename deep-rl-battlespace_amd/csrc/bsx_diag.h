@@ -57,6 +57,14 @@ constexpr int X_OBS_PLAIN_FROM = BSX_X_OBS_PLAIN_FROM;
 #endif
 constexpr int X_ATAN_TABLE_MAX_K = BSX_X_ATAN_TABLE_MAX_K;
 
+// -DBSX_X_OPAQUE_MULTI_MASK=<bits>: bit n set = the multi-tick kernels of n-v-n with int32 actions recompute their lane-derived LDS / row
+// addresses per tick instead of carrying them across the tick loop, bit 8 + n = those with score rows or continuous actions (product:
+// 0x1C18 = 3v3, 4v4; 2v2 ... 4v4; same results)
+#ifndef BSX_X_OPAQUE_MULTI_MASK
+#define BSX_X_OPAQUE_MULTI_MASK 0x1C18
+#endif
+constexpr int X_OPAQUE_MULTI_MASK = BSX_X_OPAQUE_MULTI_MASK;
+
 #ifdef BSX_STAMPS
 constexpr int BUILD_FLAGS = int(DIAG & 0xFFu) | 0x100;
 __device__ unsigned long long* g_stamps = nullptr;

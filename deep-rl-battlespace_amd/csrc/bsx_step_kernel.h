@@ -320,7 +320,13 @@ void bsx_step_kernel(const int64_t E_, const uint2* const envc_, const uint2* co
     // that the ~35 LDS / row addresses derived from them (pair slots, enemy lanes, staging rows) are per-tick work next to their use
     // instead of registers held across the actor's matrix products -- with them hoisted the kernels spilled to scratch memory.
     int tid_k = tid;
-    if constexpr (ACTOR && N > 1) asm volatile("" : "+v"(tid_k));
+    // The multi-tick kernels of larger teams likewise (round 5): with ~20 ... 35 hoisted LDS addresses the 2v2 kernels that take score rows
+    // or continuous actions (compiled for four waves per SIMD = 128 registers) kept 2 ... 7 registers in scratch memory, and 3v3 / 4v4
+    // stood at 135 ... 161 registers = three resident waves; recomputed per tick: 2v2 93 ... 106 without scratch, 3v3 / 4v4 104 ... 122 =
+    // four waves (per tick, same box: 3v3 12.19 -> 11.56 us, 4v4 16.9 -> 16.8, 2v2 continuous 8.80 -> 8.53, 4v4 continuous 21.5 -> 19.7).
+    // Not 1v1 (3.06 -> 3.10) and not 2v2 with int32 actions (5.03 -> 5.31: that kernel fitted as it was).  X_OPAQUE_MULTI_MASK: bit n =
+    // the n-v-n kernels with int32 actions, bit 8 + n = those with score rows or continuous actions.
+    if constexpr ((ACTOR && N > 1) || (MULTI && !ACTOR && N > 0 && ((X_OPAQUE_MULTI_MASK >> (((LG || CONT) ? 8 : 0) + N)) & 1))) asm volatile("" : "+v"(tid_k));
     // The kernel's arguments likewise: ~60 scalar registers of pointers, strides and reward constants were held across the tick
     // loop, ~40 of them spilled to VGPR lanes before it and read back one v_readlane at a time in every tick (78 of them at
     // 1v1).  Inside a tick the arguments are read through the kernarg segment's own address, made opaque per tick: scalar loads

@@ -461,18 +461,44 @@ def reference_checkpoint_actor(fixture, n_agents_per_team=2, device="cuda"):
     return actor
 
 
-def play_reference_evaluation(env, actor, games, T=32, one_launch=True, precision="f32", seed=0, ou_scale=0.1):
+def play_reference_evaluation(env, actor, games, T=32, one_launch=True, precision="f32", seed=0, ou_scale=0.1, first_tick_stale_obs=False):
     """The reference's evaluation workload (evaluate.py:32-76; README.md:30 quotes "~80 %" for it) for every game slot of `env` at
     once: red = `actor` through maddpg/agent.py:25-33 -- tanh scores + Ornstein-Uhlenbeck noise of scale 0.1 (utils/noise.py's
     default, which evaluate.py never rescales) that is NEVER restarted (evaluate.py never calls reset_noise) -> clamp -> arg-max --,
     blue = the scripted instinct.Team, finished games re-spawned in place.  Plays whole rollouts of T ticks until at least `games`
     games are over and returns the tally from the env's own counters (battle_env.py:102-103,169-170,449-455).
-    One difference to the script is kept out on purpose: evaluate.py resets the env twice per game and feeds the FIRST reset's
-    observations to the first tick (evaluate.py:53-66), i.e. one action in ~100 is chosen on another game's spawn."""
+    One difference to the script is kept out by default: evaluate.py resets the env twice per game and feeds the FIRST reset's
+    observations to the first tick (evaluate.py:53-66), i.e. every plane's first action of a game -- one in ~40 -- is chosen on
+    another game's spawn.  first_tick_stale_obs=True reproduces it: a second env of the same shape does nothing but draw spawns, and
+    the first tick of every game sees ITS observations (both teams, as in the script); that form runs tick by tick (actor launch,
+    scripted team, step launch -- the two-kernel form, eagerly), since the substitution sits between a step and the next actor pass."""
     from . import instinct
     if env.n_envs < 1 or not env.auto_reset or env.continuous_actions:
         raise ValueError("the evaluation workload needs a batched discrete env with auto_reset=True")
     opp = instinct.Team(env.possible_blue, env.possible_red, env)
+    if first_tick_stale_obs:
+        from .envs.battle_env import parallel_env
+        decoy = parallel_env(n_agents=env.n_agents, n_envs=env.n_envs, device=env.device, seed=env.seed + 0x5EED, env_offset=env.env_offset)
+        ro = PolicyRollout(env, actor, 1, opponent=opp, ou_scale=ou_scale, ou_restart=False, one_launch=False, precision=precision, seed=seed)
+        c0 = env.counters().sum(0)
+        env.reset()
+        ro.start()
+        fresh = torch.ones(env.n_envs, dtype=torch.bool, device=env.device)       # every slot's first game starts on the discarded reset's rows too
+        ticks = 0
+        while True:
+            for _ in range(T):
+                ro.obs[0].copy_(ro.obs[1]); ro.env_done[0].copy_(ro.env_done[1])  # (what PolicyRollout._body does around its ticks)
+                decoy.reset()                                                     # evaluate.py:53: the reset whose observations the first tick gets
+                ro.obs[0][fresh] = decoy._obs[fresh]
+                ro._tick(0)
+                env._env_done.copy_(ro.env_done[1]); ro._seq_base.add_(1)
+                fresh = (ro.env_done[0] != 0) & (ro.env_done[1] == 0)             # this call re-spawned the game (evaluate.py:64): its next tick is a first tick
+            ticks += T
+            c = env.counters().sum(0) - c0
+            if c[0] >= games:
+                break
+        return {"games": int(c[0]), "ties": int(c[1]), "red_wins": int(c[2]), "blue_wins": int(c[3]), "win_rate_red": float(c[2]) / float(c[0]),
+                "ticks": ticks, "rollout": ro}
     ro = PolicyRollout(env, actor, T, opponent=opp, ou_scale=ou_scale, ou_restart=False, one_launch=one_launch, precision=precision, seed=seed)
     c0 = env.counters().sum(0)
     env.reset()

@@ -426,3 +426,21 @@ def test_bench_line_helpers_survive_failed_variants_and_describe_a_multi_rank_jo
     assert abs(f["scaling_efficiency"] - 7.0 / 12.0) < 1e-3 and f["scaling_efficiency_device"] == 1.0
     assert f["single_shard_reference"]["ms_per_step"] == 0.007
     assert bench._ranges([0, 1, 2, 3, 8, 9, 11]) == "0-3,8-9,11" and bench._ranges(None) is None
+
+
+def test_no_kernel_of_the_product_build_keeps_registers_in_scratch_memory():
+    """round 4's `amdgpu_waves_per_eu(4)` on the multi-tick 2v2 kernels left three of them with 2 ... 7 vector
+    registers in scratch memory, touched every tick, and nothing noticed.  The product's translation units are compiled to assembly
+    here (hipcc cross-compiles without a GPU; tools/isa_meta.py) and every kernel's metadata must say: no spilled VGPR, no private
+    segment.  The committed table (profiles/r05_isa_meta.json) must be the one this tree compiles to."""
+    with __import__("tempfile").TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "meta.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_meta.py"), "--json", out], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        meta = json.load(open(out))
+    assert len(meta) >= 80 and sum(1 for k in meta if k.startswith("bsx_step_kernel<")) >= 70          # every instance of the step kernel is in the table
+    bad = {k: v for k, v in meta.items() if v["vgpr_spill_count"] or v["private_segment_fixed_size"]}
+    assert not bad, bad
+    assert all(v["vgpr_count"] <= 256 for v in meta.values())
+    committed = json.load(open(os.path.join(ROOT, "profiles", "r05_isa_meta.json")))
+    assert committed == meta, sorted(k for k in set(meta) | set(committed) if meta.get(k) != committed.get(k))[:6]

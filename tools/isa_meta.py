@@ -76,13 +76,16 @@ def compile_product(tmp):
     spec = importlib.util.spec_from_file_location("_bsx_build", os.path.join(ROOT, "deep-rl-battlespace_amd", "build.py"))
     B = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(B)
-    files = []
-    for src, extra in B.SOURCES:
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(job):
+        src, extra = job
         out = os.path.join(tmp, os.path.basename(src) + ".s")
         subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), *B.COMMON, *extra, "-I", B.INCLUDE, "--cuda-device-only", "-S", src, "-o", out],
-                       check=True)
-        files.append(out)
-    return files
+                       check=True, stderr=subprocess.DEVNULL)
+        return out
+    with ThreadPoolExecutor(max_workers=4) as ex:            # the translation units compile side by side, as in build.py
+        return list(ex.map(one, B.SOURCES))
 
 
 def main(argv):

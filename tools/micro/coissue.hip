@@ -89,6 +89,39 @@ PAIR(p_mix_mix, MIX_8V3S, MIX_8V3S)
 PAIR(p_mixdep_mixdep, MIX_DEP, MIX_DEP)
 PAIR(p_ind3_ind3, V_IND3, V_IND3)
 PAIR(p_ind3_sadd, V_IND3, S_ADD)
+// part 2 only: one instruction class per kernel (B unused)
+#define ONE(name, body) PAIR(name, body, S_NOP)
+ONE(o_add_u32, "v_add_u32 %3, %3, %4")
+ONE(o_and_or, "v_and_or_b32 %3, %3, %4, %5")
+ONE(o_bfe, "v_bfe_u32 %3, %3, 3, 27")
+ONE(o_cndmask, "v_cndmask_b32 %3, %3, %4, vcc")
+ONE(o_cmp_u32, "v_cmp_lt_u32 vcc, %3, %4")
+ONE(o_cmp_f64, "v_cmp_lt_f64 vcc, %0, %1")
+ONE(o_mul_lo, "v_mul_lo_u32 %3, %3, %4")
+ONE(o_mul_hi, "v_mul_hi_u32 %3, %3, %4")
+ONE(o_mul_u24, "v_mul_u32_u24 %3, %3, %4")
+ONE(o_mad_u64, "v_mad_u64_u32 %0, vcc, %3, %4, %0")
+ONE(o_add_f64, "v_add_f64 %0, %0, %1")
+ONE(o_mul_f64, "v_mul_f64 %0, %0, %1")
+ONE(o_fma_f64_ind, "v_fma_f64 %0, %1, %2, %0\n\tv_fma_f64 %1, %1, %2, %1")
+ONE(o_rcp_f64, "v_rcp_f64 %0, %0")
+ONE(o_rsq_f64, "v_rsq_f64 %0, %0")
+ONE(o_cvt_f64_i32, "v_cvt_f64_i32 %0, %3")
+ONE(o_cvt_i32_f64, "v_cvt_i32_f64 %3, %0")
+ONE(o_cvt_f32_f64, "v_cvt_f32_f64 %3, %0")
+ONE(o_ldexp_f64, "v_ldexp_f64 %0, %0, 1")
+ONE(o_fma_f32, "v_fma_f32 %3, %3, %4, %5")
+ONE(o_pk_add_i16, "v_pk_add_i16 %3, %3, %4")
+ONE(o_bitop3, "v_bitop3_b32 %3, %3, %4, %5 bitop3:0x96")
+ONE(o_dpp, "v_mov_b32_dpp %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+ONE(o_readlane, "v_readfirstlane_b32 s20, %3")
+ONE(o_mbcnt, "v_mbcnt_lo_u32_b32 %3, vcc_lo, %3")
+ONE(o_smov, "s_mov_b32 s20, 0x12345678")
+ONE(o_sand64, "s_and_b64 s[22:23], s[22:23], exec")
+ONE(o_scmp_br, "s_cmp_eq_u32 s20, 77\n\ts_cbranch_scc1 1f\n1:")
+ONE(o_saveexec, "s_and_saveexec_b64 s[22:23], vcc\n\ts_or_b64 exec, exec, s[22:23]")
+ONE(o_bperm, "ds_bpermute_b32 %5, %6, %3\n\ts_waitcnt lgkmcnt(0)")
+ONE(o_lds_wr_rd, "ds_write_b32 %6, %3\n\tds_read_b32 %5, %6\n\ts_waitcnt lgkmcnt(0)")
 
 typedef void (*kern_t)(Rec*, const unsigned*, double, int);
 struct P { const char* a; const char* b; kern_t k; int na, nb; };
@@ -147,7 +180,16 @@ int main() {
     struct S { const char* name; kern_t k; int instr; };
     S same[] = {{"v_xor dep", p_valu_valu, 1}, {"v_fma_f64 dep", p_fma_sadd, 1}, {"s_add_u32 dep", p_sadd_sadd, 1}, {"3 indep VALU chains (xor, add, fma64)", p_ind3_ind3, 3},
                 {"8 VALU (2 of them fma64) + 3 SALU indep", p_mix_mix, 11}, {"8 VALU + 3 SALU, scalar feeds vector", p_mixdep_mixdep, 11},
-                {"ballot group (v_cmp > s_and > v_cndmask)", p_ballot_ballot, 3}, {"masked group (cmp, saveexec, valu, s_or)", p_masked_masked, 4}};
+                {"ballot group (v_cmp > s_and > v_cndmask)", p_ballot_ballot, 3}, {"masked group (cmp, saveexec, valu, s_or)", p_masked_masked, 4},
+                {"v_add_u32 dep", o_add_u32, 1}, {"v_and_or_b32 dep", o_and_or, 1}, {"v_bfe_u32 dep", o_bfe, 1}, {"v_cndmask_b32 (vcc) dep", o_cndmask, 1},
+                {"v_cmp_lt_u32 > vcc", o_cmp_u32, 1}, {"v_cmp_lt_f64 > vcc", o_cmp_f64, 1}, {"v_mul_lo_u32 dep", o_mul_lo, 1}, {"v_mul_hi_u32 dep", o_mul_hi, 1},
+                {"v_mul_u32_u24 dep", o_mul_u24, 1}, {"v_mad_u64_u32 dep", o_mad_u64, 1}, {"v_add_f64 dep", o_add_f64, 1}, {"v_mul_f64 dep", o_mul_f64, 1},
+                {"v_fma_f64 x2 independent", o_fma_f64_ind, 2}, {"v_rcp_f64 dep", o_rcp_f64, 1}, {"v_rsq_f64 dep", o_rsq_f64, 1}, {"v_cvt_f64_i32", o_cvt_f64_i32, 1},
+                {"v_cvt_i32_f64", o_cvt_i32_f64, 1}, {"v_cvt_f32_f64", o_cvt_f32_f64, 1}, {"v_ldexp_f64 dep", o_ldexp_f64, 1}, {"v_fma_f32 dep", o_fma_f32, 1},
+                {"v_pk_add_i16 dep", o_pk_add_i16, 1}, {"v_bitop3_b32 dep", o_bitop3, 1}, {"v_mov_b32_dpp quad_perm dep", o_dpp, 1},
+                {"v_readfirstlane_b32", o_readlane, 1}, {"v_mbcnt_lo dep", o_mbcnt, 1}, {"s_mov_b32 literal", o_smov, 1}, {"s_and_b64 dep", o_sand64, 1},
+                {"s_cmp + s_cbranch_scc1 (not taken) [/2]", o_scmp_br, 2}, {"s_and_saveexec + s_or exec [/2]", o_saveexec, 2},
+                {"ds_bpermute + wait [/grp of 1]", o_bperm, 1}, {"ds_write + ds_read + wait [/grp of 2]", o_lds_wr_rd, 2}};
     printf("\nN waves per SIMD, same stream, barrier start: per-SIMD span in shader cycles per body copy, and per INSTRUCTION issued by the SIMD (span / (N x instructions per copy))\n");
     printf("%-48s | %10s %10s %10s | %10s %10s %10s\n", "stream", "N=1 /copy", "N=2", "N=4", "N=1 /instr", "N=2", "N=4");
     for (auto& t : same) {
