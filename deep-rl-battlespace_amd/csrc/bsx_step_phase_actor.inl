@@ -2,6 +2,11 @@
 // kernel's locals, so this is a textual unit for reading and review, not a function): fused rollout only (ACTOR): this tick's actions = arg-max / squash of actor(obs) on the wave's LDS observation rows (MFMA, bsx_actor_core.h), or the
 // scripted opponent's.  Reads: s_obs_all, s_small, er.done, p (weights, noise, seeds).  Writes: act (discrete) or a0, a1, a2 (continuous), p.scores,
 // p.nz.logp / value.  Compiles to nothing in the per-step and multi-tick kernels.
+// The contract (tools/check_phase_contract.py checks it against this file's text in the CPU suite; names are the kernel's locals):
+// @reads -
+// @writes  a0 a1 a2 act
+// @exports -
+// @lds     s_act_all s_gdone_all
     if constexpr (ACTOR) {
         // ---- actions = argmax(actor(obs)) (maddpg/agent.py:25-33, battle_env.py:327-328), rows straight from LDS
         constexpr int D = 3 * N + 2, A_ = 2 * N, G_ = group_width(N);

@@ -2,6 +2,11 @@
 // kernel's locals, so this is a textual unit for reading and review, not a function): Bullet.update (sprites.py:321-351) for every work slot of the wave (part 2 of the wave-packed pass: move, miss / base / plane-overlap tests,
 // compaction of the pool) and the ordered plane-hit resolve (battle_env.py:332-360).  Reads: pool_first / the pool, s_new, s_eb, s_pq, s_fl, slots, pc.
 // Writes: the pool and its count, nmiss, nbase, nplane (+ the enemy's: nplane_other, nbase_other), s_hp / s_bhit (n >= 2), tombstones.
+// The contract (tools/check_phase_contract.py checks it against this file's text in the CPU suite; names are the kernel's locals):
+// @reads   nhp_ pool_pass slots
+// @writes  pc
+// @exports nbase nbase_other nmiss nplane nplane_other
+// @lds     s_agg s_bhit s_hp s_ov s_pp
     PSTAMP(4);
     // ---- Bullet.update (sprites.py:321-351) per work slot, predicates as integer sign masks (0 / -1).
     uint64_t ovl[OW];

@@ -1,6 +1,11 @@
 // bsx_step_phase_geometry.inl -- a PHASE of bsx_step_kernel's tick (bsx_step_kernel.h includes it inside the kernel body, in tick order; it shares the
 // kernel's locals, so this is a textual unit for reading and review, not a function): observation geometry (battle_env.py:202-244): range and angle-off to the enemy base and every enemy plane in binary64 (bsx_geometry.h), each
 // red-blue pair once for n >= 2; also stores a flagged shot's float64 step (exact path).  Reads: post-move poses.  Writes: ob_d, ob_a, oe_d[], oe_a[], ex[], ey[].
+// The contract (tools/check_phase_contract.py checks it against this file's text in the CPU suite; names are the kernel's locals):
+// @reads   CHEAP_SHOT ks nbdir nexact nx_ ny_ shot_exact spawn
+// @writes  nd
+// @exports ob_a ob_d oe_a oe_d
+// @lds     s_nd s_pd s_pr
     PSTAMP(3);
     // ---- observation geometry (battle_env.py:202-244) from the staged block, BEFORE the bullets: poses are final after
     //      the move, only the alive flags can still change; this fp64 math runs while the bullet-step loads are in flight.

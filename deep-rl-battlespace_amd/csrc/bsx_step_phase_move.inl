@@ -2,6 +2,11 @@
 // kernel's locals, so this is a textual unit for reading and review, not a function): in-kernel re-spawn (M_RESET) or process_action's move (battle_env.py:383-424), then the hand-off of post-move poses to the game's other planes
 // (1v1: DPP; larger teams: wave-private LDS) and the planes' sprites as rectangles for the work slots.  Writes: x, y, dir, hp, er (re-spawn),
 // nx_, ny_, nhp_ (1v1), s_x, s_y, s_hp, s_bhit, s_pq.
+// The contract (tools/check_phase_contract.py checks it against this file's text in the CPU suite; names are the kernel's locals):
+// @reads   alive0 dir_rot dl mode rw
+// @writes  a0 a1 dir er hp tick x y
+// @exports nhp_ nx_ ny_
+// @lds     s_bhit s_hp s_pq s_x s_y
     STAMP(2);
     if (mode == M_RESET) {
         // re-spawn in place of the inert call; episode id = games played so far.  My block holds my pose and (first plane of a team) my

@@ -1,6 +1,11 @@
 // bsx_step_phase_outcome.inl -- a PHASE of bsx_step_kernel's tick (bsx_step_kernel.h includes it inside the kernel body, in tick order; it shares the
 // kernel's locals, so this is a textual unit for reading and review, not a function): rewards (battle_env.py:337-359), deaths, base hit points, win / tie (:363-372, :469-496).  Reads: nmiss, nbase, nplane, *_other, mode, tick.
 // Writes: rew, hp, alive, er (hit points, tick, done, winner), cnt_delta.
+// The contract (tools/check_phase_contract.py checks it against this file's text in the CPU suite; names are the kernel's locals):
+// @reads   alive0 mode nbase nbase_other nmiss nplane nplane_other tick
+// @writes  cnt_delta er hp
+// @exports alive rew
+// @lds -
     // ---- rewards (battle_env.py:337-359), deaths, bases, win / tie (:363-372, :469-496)
     double rew = double(nmiss) * p.cfg.miss_punishment + double(nbase) * p.cfg.hit_base_reward +
                  double(nplane) * p.cfg.hit_plane_reward;

@@ -2,6 +2,11 @@
 // kernel's locals, so this is a textual unit for reading and review, not a function): heading-table gather, call classification (inert / auto-reset / tie / physics), the shot (Bullet.__init__, sprites.py:293-318) and part 1 of
 // the wave-packed bullet pass (shots queued in LDS behind the pool).  Reads: the T0 records (x, y, hp, dir, er, games, act / a0..a2, pc).  Writes: mode,
 // tick, spawn, phys, ks, dl, dir_rot, slots, pool_pass, shot_exact, nd / nbdir / ncode / nexact, s_agg, s_eb, s_fl, s_new, bdir ring.
+// The contract (tools/check_phase_contract.py checks it against this file's text in the CPU suite; names are the kernel's locals):
+// @reads -
+// @writes  a2 rin_next
+// @exports CHEAP_SHOT alive0 cnt_delta dir_rot dl ks mode nbdir nd nexact pool_pass rw shot_exact slots spawn tick
+// @lds     s_agg s_eb s_fl s_new
     // ================= T1: the heading-table entry -- the one dependent load of the common path =====================
     // The heading table (361 x 16 B, read by every wave of every launch) stays hot in each CU's L1: the entry for the
     // post-rotation heading is gathered as soon as the action is known, so the plane can move while the shot is prepared.

@@ -1,6 +1,11 @@
 // bsx_step_phase_stores.inl -- a PHASE of bsx_step_kernel's tick (bsx_step_kernel.h includes it inside the kernel body, in tick order; it shares the
 // kernel's locals, so this is a textual unit for reading and review, not a function): write-back: plane and game records, reward, done flag, the observation row (straight from registers, or through LDS in the fused rollout and
 // the runtime-n kernel), counters by atomics at a game's end, the pool count of a multi-tick launch.
+// The contract (tools/check_phase_contract.py checks it against this file's text in the CPU suite; names are the kernel's locals):
+// @reads   alive cnt_delta mode nhp_ nplane ob_a ob_d oe_a oe_d rew
+// @writes  din_next
+// @exports -
+// @lds -
     PSTAMP(6);
     if (MULTI && !ACTOR && tk + 1 < p.T) din_next = decode(rin_next);   // the prefetch has long arrived; no store of this tick is out yet
     // ---- write back (MULTI: plane and game records travel in registers; memory gets them once, after the last tick)

@@ -444,3 +444,27 @@ def test_no_kernel_of_the_product_build_keeps_registers_in_scratch_memory():
     assert all(v["vgpr_count"] <= 256 for v in meta.values())
     committed = json.load(open(os.path.join(ROOT, "profiles", "r05_isa_meta.json")))
     assert committed == meta, sorted(k for k in set(meta) | set(committed) if meta.get(k) != committed.get(k))[:6]
+
+
+def test_phase_files_keep_their_read_write_contract(tmp_path):
+    """the step kernel's tick is seven textual phase files that share ~40 kernel locals.  Each opens with what it
+    reads, writes, exports and which LDS arrays it stores to, and tools/check_phase_contract.py holds the text to it: a phase that
+    assigns a kernel local (or an earlier phase's value) it does not declare as written, or drops an export, fails here."""
+    tool = os.path.join(ROOT, "tools", "check_phase_contract.py")
+    r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "7 phase files checked, 0 violation(s)" in r.stdout, r.stdout[-2000:]
+    # and it does catch what it is there for: a doctored copy in which the geometry phase quietly zeroes the plane's hit points and
+    # the outcome phase no longer declares `alive`
+    import shutil
+    csrc = os.path.join(ROOT, "deep-rl-battlespace_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.startswith("bsx_step_phase_") or f == "bsx_step_kernel.h":
+            shutil.copy(os.path.join(csrc, f), tmp_path / f)
+    g = tmp_path / "bsx_step_phase_geometry.inl"
+    g.write_text(g.read_text() + "\n    hp = 0;\n    s_fl[tid] |= 64u;\n")
+    o = tmp_path / "bsx_step_phase_outcome.inl"
+    o.write_text(o.read_text().replace("// @exports alive rew", "// @exports rew"))
+    r = subprocess.run([sys.executable, tool, "--csrc", str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1
+    assert "bsx_step_phase_geometry.inl: @writes misses ['hp']" in r.stdout and "bsx_step_phase_geometry.inl: @lds misses ['s_fl']" in r.stdout
+    assert "bsx_step_phase_outcome.inl: @exports misses ['alive']" in r.stdout, r.stdout
