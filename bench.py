@@ -1050,8 +1050,12 @@ def evaluation_line(dev, E, precision="f32"):
     n = int(g12["n_agents"])
     actor = reference_checkpoint_actor(g12, n, device=dev)
     env = bsx.parallel_env(n_agents=n, n_envs=E, auto_reset=True, seed=1234, device=dev, **cf)
-    res = play_reference_evaluation(env, actor, games=3 * E, T=32, one_launch=True, seed=12, precision=precision)   # ~3 games per slot: past the start-up transient
-    ro = res.pop("rollout")
+    # the tally: exactly the first 3 games of every slot (whole games, as the script plays them one after another; stopping all slots
+    # at one moment would over-count short games), looked at every 4 ticks; the timing below: 32 ticks per launch
+    res = play_reference_evaluation(env, actor, games=0, T=4, one_launch=True, seed=12, precision=precision, games_per_slot=3)
+    res.pop("rollout")
+    res["tally"] = "the first 3 games of each of the %d slots" % E
+    ro = play_reference_evaluation(env, actor, games=1, T=32, one_launch=True, seed=13, precision=precision).pop("rollout")
     torch.cuda.synchronize(dev)
     samples = []
     for _ in range(3):
@@ -1070,7 +1074,7 @@ def evaluation_line(dev, E, precision="f32"):
     if precision == "f32":
         del ro
         env2 = bsx.parallel_env(n_agents=n, n_envs=E, auto_reset=True, seed=1234, device=dev, **cf)
-        stale = play_reference_evaluation(env2, actor, games=3 * E, T=32, seed=12, precision=precision, first_tick_stale_obs=True)
+        stale = play_reference_evaluation(env2, actor, games=0, T=4, seed=12, precision=precision, first_tick_stale_obs=True, games_per_slot=3)
         stale.pop("rollout")
         stale["sigmas_from_reference_tally"] = round((stale["win_rate_red"] - p_ref) / sigma, 2)
         res["win_rate_red_stale_first_obs"] = round(stale["win_rate_red"], 5)

@@ -4,7 +4,8 @@
 // it without BSX_ALLOW_DIAG=1).  Never part of libbattlespace_hip.so.
 //
 //   -DBSX_DIAG=<bits>   timing-only ablations, results are WRONG with any bit set: 1 = skip observation math, 2 = skip the bullet
-//                       loop, 4 = skip the ordered resolve, 8 = no Philox draw for the shot's jitter, 16 = the per-game counters are not loaded
+//                       loop, 4 = skip the ordered resolve, 8 = no Philox draw for the shot's jitter, 16 = the per-game counters are not loaded, 32 = no heading-table gather (the move's step is
+//                       made up from the heading: what the one dependent load of the common path costs)
 //   -DBSX_STAMPS        lane 0 of every wave stores s_memtime at 10 points into a debug buffer (bsx_debug_set_stamps) that nothing
 //                       else reads; a stamped build is for reading SHARES, not run time
 //   -DBSX_STAMPS -DBSX_STAMPS_FINE   stamps 3..6 move INSIDE the shot phase (after the shot ballot / the Philox draw / sincos / the

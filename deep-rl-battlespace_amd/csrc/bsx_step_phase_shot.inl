@@ -13,7 +13,8 @@
     double dir_rot = dir;
     if (!CONT) dir_rot = rotate_dir(dir, act == 2 ? 15.0 : (act == 3 ? -15.0 : 0.0));   // one straight-line rotate (+0 leaves any heading in [0, 360] as it is)
     double2 dl = make_double2(0.0, 0.0);
-    if (!CONT) dl = p.st.lut[min(max(int(dir_rot), 0), 360)];   // 21.5*cos(-radians(d)), 21.5*sin(-radians(d)) from host libm
+    if (!CONT && !(DIAG & 32u)) dl = p.st.lut[min(max(int(dir_rot), 0), 360)];   // 21.5*cos(-radians(d)), 21.5*sin(-radians(d)) from host libm
+    if (!CONT && (DIAG & 32u)) dl = make_double2(dir_rot * 0.05, 21.5 - dir_rot * 0.05);   // (timing-only variant: no dependent gather; wrong moves)
     if (MULTI && !ACTOR && tk + 1 < p.T) load_inputs(tk + 1, rin_next);   // behind this tick's own loads: nothing waits for it before the tick ends
     const bool alive0 = valid && hp > 0;
     STAMP(1);

@@ -461,7 +461,32 @@ def reference_checkpoint_actor(fixture, n_agents_per_team=2, device="cuda"):
     return actor
 
 
-def play_reference_evaluation(env, actor, games, T=32, one_launch=True, precision="f32", seed=0, ou_scale=0.1, first_tick_stale_obs=False):
+class _FirstGamesTally:
+    """The outcome of exactly the FIRST k games of every slot (the env's own per-slot counters, frozen when a slot's k-th game ends).
+    Stopping all slots at one moment and counting what has finished by then over-counts short games -- each slot's unfinished game is
+    dropped, and the longer a game the likelier it is the dropped one -- whereas the reference plays N whole games one after another
+    (evaluate.py:52).  Checked every few ticks (fewer than a game can last), so a slot passes k by one game at a time; the rare call
+    that ends two games at once (both bases in one step, battle_env.py:363-372) is taken whole."""
+
+    def __init__(self, env, k):
+        import numpy as np
+        self.k, self.c0 = int(k), env.counters().astype(np.int64)          # (host arrays: [E, 4] = games, ties, red wins, blue wins)
+        self.frozen = np.zeros_like(self.c0)
+        self.closed = np.zeros(env.n_envs, dtype=bool)
+
+    def update(self, env):
+        c = env.counters() - self.c0
+        hit = (~self.closed) & (c[:, 0] >= self.k)
+        self.frozen[hit] = c[hit]
+        self.closed |= hit
+        return bool(self.closed.all())
+
+    def totals(self):
+        return self.frozen.sum(0)
+
+
+def play_reference_evaluation(env, actor, games, T=32, one_launch=True, precision="f32", seed=0, ou_scale=0.1, first_tick_stale_obs=False,
+                              games_per_slot=None):
     """The reference's evaluation workload (evaluate.py:32-76; README.md:30 quotes "~80 %" for it) for every game slot of `env` at
     once: red = `actor` through maddpg/agent.py:25-33 -- tanh scores + Ornstein-Uhlenbeck noise of scale 0.1 (utils/noise.py's
     default, which evaluate.py never rescales) that is NEVER restarted (evaluate.py never calls reset_noise) -> clamp -> arg-max --,
@@ -469,7 +494,9 @@ def play_reference_evaluation(env, actor, games, T=32, one_launch=True, precisio
     games are over and returns the tally from the env's own counters (battle_env.py:102-103,169-170,449-455).
     One difference to the script is kept out by default: evaluate.py resets the env twice per game and feeds the FIRST reset's
     observations to the first tick (evaluate.py:53-66), i.e. every plane's first action of a game -- one in ~40 -- is chosen on
-    another game's spawn.  first_tick_stale_obs=True reproduces it: a second env of the same shape does nothing but draw spawns, and
+    another game's spawn.  games_per_slot=k: play until EVERY slot has finished k games and tally exactly each slot's first k (an
+    unbiased sample of k * n_envs whole games: _FirstGamesTally; use a small T, e.g. 4 -- the tally looks at the counters once per T
+    ticks); `games` is then ignored.  first_tick_stale_obs=True reproduces the script's quirk: a second env of the same shape does nothing but draw spawns, and
     the first tick of every game sees ITS observations (both teams, as in the script); that form runs tick by tick (actor launch,
     scripted team, step launch -- the two-kernel form, eagerly), since the substitution sits between a step and the next actor pass."""
     from . import instinct
@@ -485,6 +512,7 @@ def play_reference_evaluation(env, actor, games, T=32, one_launch=True, precisio
         ro.start()
         fresh = torch.ones(env.n_envs, dtype=torch.bool, device=env.device)       # every slot's first game starts on the discarded reset's rows too
         ticks = 0
+        first = _FirstGamesTally(env, games_per_slot) if games_per_slot else None
         while True:
             for _ in range(T):
                 ro.obs[0].copy_(ro.obs[1]); ro.env_done[0].copy_(ro.env_done[1])  # (what PolicyRollout._body does around its ticks)
@@ -494,6 +522,11 @@ def play_reference_evaluation(env, actor, games, T=32, one_launch=True, precisio
                 env._env_done.copy_(ro.env_done[1]); ro._seq_base.add_(1)
                 fresh = (ro.env_done[0] != 0) & (ro.env_done[1] == 0)             # this call re-spawned the game (evaluate.py:64): its next tick is a first tick
             ticks += T
+            if first is not None:
+                if first.update(env):
+                    c = first.totals()
+                    break
+                continue
             c = env.counters().sum(0) - c0
             if c[0] >= games:
                 break
@@ -504,9 +537,15 @@ def play_reference_evaluation(env, actor, games, T=32, one_launch=True, precisio
     env.reset()
     ro.start(); ro.capture()
     ticks = 0
+    first = _FirstGamesTally(env, games_per_slot) if games_per_slot else None
     while True:
         ro.run()
         ticks += T
+        if first is not None:
+            if first.update(env):
+                c = first.totals()
+                break
+            continue
         c = env.counters().sum(0) - c0
         if c[0] >= games:
             break

@@ -152,6 +152,35 @@ def test_reference_evaluation_workload_vs_c_oracle(one_launch):
     assert 0.7 < rate < 0.9                                                 # README.md:30 "~80%"
 
 
+def test_reference_evaluation_tally_with_the_scripts_quirk_is_within_two_sigma_of_evaluate_py():
+    """VERDICT r4 item 3.  The unmodified evaluate.main() here: 3 018 games, red 82.57 % (fixture g12).  Round 4 quoted 84.6 % for the
+    device and left the 2.9-sigma gap unexplained.  Two causes, both in how the games were SAMPLED, none in the step path: (1) all
+    slots were stopped at one moment and the finished games counted -- each slot's unfinished game is dropped, the longer the likelier,
+    and ties are the longest games; (2) the script feeds a game's first tick the observations of a discarded reset (evaluate.py:53-66).
+    With the first k whole games of every slot tallied (_FirstGamesTally) and the quirk reproduced (first_tick_stale_obs) the device
+    plays the reference's evaluation: within two standard deviations of its tally; without the quirk a little above it."""
+    from deep_rl_battlespace_amd.rollout import play_reference_evaluation, reference_checkpoint_actor
+    g12 = np.load(os.path.join(GOLD, "g12_evaluation.npz"))
+    n, E, k = int(g12["n_agents"]), 32768, 2
+    cf = dict(zip(("hit_base_reward", "hit_plane_reward", "miss_punishment", "die_punishment", "lose_punishment"), (float(v) for v in g12["cf"])))
+    actor = reference_checkpoint_actor(g12, n)
+    p_ref = float(g12["red_wins"]) / float(g12["games"])
+    tie_ref = float(g12["ties"]) / float(g12["games"])
+    got = {}
+    for stale in (True, False):
+        env = _env(n_agents=n, n_envs=E, seed=77, auto_reset=True, **cf)
+        r = play_reference_evaluation(env, actor, games=0, T=4, one_launch=not stale, seed=5, first_tick_stale_obs=stale, games_per_slot=k)
+        r.pop("rollout")
+        assert k * E <= r["games"] <= k * E + E // 50 and r["games"] == r["ties"] + r["red_wins"] + r["blue_wins"]   # exactly k per slot (+ the rare two-at-once call)
+        sigma = (p_ref * (1 - p_ref) * (1.0 / float(g12["games"]) + 1.0 / r["games"])) ** 0.5
+        got[stale] = (r["win_rate_red"], (r["win_rate_red"] - p_ref) / sigma, r["ties"] / r["games"])
+    print(f"evaluation tally: with the script's stale first observation {got[True][0]:.4f} ({got[True][1]:+.2f} sigma), every tick on its own "
+          f"game {got[False][0]:.4f} ({got[False][1]:+.2f} sigma); evaluate.main() {p_ref:.4f}; ties {got[True][2]:.4f} vs {tie_ref:.4f}")
+    assert abs(got[True][1]) < 2.0, got
+    assert abs(got[False][1]) < 3.0 and got[False][0] > got[True][0] - 0.004, got     # the quirk costs red a little: its first action is blind
+    assert abs(got[True][2] - tie_ref) < 0.012, got
+
+
 @pytest.mark.parametrize("n", [1, 2])
 def test_categorical_policy_head_and_value_head_vs_torch(n):
     """The policy-gradient heads next to the reference's deterministic-plus-noise one (BASELINE.json configs[4] words C5 as a PPO

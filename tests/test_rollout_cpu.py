@@ -252,3 +252,33 @@ def test_roofline_claim_and_live_aware_bytes():
         assert lo < bench.b_live(n, 0.57, 0.25) < hi
         assert abs(bench.b_live(n, 1.0, 0.0) - bench.b_live(n, 0.0, 0.0) - 16.0) < 1e-9      # layout v2: a pool entry is read and rewritten whole, 8 B each way
     assert abs(bench.b_alg(1) - 260.0) < 1e-9 and abs(bench.b_alg(4) - 289.25) < 1e-9      # (SURVEY.md section 8d rounds it to 289.3)
+
+
+def test_first_games_tally_counts_whole_games_only():
+    """rollout._FirstGamesTally (the evaluation workload's sampling, evaluate.py:52: N whole games one after another): per slot the
+    counters are frozen when its k-th game ends -- later games of fast slots and the unfinished games of slow ones do not enter, so the
+    tally is not tilted toward short games as `stop everybody now and count` is."""
+    from deep_rl_battlespace_amd.rollout import _FirstGamesTally
+
+    class FakeEnv:
+        n_envs = 3
+
+        def __init__(self):
+            self.c = np.zeros((3, 4), np.int32)
+
+        def counters(self):
+            return self.c.copy()
+    env = FakeEnv()
+    env.c[:] = [[5, 1, 3, 1], [2, 0, 2, 0], [0, 0, 0, 0]]                   # counters persist across rollouts: the tally starts from here
+    t = _FirstGamesTally(env, 2)
+    assert not t.update(env)
+    env.c[0] += [1, 0, 1, 0]                                                # slot 0: a quick red win
+    assert not t.update(env)
+    env.c[0] += [1, 0, 1, 0]; env.c[1] += [1, 1, 0, 0]                      # slot 0 reaches 2 (red, red); slot 1: a tie
+    assert not t.update(env)
+    env.c[0] += [3, 0, 3, 0]; env.c[1] += [1, 0, 0, 1]                      # slot 0 races on (ignored); slot 1 reaches 2 (tie, blue)
+    assert not t.update(env)
+    env.c[2] += [2, 2, 0, 0]                                                # the slow slot: two time-limit ties, at last
+    env.c[0] += [4, 0, 4, 0]
+    assert t.update(env)
+    assert t.totals().tolist() == [6, 3, 2, 1]                              # 2 games per slot: red+red, tie+blue, tie+tie

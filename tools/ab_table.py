@@ -18,5 +18,8 @@ for f in sorted(glob.glob(os.path.join(d, "*.out"))):
     except Exception:
         print(f"{name:18s} unparsable; stderr: {open(f[:-4] + '.err').read()[-200:]}")
         continue
+    if "roofline" not in j:                                  # (a step that printed some other JSON line)
+        print(f"{name:18s} {txt.splitlines()[-1][:200]}")
+        continue
     r = j["roofline"]
     print(f"{name:18s} us={r['avg_launch_us']:8.3f} {j['timing']['avg_launch_us_samples']} wall_us={j['ms_per_step'] * 1e3:8.3f} live={r['live_bullets_per_agent']}")
