@@ -66,6 +66,16 @@ constexpr int X_ATAN_TABLE_MAX_K = BSX_X_ATAN_TABLE_MAX_K;
 #endif
 constexpr int X_OPAQUE_MULTI_MASK = BSX_X_OPAQUE_MULTI_MASK;
 
+// -DBSX_X_PAD_SALU=<k> / -DBSX_X_PAD_VALU=<k>: k extra s_add_u32 / v_and_or_b32 per wave and call at the top of the geometry phase (same
+// results): the marginal cost of ONE instruction of a class in each regime (round 5: is the scalar stream free beside other waves' VALU?)
+#ifndef BSX_X_PAD_SALU
+#define BSX_X_PAD_SALU 0
+#endif
+#ifndef BSX_X_PAD_VALU
+#define BSX_X_PAD_VALU 0
+#endif
+constexpr int X_PAD_SALU = BSX_X_PAD_SALU, X_PAD_VALU = BSX_X_PAD_VALU;
+
 #ifdef BSX_STAMPS
 constexpr int BUILD_FLAGS = int(DIAG & 0xFFu) | 0x100;
 __device__ unsigned long long* g_stamps = nullptr;
