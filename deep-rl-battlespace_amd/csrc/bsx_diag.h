@@ -75,6 +75,11 @@ constexpr int X_OPAQUE_MULTI_MASK = BSX_X_OPAQUE_MULTI_MASK;
 #define BSX_X_PAD_VALU 0
 #endif
 constexpr int X_PAD_SALU = BSX_X_PAD_SALU, X_PAD_VALU = BSX_X_PAD_VALU;
+// -DBSX_X_DEPHASE_SLOT=<k>: the wave in slot w of its SIMD (HW_ID) sleeps w x k x 64 cycles at kernel entry (same results)
+#ifndef BSX_X_DEPHASE_SLOT
+#define BSX_X_DEPHASE_SLOT 0
+#endif
+constexpr int X_DEPHASE_SLOT = BSX_X_DEPHASE_SLOT;
 
 #ifdef BSX_STAMPS
 constexpr int BUILD_FLAGS = int(DIAG & 0xFFu) | 0x100;

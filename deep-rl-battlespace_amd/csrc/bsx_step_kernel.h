@@ -110,6 +110,11 @@ void bsx_step_kernel(const int64_t E_, const uint2* const envc_, const uint2* co
     // dwords that the dispatcher preloads into SGPRs (-amdgpu-kernarg-preload-count), so that a wave's first loads need nothing
     // from the kernarg segment and do not queue behind its cold scalar-cache fetch.
     STAMP(8);                                            // diagnostic builds: kernel entry, before any kernarg load
+    if constexpr (X_DEPHASE_SLOT > 0) {                  // variant builds only: the wave in slot k of its SIMD starts k x X_DEPHASE_SLOT x 64 cycles late
+        uint32_t hw;                                     // (do the resident waves of a SIMD, all in the same phase at the same moment, get in each other's way?)
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        for (uint32_t i = 0; i < (hw & 15u); ++i) __builtin_amdgcn_s_sleep(X_DEPHASE_SLOT);
+    }
     typedef typename std::conditional<OFF32, uint32_t, size_t>::type ix_t;     // row / element offsets
     typedef typename std::conditional<OFF32, int32_t, int64_t>::type ixs_t;    // game indices
     constexpr bool NT_STATE = !MULTI && N >= 2;
