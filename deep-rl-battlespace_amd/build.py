@@ -26,10 +26,18 @@ COMMON = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-
 # -amdgpu-kernarg-preload-count=15: the step kernels' eight leading arguments (game count and the pointers of a wave's first
 # loads) arrive in SGPRs with the dispatch instead of through a cold scalar-cache fetch at the start of every wave.
 STEP_FLAGS = ["-ffp-contract=off", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-mfma-vgpr-form", "-mllvm", "-amdgpu-kernarg-preload-count=15"]
+# -amdgpu-sched-strategy=max-ilp, the per-call kernels only (round 5): the machine scheduler orders for instruction-level parallelism
+# instead of minimal register pressure -- 1v1 66 -> 76 VGPRs (six resident waves instead of seven), a few instructions fewer; same
+# results (scheduling only).  Measured as five ALTERNATING runs of product and base variant in one gpurun call (medians; the 1 M figure
+# moves by +-5 % from process to process, which a single pair does not survive -- profiles/r05_experiments.json): 65 536 x 4v4 20.42 ->
+# 20.23 us, 1 M x 1v1 44.2 -> 43.7, C2 6.09 -> 6.07, 262 144 games unchanged; 2v2 and the bullet-heavy workload +0.6 %.  Small, and free.
+# NOT the multi-tick kernels (neutral) and NOT the fused rollouts (1v1 18.9 -> 19.8 us per tick, 4v4 84.5 -> 94: their register budget
+# is what the default strategy protects).
+PER_CALL_FLAGS = STEP_FLAGS + ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 # bsx_kernels.hip: reset / export / scripted-opponent kernels, launchers, C ABI; the 76 step-kernel instances are three more translation
 # units (bsx_step_instances.h), compiled side by side: the build is as long as the largest of them instead of their sum
 SOURCES = [(os.path.join(CSRC, "bsx_kernels.hip"), STEP_FLAGS),
-           (os.path.join(CSRC, "bsx_step_per_call.hip"), STEP_FLAGS),
+           (os.path.join(CSRC, "bsx_step_per_call.hip"), PER_CALL_FLAGS),
            (os.path.join(CSRC, "bsx_step_multi_tick.hip"), STEP_FLAGS),
            (os.path.join(CSRC, "bsx_step_rollout.hip"), STEP_FLAGS),
            (os.path.join(CSRC, "bsx_actor.hip"), ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form"])]

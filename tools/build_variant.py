@@ -9,7 +9,10 @@
 Same sources and base flags as deep-rl-battlespace_amd/build.py; the extra flags select what differs (-DBSX_DIAG=<bits>,
 -DBSX_STAMPS -- see csrc/bsx_diag.h, which only these builds include --, -mllvm ...).  A variant whose results are not the reference's reports that through
 bsx_build_flags() and the binding refuses it without BSX_ALLOW_DIAG=1.  hipcc cross-compiles without a GPU, so variants
-are built in the build container and travel to the GPU box with the snapshot (csrc/variants/*.so is git-ignored)."""
+are built in the build container and travel to the GPU box with the snapshot (csrc/variants/*.so is git-ignored).
+A variant is ONE translation unit (bsx_kernels.hip carries every step-kernel instance) compiled with build.py's STEP_FLAGS: it does not
+have the per-call unit's `-amdgpu-sched-strategy=max-ilp`.  Compare a variant with another variant (`build_variant.py base` = no extra
+flag), or pass `-mllvm -amdgpu-sched-strategy=max-ilp` to both; against the product only where that flag is neutral (C2, 2v2 ... 4v4)."""
 import importlib.util
 import os
 import subprocess
