@@ -16,6 +16,7 @@ ACTOR_F32, ACTOR_BF16X3, ACTOR_BF16X6 = 0, 1, 2
 F_AUTO_RESET = 1
 F_EMPTY_CALL = 2
 F_WIDE_OFFSETS = 4
+F_ONE_WAVE = 8
 ACT_I32, ACT_LOGITS_F32 = 0, 1
 ACT_F32, ACT_F64, ACT_F32X4 = 0, 1, 2
 WINNER_NAMES = ("none", "red", "blue", "tie")

@@ -81,6 +81,13 @@ constexpr int X_PAD_SALU = BSX_X_PAD_SALU, X_PAD_VALU = BSX_X_PAD_VALU;
 #endif
 constexpr int X_DEPHASE_SLOT = BSX_X_DEPHASE_SLOT;
 
+// -DBSX_X_SPLIT=<1|2>: 1v1 per-call launches of up to 131 072 games take the wave-specialised kernel of bsx_step_split.h (same results):
+// form 1 = a planes wave + a bullets wave per 64 agents, form 2 = a wave for everything but the observation geometry + a geometry wave
+#ifndef BSX_X_SPLIT
+#define BSX_X_SPLIT 0
+#endif
+constexpr int X_SPLIT_FORM = BSX_X_SPLIT;
+
 #ifdef BSX_STAMPS
 constexpr int BUILD_FLAGS = int(DIAG & 0xFFu) | 0x100;
 __device__ unsigned long long* g_stamps = nullptr;
@@ -90,7 +97,7 @@ __device__ unsigned long long* g_stamps = nullptr;
         __builtin_amdgcn_sched_barrier(0);                                                         \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        if (g_stamps && (threadIdx.x & 63) == 0) g_stamps[size_t(blockIdx.x) * 10 + (i)] = t_; \
+        if (g_stamps && (threadIdx.x & 63) == 0) g_stamps[size_t(stamp_row) * 10 + (i)] = t_;  \
     } while (0)
 // where the stamps go (device buffer of 10 * waves uint64)
 extern "C" int bsx_debug_set_stamps(void* buf) {
@@ -109,7 +116,7 @@ constexpr int BUILD_FLAGS = int(DIAG & 0xFFu);
         __builtin_amdgcn_sched_barrier(0);                                                         \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        if (g_stamps) g_stamps[size_t(blockIdx.x) * 10 + (i)] = t_;                                \
+        if (g_stamps) g_stamps[size_t(stamp_row) * 10 + (i)] = t_;                                 \
     } while (0)
 #define PSTAMP(i) do { if ((i) < 3 || (i) > 6) STAMP(i); } while (0)
 #else

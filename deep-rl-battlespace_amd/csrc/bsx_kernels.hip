@@ -44,6 +44,10 @@
 #define BSX_INST_MULTI_TICK
 #define BSX_INST_ROLLOUT
 #ifdef BSX_VARIANT
+#include "bsx_step_split.h"                              // (the wave-specialised 1v1 kernel: a measured experiment, variant builds only)
+#define BSX_INST_SPLIT
+#endif
+#ifdef BSX_VARIANT
 #define BSX_INST_KW
 #else
 #define BSX_INST_KW extern
@@ -277,8 +281,29 @@ void launch_for_n_w(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs&
 inline bool narrow_offsets_ok(int64_t E, int n, uint32_t flags) {
     return !(flags & BSX_F_WIDE_OFFSETS) && uint64_t(E) * uint64_t(2 * n) * 200ull <= 0xFFFFFFFFull;
 }
+// 1v1, discrete actions, one call per launch, a launch of at most SPLIT_MAX_GAMES games: the wave-specialised kernel (bsx_step_split.h) --
+// two waves per 64 agents, one for the planes and one for the bullets; same results bit for bit.  BSX_F_ONE_WAVE keeps the one-wave
+// kernel (tests run the two against each other; larger launches take it anyway: their SIMDs are full of waves as it is).
+constexpr int64_t SPLIT_MAX_GAMES = 131072;              // (four / eight waves of the split kernel per SIMD at 65 536 / 131 072 games)
+template <bool CONT, bool MULTI>
+inline bool split_applies(int n, const StepArgs& a, int64_t bound) {
+    return !CONT && !MULTI && X_SPLIT_FORM != 0 && n == 1 && bound <= SPLIT_MAX_GAMES && !(a.flags & BSX_F_ONE_WAVE);
+}
+template <bool LG, bool OFF32>
+void launch_split(dim3 grid, hipStream_t s, const StepArgs& a, int64_t bound) {
+#ifdef BSX_VARIANT
+    hipLaunchKernelGGL((bsx_step_split_kernel<LG, OFF32>), grid, dim3(2 * SPB), 0, s, bound, a.st.envc, a.st.envd, a.st.plane, a.actions, a.st.bent, a.st.bcnt, a.action_kind, a);
+#endif
+}
 template <bool CONT, bool MULTI, bool LG>
 void launch_for_n(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs& a, int64_t bound) {
+    if constexpr (!CONT && !MULTI) {
+        if (split_applies<CONT, MULTI>(n, a, bound)) {   // (the grid is the same: one workgroup per 64 agents, of two waves instead of one)
+            if (narrow_offsets_ok(a.E, n, a.flags)) launch_split<LG, true>(grid, s, a, bound);
+            else launch_split<LG, false>(grid, s, a, bound);
+            return;
+        }
+    }
     if (narrow_offsets_ok(a.E, n, a.flags)) launch_for_n_w<CONT, MULTI, LG, true>(n, grid, block, s, a, bound);
     else launch_for_n_w<CONT, MULTI, LG, false>(n, grid, block, s, a, bound);
 }

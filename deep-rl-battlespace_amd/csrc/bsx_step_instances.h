@@ -27,3 +27,10 @@ BSX_STEP_FAMILY(0, true) BSX_STEP_FAMILY(1, true) BSX_STEP_FAMILY(2, true) BSX_S
 #ifdef BSX_INST_ROLLOUT
 BSX_ROLLOUT_FAMILY(1) BSX_ROLLOUT_FAMILY(2) BSX_ROLLOUT_FAMILY(3) BSX_ROLLOUT_FAMILY(4)
 #endif
+#ifdef BSX_INST_SPLIT
+#define BSX_SPLIT_INST(LG, OFF32)                                                                                                        \
+    BSX_INST_KW template __global__ void bsxk::bsx_step_split_kernel<LG, OFF32>(                                                         \
+        const int64_t, const uint2* const, const uint2* const, const uint2* const, const void* const, const uint2* const, const uint32_t* const, \
+        const int, const bsxk::StepArgs);
+BSX_SPLIT_INST(false, false) BSX_SPLIT_INST(false, true) BSX_SPLIT_INST(true, false) BSX_SPLIT_INST(true, true)
+#endif

@@ -109,6 +109,7 @@ void bsx_step_kernel(const int64_t E_, const uint2* const envc_, const uint2* co
     // The eight leading arguments repeat p.E, p.st.envc, p.st.envd, p.st.plane, p.actions, p.st.bent, p.st.bcnt, p.action_kind: fifteen
     // dwords that the dispatcher preloads into SGPRs (-amdgpu-kernarg-preload-count), so that a wave's first loads need nothing
     // from the kernarg segment and do not queue behind its cold scalar-cache fetch.
+    const unsigned stamp_row = blockIdx.x; (void)stamp_row;   // (diagnostic builds: where this wave's stamps go)
     STAMP(8);                                            // diagnostic builds: kernel entry, before any kernarg load
     if constexpr (X_DEPHASE_SLOT > 0) {                  // variant builds only: the wave in slot k of its SIMD starts k x X_DEPHASE_SLOT x 64 cycles late
         uint32_t hw;                                     // (do the resident waves of a SIMD, all in the same phase at the same moment, get in each other's way?)
@@ -390,6 +391,15 @@ void bsx_step_kernel(const int64_t E_, const uint2* const envc_, const uint2* co
     //   bullets   Bullet.update for every work slot (pool entries + queued shots), pool compaction, ordered plane-hit resolve
     //   outcome   rewards, deaths, base hit points, win / tie
     //   stores    plane / game records, reward, done, observation row, counters, pool length
+    // R_*: which parts of the tick this wave runs -- here all of them.  The wave-specialised 1v1 kernel (bsx_step_split.h, a measured
+    // experiment: variant builds only) includes the same phase files once per wave with different parts switched on; the phases guard
+    // their side effects by these constants and the rest falls to dead-code elimination.  With every part on, every guard is a
+    // compile-time `true` (the ISA of all 76 kernels is unchanged by the guards).
+    constexpr bool R_BULLETS = true, R_MOVE = true, R_STAGE = true, R_GEOM = true, R_OUTCOME = true, R_RDV_MOVE = false;
+    constexpr int R_RDV_COUNTS = 0, R_GEOM_LDS = 0;
+    auto split_rendezvous = [] {};                       // (names of the split kernel's role code: never reached here)
+    uint32_t* const s_npl = nullptr;
+    v4f_t* const s_gm = nullptr;
 #include "bsx_step_phase_actor.inl"
 #include "bsx_step_phase_shot.inl"
 #include "bsx_step_phase_move.inl"

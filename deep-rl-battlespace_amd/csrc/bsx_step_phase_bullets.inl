@@ -6,7 +6,7 @@
 // @reads   nhp_ pool_pass slots
 // @writes  pc
 // @exports nbase nbase_other nmiss nplane nplane_other
-// @lds     s_agg s_bhit s_hp s_ov s_pp
+// @lds     s_agg s_bhit s_hp s_npl s_ov s_pp
     PSTAMP(4);
     // ---- Bullet.update (sprites.py:321-351) per work slot, predicates as integer sign masks (0 / -1).
     uint64_t ovl[OW];
@@ -21,7 +21,7 @@
         return (uint32_t(ebx) & 0xFFFFu) | (uint32_t(eby) << 16);
     };
     bool any_hit = false;
-    if (pool_pass) {
+    if (R_BULLETS && pool_pass) {
         // ---- wave-packed bullet pass, part 2: Bullet.update per work slot.  A slot reads what its bullet's OWNER would have had
         // in registers -- the enemy base, the enemy planes' post-move poses and alive flags -- from the wave's LDS block, moves the
         // bullet, and hands the outcome back: one LDS add per bullet that ended (miss and base-hit counts), the survivor straight to
@@ -151,7 +151,7 @@
     uint64_t any_ovl = 0;
 #pragma unroll
     for (int q = 0; q < OW; ++q) any_ovl |= ovl[q];
-    if (ballot64(any_ovl != 0ull) != 0ull && !(DIAG & 4u)) {   // wave-uniform: most waves have no candidate at all
+    if (R_BULLETS && ballot64(any_ovl != 0ull) != 0ull && !(DIAG & 4u)) {   // wave-uniform: most waves have no candidate at all
         uint32_t consumed = 0;                                 // by age
         if constexpr (N == 1) {
             // one shooter per target: my candidates, oldest first, hit until the enemy's hit points run out; the rest fly on
@@ -191,6 +191,16 @@
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if constexpr (R_RDV_COUNTS != 0) {
+        // split kernel, form A: the bullets wave hands its counts to the planes wave -- misses and base hits sit in s_agg (the work slots'
+        // adds), the plane hits of the ordered resolve go beside them -- and the two waves meet once more
+        if constexpr (R_RDV_COUNTS == 1) s_npl[tid] = uint32_t(nplane);
+        split_rendezvous();
+        if constexpr (R_RDV_COUNTS == 2) {
+            if (pool_pass) { const uint32_t agg = s_agg[tid]; nmiss = int((agg >> 16) & 0xFFu); nbase = int((agg >> 24) & 0xFFu); }
+            nplane = int(s_npl[tid]);
+        }
+    }
     int nplane_other = 0, nbase_other = 0;               // 1v1: what the enemy's bullets did to me / to my base
     if constexpr (N == 1) { nplane_other = lane_xor1(nplane); nbase_other = lane_xor1(nbase); }
 

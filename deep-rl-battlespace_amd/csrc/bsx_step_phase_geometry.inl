@@ -5,7 +5,7 @@
 // @reads   CHEAP_SHOT ks nbdir nexact nx_ ny_ shot_exact spawn
 // @writes  nd
 // @exports ob_a ob_d oe_a oe_d
-// @lds     s_nd s_pd s_pr
+// @lds     s_gm s_nd s_pd s_pr
     PSTAMP(3);
     if constexpr (X_PAD_SALU > 0 || X_PAD_VALU > 0) {    // variant builds only: k extra instructions of one class per wave (what does ONE more instruction cost here?)
         uint32_t padv = uint32_t(lane);
@@ -15,7 +15,7 @@
     }
     // ---- observation geometry (battle_env.py:202-244) from the staged block, BEFORE the bullets: poses are final after
     //      the move, only the alive flags can still change; this fp64 math runs while the bullet-step loads are in flight.
-    if (shot_exact) {                                    // wave-uniform and rare: a flagged shot leaves its float64 step in the ring (and in LDS for its first update)
+    if (R_BULLETS && shot_exact) {                       // wave-uniform and rare: a flagged shot leaves its float64 step in the ring (and in LDS for its first update)
         if constexpr (N == 1) asm volatile("");          // (keeps this a scalar branch; see the bullet rounds)
         if (spawn && nexact) {
             if constexpr (CHEAP_SHOT) {                  // the exact float64 step, as Bullet.update evaluates it (sprites.py:35-42,330-333)
@@ -31,7 +31,8 @@
     float ob_d = -1.0f, ob_a = -1.0f;
     float oe_d[NE], oe_a[NE];
     int ex[NE], ey[NE];
-    if constexpr (N == 0) {                                          // runtime-n build: the enemy planes' pairs are worked out at row assembly
+    if constexpr (!R_GEOM) {                                         // (split kernels: a wave without the observation geometry)
+    } else if constexpr (N == 0) {                                   // runtime-n build: the enemy planes' pairs are worked out at row assembly
         if (!(DIAG & 1u)) obs_pair(x, y, dir, obx, oby, ob_d, ob_a);
     } else if constexpr (N == 1) {
         ex[0] = nx_; ey[0] = ny_;
@@ -90,4 +91,5 @@
             }
         }
     }
-
+    // split kernel, form G: the geometry wave hands its four observation values to the wave that stores the rows, and is done
+    if constexpr (R_GEOM_LDS == 1) s_gm[tid] = v4f_t{ob_d, ob_a, oe_d[0], oe_a[0]};

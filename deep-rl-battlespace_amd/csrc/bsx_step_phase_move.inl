@@ -8,6 +8,7 @@
 // @exports nhp_ nx_ ny_
 // @lds     s_bhit s_hp s_pq s_x s_y
     STAMP(2);
+    if constexpr (R_MOVE) {                              // (split kernels: a wave that only runs bullets does not move planes)
     if (mode == M_RESET) {
         // re-spawn in place of the inert call; episode id = games played so far.  My block holds my pose and (first plane of a team) my
         // team's base; the two bases travel to every lane of the game (all lanes of a game are here together)
@@ -46,11 +47,12 @@
             dir = rotate_dir(dir, a1 * 35.0);                          // :421-422
         }
     }
+    }
 
     // ---- hand the post-move pose and hit points to the other planes of the game.  1v1: the only other plane is the lane
     //      next door, three cross-lane moves (DPP) instead of LDS round trips; larger teams stage the block in LDS.
     int nx_ = 0, ny_ = 0, nhp_ = 0;                      // 1v1: the enemy's x, y, hit points
-    s_pq[tid] = make_rect(pack_xy(x, y), valid && hp > 0, 27, 25, 27, 24);
+    if constexpr (R_STAGE) s_pq[tid] = make_rect(pack_xy(x, y), valid && hp > 0, 27, 25, 27, 24);
     if constexpr (N == 1) {
         nx_ = lane_xor1(x); ny_ = lane_xor1(y); nhp_ = lane_xor1(valid ? hp : 0);
     } else {
@@ -59,4 +61,5 @@
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-
+    // split kernel, form A: the planes wave has staged the post-move sprites (s_pq), the bullets wave its shots and owner flags: rendezvous
+    if constexpr (R_RDV_MOVE) split_rendezvous();

@@ -53,9 +53,11 @@
     const unsigned long long shb = ballot64(spawn);
     const int srank = int(__builtin_amdgcn_mbcnt_hi(uint32_t(shb >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(shb), 0u)));
     const int slots = int(pc) + __popcll(shb);           // wave-uniform
-    s_agg[tid] = 0u;
-    s_eb[tid] = make_rect(pack_xy(team == 0 ? er.bbx : er.brx, team == 0 ? er.bby : er.bry), true, 33, 32, 33, 31);
-    s_fl[tid] = uint32_t(ks) | (phys ? OWN_PHYS : 0u) | ((mode == M_RESET && valid) ? OWN_DROP : 0u);
+    if constexpr (R_BULLETS) {                           // (split kernels: only the wave that runs the bullets stages for the work slots)
+        s_agg[tid] = 0u;
+        s_eb[tid] = make_rect(pack_xy(team == 0 ? er.bbx : er.brx, team == 0 ? er.bby : er.bry), true, 33, 32, 33, 31);
+        s_fl[tid] = uint32_t(ks) | (phys ? OWN_PHYS : 0u) | ((mode == M_RESET && valid) ? OWN_DROP : 0u);
+    }
     // does this call touch the pool at all?  (not if no game of the wave is in its physics call or being re-spawned: entries stay as they are)
     const bool pool_pass = any64(phys || (mode == M_RESET && valid));
     FSTAMP(4);
@@ -75,9 +77,10 @@
     // (episode, plane); the first plane of each team also draws its base)
     const bool respawn = mode == M_RESET;
     uint4 rw = make_uint4(0u, 0u, 0u, 0u);
-    if ((spawn && !u_t && !(DIAG & 8u)) || respawn)
+    // (split kernels: the wave that runs the bullets draws the jitter, a wave that moves planes the re-spawn -- the same block, whoever computes it)
+    if ((R_BULLETS && spawn && !u_t && !(DIAG & 8u)) || (R_MOVE && respawn))
         rw = draw4(seed_t, genv, respawn ? STREAM_AUTORESET : STREAM_JITTER, games, respawn ? uint32_t(a < A ? a : A - 1) : ((uint32_t(tick) << 8) | uint32_t(a)));
-    if (spawn) {
+    if (R_BULLETS && spawn) {
         double uu = uu_in;
         if (!u_t && !(DIAG & 8u)) uu = uniform53(rw.x, rw.y);
         const double jit = uu * 8.0 - 4.0;

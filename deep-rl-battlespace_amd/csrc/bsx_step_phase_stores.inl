@@ -2,14 +2,20 @@
 // kernel's locals, so this is a textual unit for reading and review, not a function): write-back: plane and game records, reward, done flag, the observation row (straight from registers, or through LDS in the fused rollout and
 // the runtime-n kernel), counters by atomics at a game's end, the pool count of a multi-tick launch.
 // The contract (tools/check_phase_contract.py checks it against this file's text in the CPU suite; names are the kernel's locals):
-// @reads   alive cnt_delta mode nhp_ nplane ob_a ob_d oe_a oe_d rew
-// @writes  din_next
+// @reads   alive cnt_delta mode nhp_ nplane rew
+// @writes  din_next ob_a ob_d oe_a oe_d
 // @exports -
 // @lds -
     PSTAMP(6);
     if (MULTI && !ACTOR && tk + 1 < p.T) din_next = decode(rin_next);   // the prefetch has long arrived; no store of this tick is out yet
     // ---- write back (MULTI: plane and game records travel in registers; memory gets them once, after the last tick)
     const bool last_tick = !MULTI || tk == p.T - 1;
+    // split kernel, form G: the two waves meet; the storing wave takes the observation values the geometry wave left in LDS
+    if constexpr (R_GEOM_LDS != 0) {
+        split_rendezvous();
+        if constexpr (R_GEOM_LDS == 2) { const v4f_t gm = s_gm[tid]; ob_d = gm.x; ob_a = gm.y; oe_d[0] = gm.z; oe_a[0] = gm.w; }
+    }
+    if constexpr (R_OUTCOME) {                           // (split kernels: one wave stores the step's results)
     if (valid) {
         if (MULTI ? last_tick : (mode == M_PHYS || mode == M_RESET)) {
             const uint2 pw = pack_plane(x, y, hp, dir, CONT);
@@ -128,5 +134,6 @@
             }
             if (MULTI && p.env_done_t) p.env_done_t[int64_t(tk) * E_ + e] = uint8_t(er.done);
         }
+    }
     }
     if (MULTI && last_tick && lane == 0) *elem(p.st.bcnt, ix_t(wblk)) = pc;   // the pool's length travelled in a register

@@ -1,0 +1,141 @@
+// bsx_step_split.h -- bsx_step_split_kernel: the 1v1 per-call step() as TWO co-operating wavefronts per 64 agents.
+// A MEASURED EXPERIMENT of round 5 that LOSES; it is compiled in variant builds only (-DBSX_X_SPLIT=<1|2>, tools/build_variant.py) and kept
+// because the result is the evidence for DESIGN.md section 6 ("more waves per SIMD by splitting the agent's work"); namespace bsxk.
+//
+// The idea.  At 65 536 x 1v1 the one-wave kernel (bsx_step_kernel<1, ...>) puts two waves on a SIMD, and its tick is one long chain of
+// dependent latencies: first loads -> classify -> shot (Philox, step code) -> move -> geometry -> bullet round -> resolve -> outcome ->
+// stores; two lock-stepped waves hide little of each other.  But the observation geometry (the largest block of vector work) needs
+// nothing from the shot or the bullets, and the bullets need nothing from the geometry.  Here a workgroup is TWO waves over the same 64
+// agents (32 games), four waves per SIMD at 65 536 games:
+//   form 1 (A)  wave 0, PLANES: first loads -> classify -> move (or re-spawn) -> [rendezvous] -> geometry -> [rendezvous] -> outcome -> stores
+//               wave 1, BULLETS: pool loads -> [records from wave 0] -> classify, staging, Philox, shot -> [rendezvous] -> pool pass -> resolve -> [rendezvous]
+//   form 2 (G)  wave 0: everything but the geometry;  wave 1: move + geometry, its four observation values through LDS before the stores
+// The shared records are loaded once per workgroup (wave 0 hands the raw words over through LDS); a rendezvous is an LDS drain + s_barrier.
+//
+// How.  No second copy of the game logic: the kernel includes the SAME phase files as bsx_step_kernel, once per wave, with the R_*
+// constants of the wave's role.  The phases guard their side effects (LDS staging, stores, the pool pass, the rendezvous) by them;
+// everything that only feeds a guarded-off side effect is dead code to the compiler (50 registers per wave).  Results are those of the
+// one-wave kernel bit for bit (tests/test_hip_split.py builds the variant and runs the two against each other).
+//
+// What it measured (profiles/r05_experiments.json, one gpurun call): 65 536 games 6.31 us (form 1) / 6.46 (form 2) against 6.09 for the
+// one-wave kernel; 32 768 games 4.96 / 5.06 against 4.99; 131 072 games 9.09 (form 2) against 8.31.  In-kernel stamps say why: the
+// planes wave lives 10.9 k cycles and the bullets wave 9.3 k against 11.05 k of the one wave -- the chain first loads -> shot -> pool
+// pass -> resolve -> outcome -> stores IS the critical path, the geometry was the only large piece beside it, and three rendezvous, the
+// record hand-over and twice the waves to launch cost what taking it off the chain saves.
+#pragma once
+
+namespace bsxk {
+
+template <bool LG, bool OFF32>
+__global__ __launch_bounds__(2 * SPB)
+void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uint2* const envd_, const uint2* const plane_, const void* const act_,
+                           const uint2* const bent_, const uint32_t* const bcnt_, const int kind_, const StepArgs p_) {
+    constexpr int N = 1;
+    constexpr bool CONT = false, MULTI = false, ACTOR = false;
+    const StepArgs& p = p_;
+    typedef typename std::conditional<OFF32, uint32_t, size_t>::type ix_t;     // row / element offsets
+    typedef typename std::conditional<OFF32, int32_t, int64_t>::type ixs_t;    // game indices
+    constexpr bool NT_STATE = false;
+    constexpr int WAVES = 1;                             // LDS is sized for ONE set of 64 agents: the two waves share it
+    const int n = 1, A = 2, G = 2, EPB = SPB / 2;
+    const int wave = 0;                                  // (the phases' LDS offsets: both waves use the set's only slice)
+    const int role_wave = int(threadIdx.x >> 6);         // 0 = planes, 1 = bullets
+    const unsigned stamp_row = blockIdx.x * 2u + unsigned(role_wave); (void)stamp_row;   // (diagnostic builds: a row of stamps per wave)
+    STAMP(8);
+    const int tid = int(threadIdx.x & 63);
+    const ixs_t wblk = ixs_t(blockIdx.x);
+    const int a = tid & (G - 1);
+    const ixs_t e = wblk * EPB + (tid / G);
+    const bool env_ok = e < ixs_t(E_);
+    const bool valid = env_ok && a < A;
+    const ix_t EA = ix_t(p.E) * ix_t(A);
+    const ixs_t ec = env_ok ? e : ixs_t(E_ - 1);
+    const ix_t g = ix_t(ec) * A + (a < A ? a : A - 1);
+    constexpr int NE = 1;
+    constexpr int DROW = 3 * N + 2;
+    __shared__ volatile int s_x_all[SPB], s_y_all[SPB], s_hp_all[SPB];
+    __shared__ volatile int s_bhit_all[SPB];
+    __shared__ __attribute__((aligned(16))) float s_obs_all[4];
+    __shared__ __attribute__((aligned(16))) float s_small[4];
+    __shared__ int s_act_all[1];
+    __shared__ float s_actf_all[1];
+    __shared__ double s_actd_all[1];
+    __shared__ int s_gdone_all[1];
+    __shared__ float s_pd_all[1];
+    __shared__ double s_pr_all[1];
+    __shared__ __attribute__((aligned(8))) u32x2 s_new_all[SPB];
+    __shared__ uint32_t s_agg_all[SPB];
+    __shared__ uint32_t s_npl_all[SPB];                  // plane hits per shooter, bullets wave -> planes wave
+    __shared__ __attribute__((aligned(16))) v4u_t s_t0_all[SPB], s_t1_all[SPB];   // the first loads' raw words, wave 0 -> wave 1
+    __shared__ __attribute__((aligned(16))) v4f_t s_gm_all[SPB];                  // form G: the four observation values, geometry wave -> storing wave
+    constexpr bool CORNERS = true;
+    typedef u32x2 rect_t;
+    __shared__ __attribute__((aligned(8))) rect_t s_eb_all[SPB];
+    __shared__ __attribute__((aligned(8))) rect_t s_pq_all[SPB];
+    auto make_rect = [](uint32_t c, bool alive, int xl, int yl, int xh, int yh) {
+        return alive ? u32x2{c + pk_const(PK_BIAS - xl, PK_BIAS - yl), c + pk_const(PK_BIAS + xh, PK_BIAS + yh)} : u32x2{0x7F007F00u, 0u};
+    };
+    auto hits_rect = [](s16x2 b, rect_t r, int xl, int yl, int xh, int yh) {
+        return ~pk_any_negative(pk_bits(b - as_pk(r.x)) | pk_bits(as_pk(r.y) - b));
+    };
+    constexpr uint32_t OWN_PHYS = 16u, OWN_DROP = 32u;
+    __shared__ uint32_t s_fl_all[SPB];
+    __shared__ __attribute__((aligned(16))) double s_nd_all[SPB * 2];
+    constexpr int FW = 4, OW = 1;
+    __shared__ unsigned long long s_ov_all[SPB * OW];
+    __shared__ uint16_t s_pp_all[SPB * K];
+    auto* const s_new = BSX_LDS(u32x2, s_new_all);
+    auto* const s_agg = BSX_LDS(uint32_t, s_agg_all);
+    auto* const s_npl = BSX_LDS(uint32_t, s_npl_all);
+    auto* const s_gm = (__attribute__((address_space(3))) volatile v4f_t*)(uintptr_t)(s_gm_all);
+    auto* const s_t0 = (__attribute__((address_space(3))) volatile v4u_t*)(uintptr_t)(s_t0_all);
+    auto* const s_t1 = (__attribute__((address_space(3))) volatile v4u_t*)(uintptr_t)(s_t1_all);
+    auto* const s_eb = BSX_LDS(rect_t, s_eb_all);
+    auto* const s_pq = BSX_LDS(rect_t, s_pq_all);
+    auto* const s_fl = BSX_LDS(uint32_t, s_fl_all);
+    auto* const s_nd = BSX_LDS(double, s_nd_all);
+    auto* const s_ov = BSX_LDS(unsigned long long, s_ov_all);
+    auto* const s_pp = BSX_LDS(uint16_t, s_pp_all);
+    float* const s_pd = s_pd_all;
+    double* const s_pr = s_pr_all;
+    typedef __attribute__((address_space(3))) volatile int lds_vint;
+    lds_vint* const s_x = (lds_vint*)(uintptr_t)(s_x_all);
+    lds_vint* const s_y = (lds_vint*)(uintptr_t)(s_y_all);
+    lds_vint* const s_hp = (lds_vint*)(uintptr_t)(s_hp_all);
+    lds_vint* const s_bhit = (lds_vint*)(uintptr_t)(s_bhit_all);
+    float* const s_obs = s_obs_all;
+    (void)s_small; (void)s_act_all; (void)s_actf_all; (void)s_actd_all; (void)s_gdone_all; (void)s_obs; (void)s_pd; (void)s_pr;
+    (void)s_x; (void)s_y; (void)s_hp; (void)s_bhit; (void)DROW; (void)wave; (void)EA;
+    // the two waves of a workgroup meet: every LDS operation of this wave has landed (lgkmcnt) before it arrives, nothing of it is
+    // reordered across (the LDS arrays are volatile; the asm is a compiler fence).  Global stores in flight (the shot's heading in the
+    // export ring, pool entries) are NOT waited for: nothing the other wave reads travels through global memory.
+    auto split_rendezvous = [] {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    const bool has_act = kind_ >= 0;
+    // (names of the multi-tick forms that the phase files mention behind `if (MULTI ...)`: never reached here)
+    struct RawIn {}; struct DecIn {};
+    RawIn rin_next; DecIn din_next;
+    auto load_inputs = [](int, RawIn&) {};
+    auto decode = [](const RawIn&) { return DecIn{}; };
+    (void)rin_next; (void)din_next; (void)load_inputs; (void)decode;
+    const ix_t pool0 = ix_t(wblk) * ix_t(POOL_CAP);
+    const int tk = 0;
+    // X_SPLIT_FORM 1 (A): wave 0 = planes (move, geometry, outcome, stores), wave 1 = bullets (shot, pool pass, resolve); three rendezvous
+    // X_SPLIT_FORM 2 (G): wave 0 = everything but the observation geometry, wave 1 = move + geometry only; two rendezvous
+    if (role_wave == 0) {
+        constexpr bool FIRST = true;                     // this wave loads the shared records and hands them over
+        constexpr bool R_BULLETS = X_SPLIT_FORM == 2, R_MOVE = true, R_STAGE = true, R_GEOM = X_SPLIT_FORM == 1, R_OUTCOME = true, R_RDV_MOVE = X_SPLIT_FORM == 1;
+        constexpr int R_RDV_COUNTS = X_SPLIT_FORM == 1 ? 2 : 0, R_GEOM_LDS = X_SPLIT_FORM == 2 ? 2 : 0;
+        if constexpr (R_BULLETS) s_ov[tid] = 0ull;       // (cleared again by whoever finds it set)
+#include "bsx_step_split_body.inl"
+    } else {
+        constexpr bool FIRST = false;
+        constexpr bool R_BULLETS = X_SPLIT_FORM == 1, R_MOVE = X_SPLIT_FORM == 2, R_STAGE = false, R_GEOM = X_SPLIT_FORM == 2, R_OUTCOME = false, R_RDV_MOVE = X_SPLIT_FORM == 1;
+        constexpr int R_RDV_COUNTS = X_SPLIT_FORM == 1 ? 1 : 0, R_GEOM_LDS = X_SPLIT_FORM == 2 ? 1 : 0;
+        if constexpr (R_BULLETS) s_ov[tid] = 0ull;
+#include "bsx_step_split_body.inl"
+    }
+}
+
+}  // namespace bsxk

@@ -1,0 +1,77 @@
+// bsx_step_split_body.inl -- one wave's tick of bsx_step_split_kernel (bsx_step_split.h includes it twice, with the R_* constants of the
+// wave's role): the first loads of the role, the decode, and the seven phase files of bsx_step_kernel in tick order.
+    {
+        ix_t gt = g, EAt = ix_t(p.E) * ix_t(A);
+        uint64_t seed_t = p.seed;
+        int64_t env_offset_t = p.env_offset;
+        constexpr int tie_tick = tie_tick_const(1);
+        const int lane = tid;
+        const int gl = tid & ~(G - 1);
+        const int team = (a < n) ? 0 : 1;
+        const int eb = gl + (team == 0 ? n : 0);
+        const double* const u_t = p.u;
+        float* const obs_t = p.obs;
+        float* const rew_t = p.rew;
+        uint8_t* const done_t = p.done;
+        (void)eb; (void)u_t; (void)obs_t; (void)rew_t; (void)done_t; (void)EAt;
+        // ---- T0: every load this role needs, back to back (what a role does not use -- the pool for the planes wave -- is dead code)
+        int x = 0, y = 0, hp = 0;
+        uint32_t games = 0;
+        double dir = 0.0;
+        EnvU er = {};
+        uint32_t pc = 0;
+        uint2 pool_first = make_uint2(0u, 0u);
+        int act = -1;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, uu_in = 0.0;
+        (void)a0; (void)a1; (void)a2;
+        STAMP(0);
+        // The game records, the plane record and the action are loaded ONCE per workgroup -- by the planes wave, which hands the raw words to
+        // the bullets wave through LDS (rendezvous 0) -- so that the launch's first burst of requests is the one-wave kernel's, not twice it;
+        // the bullets wave asks for its pool meanwhile.
+        {
+            uint2 ecw, edw, prw;
+            if constexpr (FIRST) {
+                ecw = *elem(envc_, ix_t(ec));
+                edw = *elem(envd_, ix_t(ec));
+                prw = *elem(plane_, gt);
+                const char* const abase = static_cast<const char*>(act_);
+                float4 lg = make_float4(0.f, 0.f, 0.f, 0.f);
+                int ai = -1;
+                if constexpr (LG) lg = *reinterpret_cast<const float4*>(elem(abase, has_act ? g * 16 : ix_t(0)));
+                else ai = *reinterpret_cast<const int32_t*>(elem(abase, has_act ? g * 4 : ix_t(0)));
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("" : "+s"(seed_t), "+s"(env_offset_t));
+                if (has_act) act = LG ? argmax4(lg.x, lg.y, lg.z, lg.w) : ai;
+                if constexpr (R_BULLETS) {
+                    pool_first = *elem(bent_, pool0 + ix_t(lane));
+                    pc = __builtin_amdgcn_readfirstlane(*elem(bcnt_, ix_t(wblk)));
+                    if (p.u) uu_in = p.u[g];                                   // (injected jitter: uniform branch)
+                }
+                s_t0[tid] = v4u_t{ecw.x, ecw.y, edw.x, edw.y};
+                s_t1[tid] = v4u_t{prw.x, prw.y, uint32_t(act), 0u};
+                split_rendezvous();
+            } else {
+                if constexpr (R_BULLETS) {
+                    pool_first = *elem(bent_, pool0 + ix_t(lane));
+                    pc = __builtin_amdgcn_readfirstlane(*elem(bcnt_, ix_t(wblk)));
+                    if (p.u) uu_in = p.u[g];                                   // (injected jitter: uniform branch)
+                }
+                asm volatile("" : "+s"(seed_t), "+s"(env_offset_t));
+                split_rendezvous();
+                const v4u_t t0 = s_t0[tid], t1 = s_t1[tid];
+                ecw = make_uint2(t0.x, t0.y); edw = make_uint2(t0.z, t0.w); prw = make_uint2(t1.x, t1.y);
+                act = int(t1.z);
+            }
+            unpack_plane(prw, x, y, hp, dir);
+            er = unpack_env(ecw, edw.x);
+            games = edw.y;
+        }
+#include "bsx_step_phase_actor.inl"
+#include "bsx_step_phase_shot.inl"
+#include "bsx_step_phase_move.inl"
+#include "bsx_step_phase_geometry.inl"
+#include "bsx_step_phase_bullets.inl"
+#include "bsx_step_phase_outcome.inl"
+#include "bsx_step_phase_stores.inl"
+        STAMP(7);
+    }

@@ -76,7 +76,7 @@ class parallel_env:
 
     def __init__(self, n_agents=1, show=False, hit_base_reward=100, hit_plane_reward=10, miss_punishment=-1,
                  die_punishment=-5, lose_punishment=-20, fps=20, continuous_actions=False,
-                 n_envs=None, device=None, seed=0, auto_reset=False, env_offset=0, rng=None, wide_offsets=False):
+                 n_envs=None, device=None, seed=0, auto_reset=False, env_offset=0, rng=None, wide_offsets=False, one_wave=False):
         """First nine arguments: exactly the reference constructor (battle_env.py:73).
 
         n_envs      None = drop-in single game (reference return types); int = batched on-device tensors
@@ -87,6 +87,8 @@ class parallel_env:
         rng         "python" (stdlib random, reference draw order; default when n_envs is None) or "philox"
         wide_offsets  take the 64-bit-offset kernels (BSX_F_WIDE_OFFSETS) although the job is small enough for 32-bit offsets;
                     the library switches by itself above 4 GB per array -- same results, for tests
+        one_wave    1v1, discrete actions: keep the one-wave step kernel (BSX_F_ONE_WAVE) instead of the wave-specialised one that
+                    per-call launches of up to 131 072 games take -- same results, for tests and A/B runs
         """
         if not isinstance(n_agents, (int, np.integer)) or not 1 <= n_agents <= _lib.MAX_N:
             raise ValueError(f"n_agents must be an int in 1..{_lib.MAX_N}, got {n_agents!r}")
@@ -140,7 +142,8 @@ class parallel_env:
                                     float(die_punishment), float(lose_punishment))
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.auto_reset = bool(auto_reset)
-        self._base_flags = (_lib.F_AUTO_RESET if self.auto_reset else 0) | (_lib.F_WIDE_OFFSETS if wide_offsets else 0)
+        self._base_flags = (_lib.F_AUTO_RESET if self.auto_reset else 0) | (_lib.F_WIDE_OFFSETS if wide_offsets else 0) | \
+            (_lib.F_ONE_WAVE if one_wave else 0)
         self.env_offset = int(env_offset)
         self.rng = rng if rng is not None else ("python" if self._compat else "philox")
         if self.rng not in ("python", "philox"):

@@ -16,11 +16,14 @@ if True:
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     cont = len(sys.argv) > 3 and sys.argv[3] == 'cont'
     mode = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] in ("many", "rollout") else "step"
-    env = bsx.parallel_env(n_agents=n, n_envs=E, auto_reset=True, seed=1, continuous_actions=cont)
+    env = bsx.parallel_env(n_agents=n, n_envs=E, auto_reset=True, seed=1, continuous_actions=cont, one_wave=bool(os.environ.get("BSX_STAMPS_ONE_WAVE")))
     env.reset()
     L = _lib.load()
     G = 2 if n == 1 else (4 if n == 2 else 8)
     waves = (E * G + 63) // 64
+    split = mode == "step" and n == 1 and not cont and E <= 131072 and not os.environ.get("BSX_STAMPS_ONE_WAVE")   # the wave-specialised kernel: two rows per workgroup
+    if split:
+        waves *= 2
     if mode == "rollout":
         waves = (E + 31) // 32                      # the fused kernel's workgroup = 32 games; stamps are indexed by workgroup (its waves share a row)
     buf = torch.zeros(waves * 10, dtype=torch.int64, device="cuda")
@@ -30,7 +33,7 @@ if True:
         env.step_batch(acts[t])
     torch.cuda.synchronize()
     assert L.bsx_debug_set_stamps(buf.data_ptr()) == 0
-    tot = np.zeros(8); span = []; pre = 0.0
+    tot = np.zeros(8); span = []; pre = 0.0; split_acc = {}
     reps = 0
     if mode == "rollout":
         from deep_rl_battlespace_amd.rollout import PolicyRollout, StackedActor
@@ -52,6 +55,13 @@ if True:
             env.step_batch(acts[t])
         torch.cuda.synchronize()
         s10 = buf.cpu().numpy().reshape(waves, 10).astype(np.float64)
+        if split:                                  # even rows: planes waves, odd rows: bullets waves -- printed one after the other
+            roles = {"planes": s10[0::2], "bullets": s10[1::2]}
+            for rn, r in roles.items():
+                seg = np.diff(np.concatenate([r[:, 8:9], r[:, :8]], axis=1), axis=1)
+                acc = split_acc.setdefault(rn, np.zeros(8)); acc += seg.mean(0)
+            split_acc["n"] = split_acc.get("n", 0) + 1
+            s10 = s10[0::2]
         s = s10[:, :8]
         if FINE:
             s = s[:, [0, 1, 3, 4, 5, 6, 2, 7]]
@@ -59,6 +69,13 @@ if True:
         d = np.diff(s, axis=1)
         tot[:7] += d.mean(0); reps += 1
         span.append(((s[:, 7].max() - s[:, 0].min()), (s[:, 7] - s[:, 0]).mean(), (s[:, 0].max() - s[:, 0].min())))
+        lf = s10[:, 7] - s10[:, 8]                        # entry -> last stamp, per wave (s_memtime bases differ between XCDs: no cross-wave differences)
+        life = np.sort(lf)
+        lifes = life if reps == 1 else np.concatenate([lifes, life])
+        order = np.argsort(lf)
+        seg = np.diff(np.concatenate([s10[:, 8:9], s], axis=1), axis=1)      # entry -> T0 issue, then the seven phases
+        fast, slow = seg[order[:len(order) // 2]].mean(0), seg[order[-len(order) // 10:]].mean(0)
+        fs = np.stack([fast, slow]) if reps == 1 else fs + np.stack([fast, slow])
     names = ["T0 loads -> plane record, heading-table request", "classify, shot (ballot, philox, table step / sincos), staging", "move (or re-spawn), pose hand-off, staging", "obs geometry", "bullet rounds (packed pass, part 2)", "resolve + rewards / game end", "stores"]
     if FINE:
         names = ["T0 loads -> plane record, heading-table request", "group ballot, call mode", "shot ballot, owner flags staged", "LDS init, wave barrier",
@@ -70,5 +87,16 @@ if True:
         print(f"  {nme:40s} {v*10:9.1f} ns")
     if mode != "step":
         print(f"  {'end-of-tick fence (stores acknowledged)':40s} {fence / reps * 10:9.1f} ns   [mode {mode}: last tick of 16; the first phase includes the actor in rollout mode]")
+    q = np.percentile(lifes, [5, 25, 50, 75, 95, 99, 100]) * 10
+    print("  wave lifetime entry -> end, percentiles 5 / 25 / 50 / 75 / 95 / 99 / max: " + " / ".join(f"{v:.0f}" for v in q) + " ns")
+    if not FINE:
+        print("  per phase, ticks x 10: the faster half of the waves / the slowest tenth")
+        for nme, a_, b_ in zip(["entry -> T0 issue"] + names, fs[0] / reps * 10, fs[1] / reps * 10):
+            print(f"    {nme:40s} {a_:9.0f} {b_:9.0f}")
+    if split:
+        print("  wave-specialised kernel, shader cycles x 10 per segment (entry->T0 | T0->STAMP1 | ->move | ->geometry | ->bullets | ->resolve | ->stores | ->end):")
+        for rn in ("planes", "bullets"):
+            v = split_acc[rn] / split_acc["n"] * 10
+            print(f"    {rn:8s} " + " ".join(f"{x:8.0f}" for x in v) + f"   total {v.sum():8.0f}")
     sp = np.asarray(span).mean(0)
     print(f"  wave lifetime mean {sp[1]*10:.0f} ns; first-start to last-end {sp[0]*10:.0f} ns; start skew {sp[2]*10:.0f} ns")
