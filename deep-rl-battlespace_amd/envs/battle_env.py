@@ -87,8 +87,8 @@ class parallel_env:
         rng         "python" (stdlib random, reference draw order; default when n_envs is None) or "philox"
         wide_offsets  take the 64-bit-offset kernels (BSX_F_WIDE_OFFSETS) although the job is small enough for 32-bit offsets;
                     the library switches by itself above 4 GB per array -- same results, for tests
-        one_wave    1v1, discrete actions: keep the one-wave step kernel (BSX_F_ONE_WAVE) instead of the wave-specialised one that
-                    per-call launches of up to 131 072 games take -- same results, for tests and A/B runs
+        one_wave    BSX_F_ONE_WAVE: no effect with the product library; with a -DBSX_X_SPLIT variant build (the wave-specialised 1v1
+                    kernel, a measured experiment) it keeps the one-wave kernel -- same results, for the test that compares the two
         """
         if not isinstance(n_agents, (int, np.integer)) or not 1 <= n_agents <= _lib.MAX_N:
             raise ValueError(f"n_agents must be an int in 1..{_lib.MAX_N}, got {n_agents!r}")
