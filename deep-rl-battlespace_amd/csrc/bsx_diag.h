@@ -87,6 +87,13 @@ constexpr int X_DEPHASE_SLOT = BSX_X_DEPHASE_SLOT;
 #define BSX_X_SPLIT 0
 #endif
 constexpr int X_SPLIT_FORM = BSX_X_SPLIT;
+// -DBSX_X_NO_SPLIT_MANY: multi-tick 1v1 launches keep the one-wave kernel whatever their size (the product takes the two-wave form of
+// bsx_step_split.h up to 65 536 games; same results)
+#ifdef BSX_X_NO_SPLIT_MANY
+constexpr bool X_SPLIT_MANY = false;
+#else
+constexpr bool X_SPLIT_MANY = true;
+#endif
 
 #ifdef BSX_STAMPS
 constexpr int BUILD_FLAGS = int(DIAG & 0xFFu) | 0x100;

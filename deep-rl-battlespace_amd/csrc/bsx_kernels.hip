@@ -43,8 +43,9 @@
 #define BSX_INST_PER_CALL
 #define BSX_INST_MULTI_TICK
 #define BSX_INST_ROLLOUT
+#include "bsx_step_split.h"                              // the two-wave 1v1 kernels: the multi-tick form is product, the per-call forms a measured experiment (variant builds)
+#define BSX_INST_SPLIT_MANY
 #ifdef BSX_VARIANT
-#include "bsx_step_split.h"                              // (the wave-specialised 1v1 kernel: a measured experiment, variant builds only)
 #define BSX_INST_SPLIT
 #endif
 #ifdef BSX_VARIANT
@@ -281,26 +282,29 @@ void launch_for_n_w(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs&
 inline bool narrow_offsets_ok(int64_t E, int n, uint32_t flags) {
     return !(flags & BSX_F_WIDE_OFFSETS) && uint64_t(E) * uint64_t(2 * n) * 200ull <= 0xFFFFFFFFull;
 }
-// 1v1, discrete actions, one call per launch, a launch of at most SPLIT_MAX_GAMES games: the wave-specialised kernel (bsx_step_split.h) --
-// two waves per 64 agents, one for the planes and one for the bullets; same results bit for bit.  BSX_F_ONE_WAVE keeps the one-wave
-// kernel (tests run the two against each other; larger launches take it anyway: their SIMDs are full of waves as it is).
-constexpr int64_t SPLIT_MAX_GAMES = 131072;              // (four / eight waves of the split kernel per SIMD at 65 536 / 131 072 games)
+// The two-wave 1v1 kernels (bsx_step_split.h).  Multi-tick launches (bsx_step_many_discrete) of up to 65 536 games take the two-wave form
+// -- a GAME wave and an OUTPUTS wave per 64 agents, four waves per SIMD at 65 536 games: 3.07 -> 2.84 us per tick there, 2.65 -> 2.05 at
+// 32 768; beyond that the SIMDs are full of waves anyway and the one-wave kernel's fewer instructions win (131 072 games: 4.47 against 5.44).
+// The per-call forms are a measured experiment that loses (variant builds, -DBSX_X_SPLIT).  BSX_F_ONE_WAVE keeps the one-wave kernel.
+constexpr int64_t SPLIT_MAX_GAMES = 131072, SPLIT_MANY_MAX_GAMES = 65536;
 template <bool CONT, bool MULTI>
 inline bool split_applies(int n, const StepArgs& a, int64_t bound) {
-    return !CONT && !MULTI && X_SPLIT_FORM != 0 && n == 1 && bound <= SPLIT_MAX_GAMES && !(a.flags & BSX_F_ONE_WAVE);
+    if (CONT || n != 1 || (a.flags & BSX_F_ONE_WAVE)) return false;
+    return MULTI ? (X_SPLIT_MANY && bound <= SPLIT_MANY_MAX_GAMES) : (X_SPLIT_FORM != 0 && bound <= SPLIT_MAX_GAMES);
 }
-template <bool LG, bool OFF32>
+template <bool LG, bool OFF32, bool MANY>
 void launch_split(dim3 grid, hipStream_t s, const StepArgs& a, int64_t bound) {
-#ifdef BSX_VARIANT
-    hipLaunchKernelGGL((bsx_step_split_kernel<LG, OFF32>), grid, dim3(2 * SPB), 0, s, bound, a.st.envc, a.st.envd, a.st.plane, a.actions, a.st.bent, a.st.bcnt, a.action_kind, a);
+#ifndef BSX_VARIANT
+    if constexpr (MANY)
 #endif
+    hipLaunchKernelGGL((bsx_step_split_kernel<LG, OFF32, MANY>), grid, dim3(2 * SPB), 0, s, bound, a.st.envc, a.st.envd, a.st.plane, a.actions, a.st.bent, a.st.bcnt, a.action_kind, a);
 }
 template <bool CONT, bool MULTI, bool LG>
 void launch_for_n(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs& a, int64_t bound) {
-    if constexpr (!CONT && !MULTI) {
+    if constexpr (!CONT) {
         if (split_applies<CONT, MULTI>(n, a, bound)) {   // (the grid is the same: one workgroup per 64 agents, of two waves instead of one)
-            if (narrow_offsets_ok(a.E, n, a.flags)) launch_split<LG, true>(grid, s, a, bound);
-            else launch_split<LG, false>(grid, s, a, bound);
+            if (narrow_offsets_ok(a.E, n, a.flags)) launch_split<LG, true, MULTI>(grid, s, a, bound);
+            else launch_split<LG, false, MULTI>(grid, s, a, bound);
             return;
         }
     }

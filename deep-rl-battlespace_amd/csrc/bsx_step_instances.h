@@ -1,6 +1,6 @@
 // bsx_step_instances.h -- the 76 instantiations of bsx_step_kernel<N, CONT, MULTI, ACTOR, LG, OFF32>, in three groups, one translation unit
 // each (they compile side by side): per-call kernels (bsx_step_per_call.hip), multi-tick kernels (bsx_step_multi_tick.hip), fused rollouts
-// (bsx_step_rollout.hip).  bsx_kernels.hip -- launchers and C ABI -- includes this file with BSX_INST_KW = extern: explicit instantiation
+// (bsx_step_rollout.hip); and the four multi-tick instances of the two-wave 1v1 kernel (bsx_step_split.h) with the multi-tick group.  bsx_kernels.hip -- launchers and C ABI -- includes this file with BSX_INST_KW = extern: explicit instantiation
 // DECLARATIONS, so that nothing is instantiated there.  A diagnostic variant build (-DBSX_VARIANT) is ONE translation unit: bsx_kernels.hip
 // then defines all three groups itself (its stamp buffer is a device global of that unit).
 #pragma once
@@ -28,9 +28,18 @@ BSX_STEP_FAMILY(0, true) BSX_STEP_FAMILY(1, true) BSX_STEP_FAMILY(2, true) BSX_S
 BSX_ROLLOUT_FAMILY(1) BSX_ROLLOUT_FAMILY(2) BSX_ROLLOUT_FAMILY(3) BSX_ROLLOUT_FAMILY(4)
 #endif
 #ifdef BSX_INST_SPLIT
-#define BSX_SPLIT_INST(LG, OFF32)                                                                                                        \
-    BSX_INST_KW template __global__ void bsxk::bsx_step_split_kernel<LG, OFF32>(                                                         \
+#define BSX_SPLIT_INST(LG, OFF32, MANY)                                                                                                  \
+    BSX_INST_KW template __global__ void bsxk::bsx_step_split_kernel<LG, OFF32, MANY>(                                                   \
         const int64_t, const uint2* const, const uint2* const, const uint2* const, const void* const, const uint2* const, const uint32_t* const, \
         const int, const bsxk::StepArgs);
-BSX_SPLIT_INST(false, false) BSX_SPLIT_INST(false, true) BSX_SPLIT_INST(true, false) BSX_SPLIT_INST(true, true)
+BSX_SPLIT_INST(false, false, false) BSX_SPLIT_INST(false, true, false) BSX_SPLIT_INST(true, false, false) BSX_SPLIT_INST(true, true, false)
+#endif
+#ifdef BSX_INST_SPLIT_MANY
+#ifndef BSX_SPLIT_INST
+#define BSX_SPLIT_INST(LG, OFF32, MANY)                                                                                                  \
+    BSX_INST_KW template __global__ void bsxk::bsx_step_split_kernel<LG, OFF32, MANY>(                                                   \
+        const int64_t, const uint2* const, const uint2* const, const uint2* const, const void* const, const uint2* const, const uint32_t* const, \
+        const int, const bsxk::StepArgs);
+#endif
+BSX_SPLIT_INST(false, false, true) BSX_SPLIT_INST(false, true, true) BSX_SPLIT_INST(true, false, true) BSX_SPLIT_INST(true, true, true)
 #endif

@@ -194,11 +194,12 @@
     if constexpr (R_RDV_COUNTS != 0) {
         // split kernel, form A: the bullets wave hands its counts to the planes wave -- misses and base hits sit in s_agg (the work slots'
         // adds), the plane hits of the ordered resolve go beside them -- and the two waves meet once more
-        if constexpr (R_RDV_COUNTS == 1) s_npl[tid] = uint32_t(nplane);
+        // (one packed word per shooter in a buffer of the tick's parity: in the multi-tick form the bullets wave is a tick ahead)
+        if constexpr (R_RDV_COUNTS == 1) s_npl[(tk & 1) * SPB + tid] = uint32_t(nmiss) | (uint32_t(nbase) << 8) | (uint32_t(nplane) << 16);
         split_rendezvous();
         if constexpr (R_RDV_COUNTS == 2) {
-            if (pool_pass) { const uint32_t agg = s_agg[tid]; nmiss = int((agg >> 16) & 0xFFu); nbase = int((agg >> 24) & 0xFFu); }
-            nplane = int(s_npl[tid]);
+            const uint32_t c3 = s_npl[(tk & 1) * SPB + tid];
+            nmiss = int(c3 & 0xFFu); nbase = int((c3 >> 8) & 0xFFu); nplane = int((c3 >> 16) & 0xFFu);
         }
     }
     int nplane_other = 0, nbase_other = 0;               // 1v1: what the enemy's bullets did to me / to my base

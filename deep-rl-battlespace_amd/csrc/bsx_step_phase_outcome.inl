@@ -10,7 +10,7 @@
     double rew = double(nmiss) * p.cfg.miss_punishment + double(nbase) * p.cfg.hit_base_reward +
                  double(nplane) * p.cfg.hit_plane_reward;
     bool alive = valid && hp > 0;
-    if constexpr (R_OUTCOME) {                           // (split kernels: only the wave that stores the results works them out)
+    if constexpr (R_OUTCOME) {                           // (split kernels: a wave that neither stores the results nor carries the state on works nothing out)
     if (mode == M_PHYS) {
         const int hp_new = (N == 1) ? (valid ? hp : 0) - nplane_other : s_hp[tid];
         if (alive0 && hp_new <= 0) rew += p.cfg.die_punishment;                              // :359

@@ -15,7 +15,7 @@
         split_rendezvous();
         if constexpr (R_GEOM_LDS == 2) { const v4f_t gm = s_gm[tid]; ob_d = gm.x; ob_a = gm.y; oe_d[0] = gm.z; oe_a[0] = gm.w; }
     }
-    if constexpr (R_OUTCOME) {                           // (split kernels: one wave stores the step's results)
+    if constexpr (R_STORES) {                            // (split kernels: one wave stores the step's results)
     if (valid) {
         if (MULTI ? last_tick : (mode == M_PHYS || mode == M_RESET)) {
             const uint2 pw = pack_plane(x, y, hp, dir, CONT);
@@ -136,4 +136,4 @@
         }
     }
     }
-    if (MULTI && last_tick && lane == 0) *elem(p.st.bcnt, ix_t(wblk)) = pc;   // the pool's length travelled in a register
+    if (R_BULLETS && MULTI && last_tick && lane == 0) *elem(p.st.bcnt, ix_t(wblk)) = pc;   // the pool's length travelled in a register

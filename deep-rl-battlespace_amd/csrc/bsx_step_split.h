@@ -1,37 +1,52 @@
-// bsx_step_split.h -- bsx_step_split_kernel: the 1v1 per-call step() as TWO co-operating wavefronts per 64 agents.
-// A MEASURED EXPERIMENT of round 5 that LOSES; it is compiled in variant builds only (-DBSX_X_SPLIT=<1|2>, tools/build_variant.py) and kept
-// because the result is the evidence for DESIGN.md section 6 ("more waves per SIMD by splitting the agent's work"); namespace bsxk.
+// bsx_step_split.h -- bsx_step_split_kernel: the 1v1 step() as TWO co-operating wavefronts per 64 agents (round 5); namespace bsxk.
+// Part of the step() path of libbattlespace_hip.so (included after bsx_step_kernel.h).  Two uses:
+//   * MANY = true, PRODUCT: multi-tick launches (bsx_step_many_discrete) of up to 65 536 games -- 3.07 -> 2.84 us per tick at 65 536
+//     games (46.2 G agent-steps/s), 2.65 -> 2.05 at 32 768; instantiated with the multi-tick unit (bsx_step_multi_tick.hip);
+//   * MANY = false, a MEASURED EXPERIMENT THAT LOSES: one call per launch, variant builds only (-DBSX_X_SPLIT=<1|2>) -- kept because its
+//     result is the evidence for DESIGN.md section 6 ("more waves per SIMD by splitting the agent's work").
 //
 // The idea.  At 65 536 x 1v1 the one-wave kernel (bsx_step_kernel<1, ...>) puts two waves on a SIMD, and its tick is one long chain of
 // dependent latencies: first loads -> classify -> shot (Philox, step code) -> move -> geometry -> bullet round -> resolve -> outcome ->
-// stores; two lock-stepped waves hide little of each other.  But the observation geometry (the largest block of vector work) needs
-// nothing from the shot or the bullets, and the bullets need nothing from the geometry.  Here a workgroup is TWO waves over the same 64
-// agents (32 games), four waves per SIMD at 65 536 games:
-//   form 1 (A)  wave 0, PLANES: first loads -> classify -> move (or re-spawn) -> [rendezvous] -> geometry -> [rendezvous] -> outcome -> stores
-//               wave 1, BULLETS: pool loads -> [records from wave 0] -> classify, staging, Philox, shot -> [rendezvous] -> pool pass -> resolve -> [rendezvous]
-//   form 2 (G)  wave 0: everything but the geometry;  wave 1: move + geometry, its four observation values through LDS before the stores
-// The shared records are loaded once per workgroup (wave 0 hands the raw words over through LDS); a rendezvous is an LDS drain + s_barrier.
+// stores; two lock-stepped waves hide little of each other.  But the observation geometry (the largest block of vector work) and the
+// output stores need nothing from the shot or the bullets except three small counts, and the bullets need nothing from them.
+//
+// The multi-tick form (MANY).  The waves are persistent, so nothing is launched per tick, and ONE rendezvous per tick is enough:
+//   wave 0, GAME     the whole state machine except observations and outputs: classify -> shot -> move -> pool pass -> resolve -> outcome
+//                    (in registers), tick after tick; before each tick's outcome it leaves the bullets' counts in LDS (a buffer per tick parity)
+//   wave 1, OUTPUTS  classify -> move -> geometry -> [rendezvous: the counts] -> outcome -> stores (rows, rewards, flags; the state after the last tick)
+// Both waves carry the planes' and the game's records in registers and advance them by the same arithmetic on the same counts, so they
+// never exchange state; the outputs wave runs up to a tick behind, its geometry and stores beside the game wave's next shot.
+//
+// The per-call forms (experiment).  form 1: wave 0 PLANES (move, geometry, outcome, stores), wave 1 BULLETS (shot, pool pass, resolve),
+// three rendezvous (the shared records loaded once and handed over; post-move sprites; counts).  form 2: wave 0 everything but the
+// geometry, wave 1 move + geometry, its four observation values through LDS before the stores.  65 536 games: 6.31 / 6.46 us against 6.09
+// for the one-wave kernel; 32 768: 4.96 / 5.06 against 4.99; 131 072: 9.09 against 8.31.  Stamps say why: the planes wave lives 10.9 k
+// cycles and the bullets wave 9.3 k against 11.05 k of the one wave -- the chain first loads -> shot -> pool pass -> resolve -> outcome ->
+// stores IS the critical path of a single call, the geometry was the only large piece beside it, and the rendezvous, the hand-over and
+// twice the waves to launch cost what taking it off the chain saves.  In the multi-tick form the outputs wave's work overlaps the NEXT
+// tick of the game wave instead, and there is nothing to launch.
 //
 // How.  No second copy of the game logic: the kernel includes the SAME phase files as bsx_step_kernel, once per wave, with the R_*
 // constants of the wave's role.  The phases guard their side effects (LDS staging, stores, the pool pass, the rendezvous) by them;
-// everything that only feeds a guarded-off side effect is dead code to the compiler (50 registers per wave).  Results are those of the
-// one-wave kernel bit for bit (tests/test_hip_split.py builds the variant and runs the two against each other).
-//
-// What it measured (profiles/r05_experiments.json, one gpurun call): 65 536 games 6.31 us (form 1) / 6.46 (form 2) against 6.09 for the
-// one-wave kernel; 32 768 games 4.96 / 5.06 against 4.99; 131 072 games 9.09 (form 2) against 8.31.  In-kernel stamps say why: the
-// planes wave lives 10.9 k cycles and the bullets wave 9.3 k against 11.05 k of the one wave -- the chain first loads -> shot -> pool
-// pass -> resolve -> outcome -> stores IS the critical path, the geometry was the only large piece beside it, and three rendezvous, the
-// record hand-over and twice the waves to launch cost what taking it off the chain saves.
+// everything that only feeds a guarded-off side effect is dead code to the compiler.  Results are those of the one-wave kernels bit
+// for bit (tests/test_hip_split.py runs them against each other; every multi-tick 1v1 test, fuzz case and soak runs the two-wave form).
 #pragma once
 
 namespace bsxk {
 
-template <bool LG, bool OFF32>
+// MANY = false: one call per launch (forms 1 and 2 above).  MANY = true: T calls per launch (bsx_step_many_discrete) -- the form in which
+// specialisation can pay, because the waves are persistent (nothing to launch per tick) and ONE rendezvous per tick is enough:
+//   wave 0, GAME     the whole game state machine except the observations and the outputs: classify -> shot -> move -> pool pass -> resolve
+//                    -> outcome (in registers), tick after tick; before each tick's outcome it leaves the bullets' counts in LDS (by tick parity)
+//   wave 1, OUTPUTS  classify -> move -> geometry -> [rendezvous: the counts] -> outcome -> stores (rows, rewards, flags; state after the last tick)
+// Both waves carry the planes' and the game's records in registers and advance them by the same arithmetic on the same counts, so
+// they never exchange state; the outputs wave is up to a tick behind.
+template <bool LG, bool OFF32, bool MANY = false>
 __global__ __launch_bounds__(2 * SPB)
 void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uint2* const envd_, const uint2* const plane_, const void* const act_,
                            const uint2* const bent_, const uint32_t* const bcnt_, const int kind_, const StepArgs p_) {
     constexpr int N = 1;
-    constexpr bool CONT = false, MULTI = false, ACTOR = false;
+    constexpr bool CONT = false, MULTI = MANY, ACTOR = false;
     const StepArgs& p = p_;
     typedef typename std::conditional<OFF32, uint32_t, size_t>::type ix_t;     // row / element offsets
     typedef typename std::conditional<OFF32, int32_t, int64_t>::type ixs_t;    // game indices
@@ -48,7 +63,7 @@ void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uin
     const ixs_t e = wblk * EPB + (tid / G);
     const bool env_ok = e < ixs_t(E_);
     const bool valid = env_ok && a < A;
-    const ix_t EA = ix_t(p.E) * ix_t(A);
+    const ix_t EA = ix_t(MULTI ? E_ : p.E) * ix_t(A);
     const ixs_t ec = env_ok ? e : ixs_t(E_ - 1);
     const ix_t g = ix_t(ec) * A + (a < A ? a : A - 1);
     constexpr int NE = 1;
@@ -65,7 +80,7 @@ void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uin
     __shared__ double s_pr_all[1];
     __shared__ __attribute__((aligned(8))) u32x2 s_new_all[SPB];
     __shared__ uint32_t s_agg_all[SPB];
-    __shared__ uint32_t s_npl_all[SPB];                  // plane hits per shooter, bullets wave -> planes wave
+    __shared__ uint32_t s_npl_all[2 * SPB];              // the bullets' counts per shooter (misses | base hits << 8 | plane hits << 16), by tick parity
     __shared__ __attribute__((aligned(16))) v4u_t s_t0_all[SPB], s_t1_all[SPB];   // the first loads' raw words, wave 0 -> wave 1
     __shared__ __attribute__((aligned(16))) v4f_t s_gm_all[SPB];                  // form G: the four observation values, geometry wave -> storing wave
     constexpr bool CORNERS = true;
@@ -113,28 +128,53 @@ void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uin
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
     const bool has_act = kind_ >= 0;
-    // (names of the multi-tick forms that the phase files mention behind `if (MULTI ...)`: never reached here)
-    struct RawIn {}; struct DecIn {};
-    RawIn rin_next; DecIn din_next;
-    auto load_inputs = [](int, RawIn&) {};
-    auto decode = [](const RawIn&) { return DecIn{}; };
-    (void)rin_next; (void)din_next; (void)load_inputs; (void)decode;
+    // a call's inputs: the action (int32 or four scores) and, when the caller injects it, the shot's random() value -- fetched a tick ahead in
+    // the multi-tick form (as bsx_step_kernel does)
+    struct RawIn { int ai; float4 lg; double uu; };
+    struct DecIn { int act; double uu; };
+    auto load_inputs = [&](int t, RawIn& r) {
+        const char* const abase = static_cast<const char*>(act_) + (MULTI ? int64_t(t) * p.act_tb : int64_t(0));
+        if constexpr (LG) r.lg = *reinterpret_cast<const float4*>(elem(abase, has_act ? g * 16 : ix_t(0)));
+        else r.ai = *reinterpret_cast<const int32_t*>(elem(abase, has_act ? g * 4 : ix_t(0)));
+        __builtin_amdgcn_sched_barrier(0);
+        const double* const ut = (MULTI && p.u) ? p.u + int64_t(t) * p.u_ts : p.u;
+        if (ut) r.uu = ut[g];
+    };
+    auto decode = [&](const RawIn& r) {
+        DecIn d = {-1, 0.0};
+        if (has_act) d.act = LG ? argmax4(r.lg.x, r.lg.y, r.lg.z, r.lg.w) : r.ai;
+        if (p.u) d.uu = r.uu;
+        return d;
+    };
     const ix_t pool0 = ix_t(wblk) * ix_t(POOL_CAP);
-    const int tk = 0;
     // X_SPLIT_FORM 1 (A): wave 0 = planes (move, geometry, outcome, stores), wave 1 = bullets (shot, pool pass, resolve); three rendezvous
     // X_SPLIT_FORM 2 (G): wave 0 = everything but the observation geometry, wave 1 = move + geometry only; two rendezvous
+    if constexpr (MANY) {
+        if (role_wave == 0) {
+            constexpr bool R_BULLETS = true, R_MOVE = true, R_STAGE = true, R_GEOM = false, R_OUTCOME = true, R_STORES = false, R_RDV_MOVE = false;
+            constexpr int R_RDV_COUNTS = 1, R_GEOM_LDS = 0;
+            s_ov[tid] = 0ull;                            // (cleared again by whoever finds it set)
+#include "bsx_step_split_many_body.inl"
+        } else {
+            constexpr bool R_BULLETS = false, R_MOVE = true, R_STAGE = false, R_GEOM = true, R_OUTCOME = true, R_STORES = true, R_RDV_MOVE = false;
+            constexpr int R_RDV_COUNTS = 2, R_GEOM_LDS = 0;
+#include "bsx_step_split_many_body.inl"
+        }
+    } else {
+    const int tk = 0;
     if (role_wave == 0) {
         constexpr bool FIRST = true;                     // this wave loads the shared records and hands them over
-        constexpr bool R_BULLETS = X_SPLIT_FORM == 2, R_MOVE = true, R_STAGE = true, R_GEOM = X_SPLIT_FORM == 1, R_OUTCOME = true, R_RDV_MOVE = X_SPLIT_FORM == 1;
+        constexpr bool R_BULLETS = X_SPLIT_FORM == 2, R_MOVE = true, R_STAGE = true, R_GEOM = X_SPLIT_FORM == 1, R_OUTCOME = true, R_STORES = true, R_RDV_MOVE = X_SPLIT_FORM == 1;
         constexpr int R_RDV_COUNTS = X_SPLIT_FORM == 1 ? 2 : 0, R_GEOM_LDS = X_SPLIT_FORM == 2 ? 2 : 0;
         if constexpr (R_BULLETS) s_ov[tid] = 0ull;       // (cleared again by whoever finds it set)
 #include "bsx_step_split_body.inl"
     } else {
         constexpr bool FIRST = false;
-        constexpr bool R_BULLETS = X_SPLIT_FORM == 1, R_MOVE = X_SPLIT_FORM == 2, R_STAGE = false, R_GEOM = X_SPLIT_FORM == 2, R_OUTCOME = false, R_RDV_MOVE = X_SPLIT_FORM == 1;
+        constexpr bool R_BULLETS = X_SPLIT_FORM == 1, R_MOVE = X_SPLIT_FORM == 2, R_STAGE = false, R_GEOM = X_SPLIT_FORM == 2, R_OUTCOME = false, R_STORES = false, R_RDV_MOVE = X_SPLIT_FORM == 1;
         constexpr int R_RDV_COUNTS = X_SPLIT_FORM == 1 ? 1 : 0, R_GEOM_LDS = X_SPLIT_FORM == 2 ? 1 : 0;
         if constexpr (R_BULLETS) s_ov[tid] = 0ull;
 #include "bsx_step_split_body.inl"
+    }
     }
 }
 

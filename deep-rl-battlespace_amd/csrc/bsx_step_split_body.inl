@@ -14,6 +14,8 @@
         float* const rew_t = p.rew;
         uint8_t* const done_t = p.done;
         (void)eb; (void)u_t; (void)obs_t; (void)rew_t; (void)done_t; (void)EAt;
+        RawIn rin_next = {}; DecIn din_next = {-1, 0.0};             // (named by the phases behind `if (MULTI ...)`: never reached in this form)
+        (void)rin_next; (void)din_next;
         // ---- T0: every load this role needs, back to back (what a role does not use -- the pool for the planes wave -- is dead code)
         int x = 0, y = 0, hp = 0;
         uint32_t games = 0;

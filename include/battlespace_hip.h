@@ -54,7 +54,7 @@ typedef struct BsxRewards {
 /* Flags for bsx_step_* */
 #define BSX_F_AUTO_RESET 1u  /* a call on a finished env re-spawns it (Philox) instead of the inert step of battle_env.py:303-306 */
 #define BSX_F_EMPTY_CALL 2u  /* step({}) : every running env ties (battle_env.py:309-313) */
-#define BSX_F_ONE_WAVE 8u     /* accepted, no effect in the product build.  A variant build with -DBSX_X_SPLIT takes the wave-specialised 1v1 kernel (csrc/bsx_step_split.h: a measured experiment, slower) for per-call launches of up to 131 072 games; this flag keeps the one-wave kernel there, so that a test can run the two against each other.  Same results either way */
+#define BSX_F_ONE_WAVE 8u     /* keep the one-wave step kernel where the library would take a two-wave form of it (csrc/bsx_step_split.h): multi-tick 1v1 launches of up to 65 536 games (bsx_step_many_discrete: a game wave + an outputs wave per 64 agents); in variant builds with -DBSX_X_SPLIT also per-call launches (a measured experiment).  Same results either way -- for the tests that run the two against each other, and for A/B runs */
 #define BSX_F_WIDE_OFFSETS 4u /* take the 64-bit-offset kernels although the job's arrays stay below 4 GB (they are chosen automatically above that; same results -- for tests) */
 
 /* Action encodings for bsx_step_discrete */

@@ -1,7 +1,8 @@
-"""The wave-specialised 1v1 step kernel (csrc/bsx_step_split.h: a planes wave and a bullets wave per 64 agents; a variant build takes it
-for per-call launches of up to 131 072 games of 1v1 with discrete actions) against the one-wave kernel (BSX_F_ONE_WAVE / `one_wave=True`):
-the same step() of envs/battle_env.py:281-381, so every output of every call and the complete game state must be IDENTICAL -- the two
-kernels include the same phase files, each wave with the side effects of its role."""
+"""The two-wave 1v1 step kernels (csrc/bsx_step_split.h) against the one-wave kernels (BSX_F_ONE_WAVE / `one_wave=True`): the same step() of
+envs/battle_env.py:281-381, so every output of every call and the complete game state must be IDENTICAL -- the kernels include the same
+phase files, each wave with the side effects of its role.  The MULTI-TICK form (a game wave + an outputs wave per 64 agents) is what the
+product runs for bsx_step_many_discrete up to 65 536 games; the PER-CALL forms (a planes wave + a bullets wave) are a measured experiment
+that loses and live in variant builds only."""
 import os
 import subprocess
 import sys
@@ -19,10 +20,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 inner = pytest.mark.skipif(os.environ.get("BSX_SPLIT_INNER") != "1", reason="runs in the child process of test_split_variant_equals_the_one_wave_kernel")
 
 
-@pytest.mark.parametrize("form", [1])                   # (form 2 -- a geometry wave beside a wave for everything else -- was measured too and is recorded)
+@pytest.mark.parametrize("form", ["1"])                 # (per-call form 2 -- a geometry wave beside a wave for everything else -- was measured too and is recorded)
 def test_split_variant_equals_the_one_wave_kernel(form):
+    flag = f"-DBSX_X_SPLIT={form}"
     try:                                                 # (an experiment's test must not cost the suite: no compiler on the box, or a slow one, skips it)
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "build_variant.py"), f"citest_split{form}", f"-DBSX_X_SPLIT={form}"],
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "build_variant.py"), f"citest_split{form}", flag],
                              capture_output=True, text=True, timeout=600)
     except (OSError, subprocess.TimeoutExpired) as exc:
         pytest.skip(f"could not build the variant library here: {type(exc).__name__}")
@@ -31,8 +33,9 @@ def test_split_variant_equals_the_one_wave_kernel(form):
     lib = out.stdout.strip().splitlines()[-1]
     try:
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "inner_"],
-                           capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, BSX_LIB_PATH=lib, BSX_SPLIT_INNER="1"))
-        assert r.returncode == 0 and " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], (r.stdout[-3000:], r.stderr[-1500:])
+                           capture_output=True, text=True, timeout=900, cwd=ROOT,
+                           env=dict(os.environ, BSX_LIB_PATH=lib, BSX_SPLIT_INNER="1"))
+        assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-3000:], r.stderr[-1500:])
     finally:
         os.remove(lib)
 
@@ -130,3 +133,39 @@ def test_inner_drop_in_game_runs_on_the_split_kernel_too():
             log.append(np.concatenate([o[k] for k in env.possible_agents] + [[float(r[k]) for k in env.possible_agents], [float(d[k]) for k in env.possible_agents]]))
         outs.append((np.concatenate(log), env.total_games, env.winner))
     assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1:] == outs[1][1:]
+
+
+@pytest.mark.parametrize("E,enc,auto,inject", [(65536, "int", True, False), (3000, "scores", True, False), (33, "int", False, True), (131072, "int", True, False)])
+def test_two_wave_multi_tick_kernel_equals_the_one_wave_multi_tick_kernel(E, enc, auto, inject):
+    """The PRODUCT's multi-tick 1v1 launches of up to 65 536 games (bsx_step_many_discrete; csrc/bsx_step_split.h, MANY): a GAME wave (the
+    whole state machine, up to a tick ahead) and an OUTPUTS wave (geometry, rewards, rows, flags) per 64 agents, against the one-wave
+    multi-tick kernel (BSX_F_ONE_WAVE): every tick's outputs, env_done per tick and the complete state identical.  (131 072 games take the
+    one-wave kernel either way: the case checks that the size switch changes nothing.)"""
+    kw = dict(n_agents=1, n_envs=E, seed=41, auto_reset=auto)
+    a, b = _env(**kw), _env(one_wave=True, **kw)
+    a.reset(); b.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(6)
+    T = 50
+    for rep in range(6 if E <= 65536 else 3):
+        act = torch.where(torch.rand((T, E, 2), generator=g, device="cuda") < 0.5, 1, torch.randint(-1, 5, (T, E, 2), generator=g, device="cuda")).to(torch.int32)
+        u = torch.rand((T, E, 2), generator=g, device="cuda", dtype=torch.float64) if inject else None
+        if enc == "scores":
+            sc = torch.rand((T, E, 2, 4), generator=g, device="cuda") * 0.5
+            sc.scatter_(3, act.clamp(0, 3).long().unsqueeze(-1), 1.0)
+            act = sc
+        eda, edb = torch.zeros((T, E), dtype=torch.uint8, device="cuda"), torch.zeros((T, E), dtype=torch.uint8, device="cuda")
+        ra = a.step_many(act, store=True, u=u, env_done_out=eda)
+        rb = b.step_many(act, store=True, u=u, env_done_out=edb)
+        for x, y, name in zip(ra, rb, ("obs", "rew", "done")):
+            assert torch.equal(x, y), (rep, name)
+        assert torch.equal(eda, edb), rep
+        _same_state(a, b)
+        if not auto:
+            m = a.env_done.clone()
+            a.reset(mask=m); b.reset(mask=m)
+    # and a launch whose results are the env-owned last-tick tensors (store=False)
+    act = torch.randint(0, 4, (7, E, 2), generator=g, device="cuda", dtype=torch.int32)
+    ra, rb = a.step_many(act), b.step_many(act)
+    assert all(torch.equal(x, y) for x, y in zip(ra, rb))
+    _same_state(a, b)
+    assert int(a.counters()[:, 0].sum()) > 0
