@@ -15,15 +15,27 @@
         split_rendezvous();
         if constexpr (R_GEOM_LDS == 2) { const v4f_t gm = s_gm[tid]; ob_d = gm.x; ob_a = gm.y; oe_d[0] = gm.z; oe_a[0] = gm.w; }
     }
-    if constexpr (R_STORES) {                            // (split kernels: one wave stores the step's results)
+    // two-wave multi-tick kernel: the game wave publishes what the outputs wave needs of this tick (one 16-byte word per agent, a buffer
+    // per tick parity): the post-move position, heading, flags, the enemy base, the reward -- and the two waves meet
+    if constexpr (R_PUB == 1) {
+        const bool on_pub = alive && (mode == M_PHYS ? nhp_ - nplane : nhp_) > 0;
+        s_pub[(tk & 1) * SPB + tid] = v4u_t{pack_xy(x, y),
+                                            uint32_t(int(dir)) | (alive ? 512u : 0u) | (on_pub ? 1024u : 0u) | (er.done ? 2048u : 0u),
+                                            __float_as_uint(float(rew)), pack_xy(team == 0 ? er.bbx : er.brx, team == 0 ? er.bby : er.bry)};
+        split_rendezvous();
+    }
+    if constexpr (R_ST_STATE || R_ST_OUT) {              // (split kernels: which wave stores what of the step's results)
     if (valid) {
+        if constexpr (R_ST_STATE)
         if (MULTI ? last_tick : (mode == M_PHYS || mode == M_RESET)) {
             const uint2 pw = pack_plane(x, y, hp, dir, CONT);
             st_store<NT_STATE>(reinterpret_cast<u32x2*>(elem(p.st.plane, gt)), u32x2{pw.x, pw.y});
             if constexpr (CONT) st_store<NT_STATE>(elem(p.st.pdirf, gt), dir);   // continuous headings are fractional: the float64 beside the record
         }
+        if constexpr (R_ST_OUT) {
         out_store(elem(rew_t, gt), float(rew));
         out_store(elem(done_t, gt), er.done ? uint8_t(1) : uint8_t(alive ? 0 : 1));
+        }
     }
     // observation row: a dead observer sees all -1, a dead enemy is [-1,-1,-1] (battle_env.py:215-218,235-242).
     // Compile-time team sizes outside the fused rollout: the row leaves straight from registers, 16 bytes at a time plus a tail
@@ -31,7 +43,8 @@
     // rows in LDS to emit fully coalesced 16-byte stores; with non-temporal stores that transpose only costs: C2 8.21 -> 7.92 us,
     // 4v4 28.0 -> 24.9 (-DBSX_X_LDSOBS builds it for A/B).  The fused rollout keeps its rows in LDS (the actor reads them there).
     constexpr bool DIRECT_OBS = !ACTOR && N > 0 && OBS_FORM == 0;
-    if constexpr (DIRECT_OBS) {
+    if constexpr (!R_ST_OUT) {
+    } else if constexpr (DIRECT_OBS) {
         constexpr int D = 3 * N + 2;
         float row[D];
         row[0] = alive ? ob_d : -1.0f;
@@ -111,6 +124,7 @@
             for (int i = 0; i < D; ++i) out[i] = srow[i];
         }
     }
+    if constexpr (R_ST_STATE)
     if (valid) {
         if (a == 0) {
             if (MULTI ? last_tick : (mode != M_INERT)) {
