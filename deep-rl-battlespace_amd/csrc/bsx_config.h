@@ -27,7 +27,6 @@ constexpr int X_OBS_PLAIN_FROM = 99;
 constexpr int X_ATAN_TABLE_MAX_K = 2;
 constexpr int X_OPAQUE_MULTI_MASK = 0x1C18;      // multi-tick kernels that recompute lane-derived addresses per tick (bsx_step_kernel.h)
 constexpr int X_PAD_SALU = 0, X_PAD_VALU = 0, X_DEPHASE_SLOT = 0;
-constexpr int X_SPLIT_MANY_FORM = 1;
 constexpr bool X_SPLIT_MANY = true;                 // multi-tick 1v1 launches of up to 65 536 games take the two-wave kernel (bsx_step_split.h)
 constexpr int X_SPLIT_FORM = 0;                      // (the wave-specialised 1v1 kernel of bsx_step_split.h is a variant-build experiment: -DBSX_X_SPLIT=<1|2>)
 #define STAMP(i) do { } while (0)

@@ -87,12 +87,6 @@ constexpr int X_DEPHASE_SLOT = BSX_X_DEPHASE_SLOT;
 #define BSX_X_SPLIT 0
 #endif
 constexpr int X_SPLIT_FORM = BSX_X_SPLIT;
-// -DBSX_X_SPLIT_MANY_FORM=<1|2>: the two-wave multi-tick kernel with an outputs wave that carries the state too (1) or only takes what
-// the game wave publishes per tick (2); same results
-#ifndef BSX_X_SPLIT_MANY_FORM
-#define BSX_X_SPLIT_MANY_FORM 1
-#endif
-constexpr int X_SPLIT_MANY_FORM = BSX_X_SPLIT_MANY_FORM;
 // -DBSX_X_NO_SPLIT_MANY: multi-tick 1v1 launches keep the one-wave kernel whatever their size (the product takes the two-wave form of
 // bsx_step_split.h up to 65 536 games; same results)
 #ifdef BSX_X_NO_SPLIT_MANY

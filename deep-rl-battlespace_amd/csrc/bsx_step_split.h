@@ -15,7 +15,9 @@
 //                    (in registers), tick after tick; before each tick's outcome it leaves the bullets' counts in LDS (a buffer per tick parity)
 //   wave 1, OUTPUTS  classify -> move -> geometry -> [rendezvous: the counts] -> outcome -> stores (rows, rewards, flags; the state after the last tick)
 // Both waves carry the planes' and the game's records in registers and advance them by the same arithmetic on the same counts, so they
-// never exchange state; the outputs wave runs up to a tick behind, its geometry and stores beside the game wave's next shot.
+// never exchange state; the outputs wave runs up to a tick behind, its geometry and stores beside the game wave's next shot.  (A form
+// in which the outputs wave repeats none of the game logic and takes a 16-byte publish per agent and tick instead was measured too:
+// +-1 % at 65 536 games, 7 % slower at 32 768 -- not kept; profiles/r05_experiments.json.)
 //
 // The per-call forms (experiment).  form 1: wave 0 PLANES (move, geometry, outcome, stores), wave 1 BULLETS (shot, pool pass, resolve),
 // three rendezvous (the shared records loaded once and handed over; post-move sprites; counts).  form 2: wave 0 everything but the
@@ -82,7 +84,6 @@ void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uin
     __shared__ uint32_t s_agg_all[SPB];
     __shared__ uint32_t s_npl_all[2 * SPB];              // the bullets' counts per shooter (misses | base hits << 8 | plane hits << 16), by tick parity
     __shared__ __attribute__((aligned(16))) v4u_t s_t0_all[SPB], s_t1_all[SPB];   // the first loads' raw words, wave 0 -> wave 1
-    __shared__ __attribute__((aligned(16))) v4u_t s_pub_all[2 * SPB];             // multi-tick form 2: what a tick's outputs need, game wave -> outputs wave, by tick parity
     __shared__ __attribute__((aligned(16))) v4f_t s_gm_all[SPB];                  // form G: the four observation values, geometry wave -> storing wave
     constexpr bool CORNERS = true;
     typedef u32x2 rect_t;
@@ -104,7 +105,6 @@ void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uin
     auto* const s_agg = BSX_LDS(uint32_t, s_agg_all);
     auto* const s_npl = BSX_LDS(uint32_t, s_npl_all);
     auto* const s_gm = (__attribute__((address_space(3))) volatile v4f_t*)(uintptr_t)(s_gm_all);
-    auto* const s_pub = (__attribute__((address_space(3))) volatile v4u_t*)(uintptr_t)(s_pub_all);
     auto* const s_t0 = (__attribute__((address_space(3))) volatile v4u_t*)(uintptr_t)(s_t0_all);
     auto* const s_t1 = (__attribute__((address_space(3))) volatile v4u_t*)(uintptr_t)(s_t1_all);
     auto* const s_eb = BSX_LDS(rect_t, s_eb_all);
@@ -152,28 +152,19 @@ void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uin
     // X_SPLIT_FORM 1 (A): wave 0 = planes (move, geometry, outcome, stores), wave 1 = bullets (shot, pool pass, resolve); three rendezvous
     // X_SPLIT_FORM 2 (G): wave 0 = everything but the observation geometry, wave 1 = move + geometry only; two rendezvous
     if constexpr (MANY) {
-        // X_SPLIT_MANY_FORM 1: the outputs wave carries the state too (classify, move, outcome on the game wave's counts) and stores everything
-        // X_SPLIT_MANY_FORM 2: the game wave owns the state alone (and stores it); per tick it PUBLISHES what the outputs of the tick need --
-        //                      position, heading, flags, enemy base, reward: 16 bytes per agent -- and the outputs wave does the geometry,
-        //                      the row and the output stores from that, with none of the game logic
         if (role_wave == 0) {
             constexpr bool R_BULLETS = true, R_MOVE = true, R_STAGE = true, R_GEOM = false, R_OUTCOME = true, R_RDV_MOVE = false;
-            constexpr bool R_ST_STATE = X_SPLIT_MANY_FORM == 2, R_ST_OUT = false;
-            constexpr int R_RDV_COUNTS = X_SPLIT_MANY_FORM == 2 ? 0 : 1, R_GEOM_LDS = 0, R_PUB = X_SPLIT_MANY_FORM == 2 ? 1 : 0;
+            constexpr bool R_ST_STATE = false, R_ST_OUT = false;
+            constexpr int R_RDV_COUNTS = 1, R_GEOM_LDS = 0;
             s_ov[tid] = 0ull;                            // (cleared again by whoever finds it set)
 #include "bsx_step_split_many_body.inl"
-        } else if constexpr (X_SPLIT_MANY_FORM == 2) {
-            constexpr bool R_BULLETS = false, R_GEOM = true, R_ST_STATE = false, R_ST_OUT = true;
-            constexpr int R_GEOM_LDS = 0, R_PUB = 0;
-#include "bsx_step_split_out_body.inl"
         } else {
             constexpr bool R_BULLETS = false, R_MOVE = true, R_STAGE = false, R_GEOM = true, R_OUTCOME = true, R_RDV_MOVE = false;
             constexpr bool R_ST_STATE = true, R_ST_OUT = true;
-            constexpr int R_RDV_COUNTS = 2, R_GEOM_LDS = 0, R_PUB = 0;
+            constexpr int R_RDV_COUNTS = 2, R_GEOM_LDS = 0;
 #include "bsx_step_split_many_body.inl"
         }
     } else {
-    constexpr int R_PUB = 0;
     const int tk = 0;
     if (role_wave == 0) {
         constexpr bool FIRST = true;                     // this wave loads the shared records and hands them over
