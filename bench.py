@@ -620,14 +620,15 @@ def main():
             live = round(float(env.export_state(("bl_live",))["bl_live"].float().sum()) / (E * A), 3)
         return dict(env=env, walls=walls, kms=kms, G=G, live=live, Kb=Kb or K, solo=solo)
 
-    def split_many(n, continuous, many, E):
-        """csrc split_applies(): multi-tick 1v1 launches of up to 65 536 games run as the two-wave kernel (bsx_step_split.h)."""
-        return many and n == 1 and not continuous and E <= 65536
+    def two_wave(n, continuous, many, E):
+        """csrc split_applies(): discrete 1v1 launches run as a two-wave kernel (bsx_step_split.h) -- multi-tick launches of up to 65 536
+        games, per-call launches of up to 98 304."""
+        return n == 1 and not continuous and E <= (65536 if many else 98304)
 
     def kernel_name(n, continuous, many, E):
         narrow = E * 2 * n * 200 <= 0xFFFFFFFF            # csrc narrow_offsets_ok(): 32-bit offsets while every array stays below 4 GB
-        if split_many(n, continuous, many, E):
-            return f"bsx_step_split_kernel<false,{'true' if narrow else 'false'},true>"      # <LG, OFF32, MANY>
+        if two_wave(n, continuous, many, E):
+            return f"bsx_step_split_kernel<false,{'true' if narrow else 'false'},{'true' if many else 'false'}>"      # <LG, OFF32, MANY>
         return (f"bsx_step_kernel<{n if n <= 4 else 0},{'true' if continuous else 'false'},{'true' if many else 'false'},false,false,"
                 f"{'true' if narrow else 'false'}>")       # <N, CONT, MULTI, ACTOR, LG, OFF32>
 
@@ -757,7 +758,7 @@ def main():
             Gw = 2
             while Gw < A:
                 Gw *= 2
-            grid_threads = ((E + 64 // Gw - 1) // (64 // Gw)) * 64 * (2 if split_many(n, args.continuous, many, E) else 1)
+            grid_threads = ((E + 64 // Gw - 1) // (64 // Gw)) * 64 * (2 if two_wave(n, args.continuous, many, E) else 1)
             live_b, info = live_traffic(args, kernel_name(n, args.continuous, many, E), grid_threads)
             if live_b is not None:
                 traffic, tdetail = live_b, info

@@ -27,8 +27,12 @@ constexpr int X_OBS_PLAIN_FROM = 99;
 constexpr int X_ATAN_TABLE_MAX_K = 2;
 constexpr int X_OPAQUE_MULTI_MASK = 0x1C18;      // multi-tick kernels that recompute lane-derived addresses per tick (bsx_step_kernel.h)
 constexpr int X_PAD_SALU = 0, X_PAD_VALU = 0, X_DEPHASE_SLOT = 0;
-constexpr bool X_SPLIT_MANY = true;                 // multi-tick 1v1 launches of up to 65 536 games take the two-wave kernel (bsx_step_split.h)
-constexpr int X_SPLIT_FORM = 0;                      // (the wave-specialised 1v1 kernel of bsx_step_split.h is a variant-build experiment: -DBSX_X_SPLIT=<1|2>)
+constexpr int X_PRIO_BY_SLOT = 0;
+// The two-wave 1v1 kernels (bsx_step_split.h).  Multi-tick launches of up to 65 536 games: a GAME wave + an OUTPUTS wave per 64 agents.
+// Per-call launches of up to 98 304 games: form 2, a wave for everything but the observation geometry + a GEOMETRY wave.  In both the
+// first wave -- whose chain sets the pace -- runs at s_setprio 1: without that the per-call form loses to the one-wave kernel.
+constexpr bool X_SPLIT_MANY = true;
+constexpr int X_SPLIT_FORM = 2, X_SPLIT_PRIO = 1;
 #define STAMP(i) do { } while (0)
 #define FSTAMP(i) do { } while (0)
 #define PSTAMP(i) do { } while (0)

@@ -81,12 +81,24 @@ constexpr int X_PAD_SALU = BSX_X_PAD_SALU, X_PAD_VALU = BSX_X_PAD_VALU;
 #endif
 constexpr int X_DEPHASE_SLOT = BSX_X_DEPHASE_SLOT;
 
-// -DBSX_X_SPLIT=<1|2>: 1v1 per-call launches of up to 131 072 games take the wave-specialised kernel of bsx_step_split.h (same results):
-// form 1 = a planes wave + a bullets wave per 64 agents, form 2 = a wave for everything but the observation geometry + a geometry wave
+// -DBSX_X_SPLIT=<0|1|2|3>: the form of the two-wave kernel of bsx_step_split.h that 1v1 per-call launches take (same results): 0 = none (the
+// one-wave kernel), 1 = a planes wave + a bullets wave per 64 agents, 2 (the product) = a wave for everything but the observation geometry
+// + a geometry wave, 3 = the multi-tick kernel as a launch of one tick (unfinished: fails parity)
 #ifndef BSX_X_SPLIT
-#define BSX_X_SPLIT 0
+#define BSX_X_SPLIT 2
 #endif
 constexpr int X_SPLIT_FORM = BSX_X_SPLIT;
+// -DBSX_X_SPLIT_PRIO=<-3..3>: s_setprio of the first wave of the two-wave kernels (negative: of the second wave of the per-call forms
+// instead); the product has 1 (same results)
+#ifndef BSX_X_SPLIT_PRIO
+#define BSX_X_SPLIT_PRIO 1
+#endif
+constexpr int X_SPLIT_PRIO = BSX_X_SPLIT_PRIO;
+// -DBSX_X_PRIO_BY_SLOT=<1|2>: one-wave kernels, s_setprio by the wave's slot on its SIMD (1: slot & 1, 2: slot & 3; same results)
+#ifndef BSX_X_PRIO_BY_SLOT
+#define BSX_X_PRIO_BY_SLOT 0
+#endif
+constexpr int X_PRIO_BY_SLOT = BSX_X_PRIO_BY_SLOT;
 // -DBSX_X_NO_SPLIT_MANY: multi-tick 1v1 launches keep the one-wave kernel whatever their size (the product takes the two-wave form of
 // bsx_step_split.h up to 65 536 games; same results)
 #ifdef BSX_X_NO_SPLIT_MANY

@@ -43,11 +43,9 @@
 #define BSX_INST_PER_CALL
 #define BSX_INST_MULTI_TICK
 #define BSX_INST_ROLLOUT
-#include "bsx_step_split.h"                              // the two-wave 1v1 kernels: the multi-tick form is product, the per-call forms a measured experiment (variant builds)
+#include "bsx_step_split.h"                              // the two-wave 1v1 kernels
 #define BSX_INST_SPLIT_MANY
-#ifdef BSX_VARIANT
 #define BSX_INST_SPLIT
-#endif
 #ifdef BSX_VARIANT
 #define BSX_INST_KW
 #else
@@ -282,25 +280,39 @@ void launch_for_n_w(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs&
 inline bool narrow_offsets_ok(int64_t E, int n, uint32_t flags) {
     return !(flags & BSX_F_WIDE_OFFSETS) && uint64_t(E) * uint64_t(2 * n) * 200ull <= 0xFFFFFFFFull;
 }
-// The two-wave 1v1 kernels (bsx_step_split.h).  Multi-tick launches (bsx_step_many_discrete) of up to 65 536 games take the two-wave form
-// -- a GAME wave and an OUTPUTS wave per 64 agents, four waves per SIMD at 65 536 games: 3.07 -> 2.84 us per tick there, 2.65 -> 2.05 at
-// 32 768; beyond that the SIMDs are full of waves anyway and the one-wave kernel's fewer instructions win (131 072 games: 4.47 against 5.44).
-// The per-call forms are a measured experiment that loses (variant builds, -DBSX_X_SPLIT).  BSX_F_ONE_WAVE keeps the one-wave kernel.
-constexpr int64_t SPLIT_MAX_GAMES = 131072, SPLIT_MANY_MAX_GAMES = 65536;
+// The two-wave 1v1 kernels (bsx_step_split.h); in both the first wave runs at s_setprio 1 (bsx_config.h).  BSX_F_ONE_WAVE keeps the one-wave kernel.
+// Multi-tick launches (bsx_step_many_discrete) of up to 65 536 games: a GAME wave and an OUTPUTS wave per 64 agents, four waves per SIMD at
+// 65 536 games -- 3.05 -> 2.58 us per tick there, 2.65 -> 1.81 at 32 768; beyond that the SIMDs are full of waves anyway and the one-wave
+// kernel's fewer instructions win (131 072 games: 4.45 against 5.2).
+// Per-call launches (bsx_step_discrete, *_range) of up to 98 304 games: a wave for everything but the observation geometry and a GEOMETRY
+// wave -- 6.08 -> 5.66 us per call at 65 536 games, 4.34 -> 4.02 at 4 096, 7.27 -> 6.90 at 98 304 (131 072: loses).
+#ifndef BSX_X_SPLIT_MANY_MAX
+#define BSX_X_SPLIT_MANY_MAX 65536
+#endif
+#ifndef BSX_X_SPLIT_MAX
+#define BSX_X_SPLIT_MAX 98304
+#endif
+constexpr int64_t SPLIT_MAX_GAMES = BSX_X_SPLIT_MAX, SPLIT_MANY_MAX_GAMES = BSX_X_SPLIT_MANY_MAX;
 template <bool CONT, bool MULTI>
 inline bool split_applies(int n, const StepArgs& a, int64_t bound) {
     if (CONT || n != 1 || (a.flags & BSX_F_ONE_WAVE)) return false;
-    return MULTI ? (X_SPLIT_MANY && bound <= SPLIT_MANY_MAX_GAMES) : (X_SPLIT_FORM != 0 && bound <= SPLIT_MAX_GAMES);
+    return MULTI ? (X_SPLIT_MANY && bound <= SPLIT_MANY_MAX_GAMES) : ((X_SPLIT_FORM == 1 || X_SPLIT_FORM == 2) && bound <= SPLIT_MAX_GAMES);
 }
 template <bool LG, bool OFF32, bool MANY>
 void launch_split(dim3 grid, hipStream_t s, const StepArgs& a, int64_t bound) {
-#ifndef BSX_VARIANT
-    if constexpr (MANY)
-#endif
     hipLaunchKernelGGL((bsx_step_split_kernel<LG, OFF32, MANY>), grid, dim3(2 * SPB), 0, s, bound, a.st.envc, a.st.envd, a.st.plane, a.actions, a.st.bent, a.st.bcnt, a.action_kind, a);
 }
 template <bool CONT, bool MULTI, bool LG>
 void launch_for_n(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs& a, int64_t bound) {
+    if constexpr (!CONT && !MULTI && X_SPLIT_FORM == 3) {   // variant: one call through the two-wave MULTI-TICK kernel, as a launch of one tick
+        if (n == 1 && !(a.flags & BSX_F_ONE_WAVE) && bound <= SPLIT_MAX_GAMES) {
+            StepArgs b = a;
+            b.T = 1; b.obs_ts = b.rew_ts = b.done_ts = 0;
+            if (narrow_offsets_ok(a.E, n, a.flags)) launch_split<LG, true, true>(grid, s, b, bound);
+            else launch_split<LG, false, true>(grid, s, b, bound);
+            return;
+        }
+    }
     if constexpr (!CONT) {
         if (split_applies<CONT, MULTI>(n, a, bound)) {   // (the grid is the same: one workgroup per 64 agents, of two waves instead of one)
             if (narrow_offsets_ok(a.E, n, a.flags)) launch_split<LG, true, MULTI>(grid, s, a, bound);

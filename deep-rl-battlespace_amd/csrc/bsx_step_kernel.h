@@ -116,6 +116,14 @@ void bsx_step_kernel(const int64_t E_, const uint2* const envc_, const uint2* co
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         for (uint32_t i = 0; i < (hw & 15u); ++i) __builtin_amdgcn_s_sleep(X_DEPHASE_SLOT);
     }
+    if constexpr (X_PRIO_BY_SLOT > 0) {                  // variant builds only: the waves of a SIMD at different issue priorities, by wave slot
+        uint32_t hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        const uint32_t k = X_PRIO_BY_SLOT == 1 ? (hw & 1u) : (hw & 3u);
+        if (k == 1) __builtin_amdgcn_s_setprio(1);
+        else if (k == 2) __builtin_amdgcn_s_setprio(2);
+        else if (k == 3) __builtin_amdgcn_s_setprio(3);
+    }
     typedef typename std::conditional<OFF32, uint32_t, size_t>::type ix_t;     // row / element offsets
     typedef typename std::conditional<OFF32, int32_t, int64_t>::type ixs_t;    // game indices
     constexpr bool NT_STATE = !MULTI && N >= 2;

@@ -153,6 +153,7 @@ void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uin
     // X_SPLIT_FORM 2 (G): wave 0 = everything but the observation geometry, wave 1 = move + geometry only; two rendezvous
     if constexpr (MANY) {
         if (role_wave == 0) {
+            if constexpr (X_SPLIT_PRIO > 0) __builtin_amdgcn_s_setprio(X_SPLIT_PRIO);   // the game wave's tick sets the pace: it goes first at the SIMD's ports
             constexpr bool R_BULLETS = true, R_MOVE = true, R_STAGE = true, R_GEOM = false, R_OUTCOME = true, R_RDV_MOVE = false;
             constexpr bool R_ST_STATE = false, R_ST_OUT = false;
             constexpr int R_RDV_COUNTS = 1, R_GEOM_LDS = 0;
@@ -168,12 +169,14 @@ void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uin
     const int tk = 0;
     if (role_wave == 0) {
         constexpr bool FIRST = true;                     // this wave loads the shared records and hands them over
+        if constexpr (X_SPLIT_PRIO > 0) __builtin_amdgcn_s_setprio(X_SPLIT_PRIO);
         constexpr bool R_BULLETS = X_SPLIT_FORM == 2, R_MOVE = true, R_STAGE = true, R_GEOM = X_SPLIT_FORM == 1, R_OUTCOME = true, R_ST_STATE = true, R_ST_OUT = true, R_RDV_MOVE = X_SPLIT_FORM == 1;
         constexpr int R_RDV_COUNTS = X_SPLIT_FORM == 1 ? 2 : 0, R_GEOM_LDS = X_SPLIT_FORM == 2 ? 2 : 0;
         if constexpr (R_BULLETS) s_ov[tid] = 0ull;       // (cleared again by whoever finds it set)
 #include "bsx_step_split_body.inl"
     } else {
         constexpr bool FIRST = false;
+        if constexpr (X_SPLIT_PRIO < 0) __builtin_amdgcn_s_setprio(-X_SPLIT_PRIO);   // (negative: the second wave is the one raised)
         constexpr bool R_BULLETS = X_SPLIT_FORM == 1, R_MOVE = X_SPLIT_FORM == 2, R_STAGE = false, R_GEOM = X_SPLIT_FORM == 2, R_OUTCOME = false, R_ST_STATE = false, R_ST_OUT = false, R_RDV_MOVE = X_SPLIT_FORM == 1;
         constexpr int R_RDV_COUNTS = X_SPLIT_FORM == 1 ? 1 : 0, R_GEOM_LDS = X_SPLIT_FORM == 2 ? 1 : 0;
         if constexpr (R_BULLETS) s_ov[tid] = 0ull;

@@ -1,8 +1,9 @@
 """The two-wave 1v1 step kernels (csrc/bsx_step_split.h) against the one-wave kernels (BSX_F_ONE_WAVE / `one_wave=True`): the same step() of
 envs/battle_env.py:281-381, so every output of every call and the complete game state must be IDENTICAL -- the kernels include the same
-phase files, each wave with the side effects of its role.  The MULTI-TICK form (a game wave + an outputs wave per 64 agents) is what the
-product runs for bsx_step_many_discrete up to 65 536 games; the PER-CALL forms (a planes wave + a bullets wave) are a measured experiment
-that loses and live in variant builds only."""
+phase files, each wave with the side effects of its role.  The product runs the MULTI-TICK form (a game wave + an outputs wave per 64
+agents) for bsx_step_many_discrete up to 65 536 games and the PER-CALL form 2 (a wave for everything but the observation geometry + a
+geometry wave) for bsx_step_discrete / _range up to 98 304 games; per-call form 1 (a planes wave + a bullets wave) is a measured
+experiment that loses and lives in variant builds only."""
 import os
 import subprocess
 import sys
@@ -13,15 +14,14 @@ import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# The split kernel is a measured EXPERIMENT (it loses: DESIGN.md section 6, profiles/r05_experiments.json) and lives in variant builds
-# only (-DBSX_X_SPLIT=<form>).  The comparisons below need such a library: the outer test builds it (tools/build_variant.py, ~1 min on
-# the GPU box) and runs this file again in a child process with BSX_LIB_PATH pointing at it; run directly against the product library
-# they would compare the one-wave kernel with itself, so they skip.
-inner = pytest.mark.skipif(os.environ.get("BSX_SPLIT_INNER") != "1", reason="runs in the child process of test_split_variant_equals_the_one_wave_kernel")
 
 
-@pytest.mark.parametrize("form", ["1"])                 # (per-call form 2 -- a geometry wave beside a wave for everything else -- was measured too and is recorded)
-def test_split_variant_equals_the_one_wave_kernel(form):
+@pytest.mark.parametrize("form", ["1"])                 # (form 2 is the product's; the tests below run against it directly)
+def test_per_call_form_1_variant_equals_the_one_wave_kernel(form):
+    """The experiment's kernel stays correct: a variant library with per-call form 1 (tools/build_variant.py, ~1 min on the GPU box), and
+    this file's per-call tests again in a child process with BSX_LIB_PATH pointing at it."""
+    if os.environ.get("BSX_SPLIT_CHILD") == "1":
+        pytest.skip("this IS the child process")
     flag = f"-DBSX_X_SPLIT={form}"
     try:                                                 # (an experiment's test must not cost the suite: no compiler on the box, or a slow one, skips it)
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "build_variant.py"), f"citest_split{form}", flag],
@@ -32,9 +32,9 @@ def test_split_variant_equals_the_one_wave_kernel(form):
         pytest.skip("could not build the variant library here: " + out.stderr[-300:])
     lib = out.stdout.strip().splitlines()[-1]
     try:
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "inner_"],
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "per_call_two_wave"],
                            capture_output=True, text=True, timeout=900, cwd=ROOT,
-                           env=dict(os.environ, BSX_LIB_PATH=lib, BSX_SPLIT_INNER="1"))
+                           env=dict(os.environ, BSX_LIB_PATH=lib, BSX_SPLIT_CHILD="1"))
         assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-3000:], r.stderr[-1500:])
     finally:
         os.remove(lib)
@@ -55,12 +55,12 @@ def _same_state(a, b):
             assert torch.equal(sa[k], sb[k]), k
 
 
-@inner
 @pytest.mark.parametrize("E,enc,wide,auto", [(65536, "int", False, True), (1000, "scores", False, True), (31, "int", True, False),
-                                             (4097, "scores", True, True), (131072, "int", False, True)])
-def test_inner_split_kernel_equals_the_one_wave_kernel(E, enc, wide, auto):
+                                             (4097, "scores", True, True), (98304, "int", False, True), (131072, "int", False, True)])
+def test_per_call_two_wave_kernel_equals_the_one_wave_kernel(E, enc, wide, auto):
     """Random play with many shots (so that pools fill, planes die, bases fall, games end and -- auto -- re-spawn in place), masked resets by
-    hand otherwise, an empty call in between: outputs equal on every call, state equal at the end and at a few calls in between."""
+    hand otherwise, an empty call in between: outputs equal on every call, state equal at the end and at a few calls in between.
+    (131 072 games take the one-wave kernel either way: the case checks that the size switch changes nothing.)"""
     kw = dict(n_agents=1, n_envs=E, seed=99, auto_reset=auto, wide_offsets=wide)
     a, b = _env(**kw), _env(one_wave=True, **kw)
     oa, ob = a.reset(), b.reset()
@@ -92,8 +92,7 @@ def test_inner_split_kernel_equals_the_one_wave_kernel(E, enc, wide, auto):
     assert (c == b.counters()).all() and int(c[:, 0].sum()) > 0 and int(c[:, 2:].sum()) > 0        # games ended, some by a base kill
 
 
-@inner
-def test_inner_split_kernel_with_injected_jitter_and_as_range_launches():
+def test_per_call_two_wave_kernel_with_injected_jitter_and_as_range_launches():
     """Host-drawn random() values for the shots (the parity traces' form) and the batch as two chains of range launches in one graph
     (bsx_step_discrete_range): the launcher takes the split kernel for each range; same games as the one-wave kernel per call."""
     E, T = 8192, 64
@@ -115,8 +114,7 @@ def test_inner_split_kernel_with_injected_jitter_and_as_range_launches():
     _same_state(a, b)
 
 
-@inner
-def test_inner_drop_in_game_runs_on_the_split_kernel_too():
+def test_per_call_two_wave_kernel_runs_the_drop_in_game_too():
     """One game behind the reference's surface (n_envs=None): the launch is one workgroup of two waves; same game as the one-wave kernel."""
     import random
     outs = []

@@ -21,7 +21,7 @@ if True:
     L = _lib.load()
     G = 2 if n == 1 else (4 if n == 2 else 8)
     waves = (E * G + 63) // 64
-    split = mode == "step" and n == 1 and not cont and E <= 131072 and not os.environ.get("BSX_STAMPS_ONE_WAVE")   # the wave-specialised kernel: two rows per workgroup
+    split = mode == "step" and n == 1 and not cont and E <= 98304 and not os.environ.get("BSX_STAMPS_ONE_WAVE")   # the wave-specialised kernel: two rows per workgroup
     if split:
         waves *= 2
     if mode == "rollout":
