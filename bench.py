@@ -622,8 +622,8 @@ def main():
 
     def two_wave(n, continuous, many, E):
         """csrc split_applies(): discrete 1v1 launches run as a two-wave kernel (bsx_step_split.h) -- multi-tick launches of up to 65 536
-        games, per-call launches of up to 98 304."""
-        return n == 1 and not continuous and E <= (65536 if many else 98304)
+        games, per-call launches of up to 114 688."""
+        return n == 1 and not continuous and E <= (65536 if many else 114688)
 
     def kernel_name(n, continuous, many, E):
         narrow = E * 2 * n * 200 <= 0xFFFFFFFF            # csrc narrow_offsets_ok(): 32-bit offsets while every array stays below 4 GB

@@ -31,14 +31,16 @@ STEP_FLAGS = ["-ffp-contract=off", "-mllvm", "-disable-machine-licm", "-mllvm", 
 # results (scheduling only).  Measured as five ALTERNATING runs of product and base variant in one gpurun call (medians; the 1 M figure
 # moves by +-5 % from process to process, which a single pair does not survive -- profiles/r05_experiments.json): 65 536 x 4v4 20.42 ->
 # 20.23 us, 1 M x 1v1 44.2 -> 43.7, C2 6.09 -> 6.07, 262 144 games unchanged; 2v2 and the bullet-heavy workload +0.6 %.  Small, and free.
-# NOT the multi-tick kernels (neutral) and NOT the fused rollouts (1v1 18.9 -> 19.8 us per tick, 4v4 84.5 -> 94: their register budget
+# The two-wave 1v1 kernels (bsx_step_two_wave.hip) gain more: per call 5.93 -> 5.66 us at C2, multi-tick 2.57 -> 2.54 us per tick (1.80 -> 1.75
+# at 32 768 games).  NOT the one-wave multi-tick kernels (neutral) and NOT the fused rollouts (1v1 18.9 -> 19.8 us per tick, 4v4 84.5 -> 94: their register budget
 # is what the default strategy protects).
 PER_CALL_FLAGS = STEP_FLAGS + ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
-# bsx_kernels.hip: reset / export / scripted-opponent kernels, launchers, C ABI; the 76 step-kernel instances are three more translation
+# bsx_kernels.hip: reset / export / scripted-opponent kernels, launchers, C ABI; the 84 step-kernel instances are four more translation
 # units (bsx_step_instances.h), compiled side by side: the build is as long as the largest of them instead of their sum
 SOURCES = [(os.path.join(CSRC, "bsx_kernels.hip"), STEP_FLAGS),
            (os.path.join(CSRC, "bsx_step_per_call.hip"), PER_CALL_FLAGS),
            (os.path.join(CSRC, "bsx_step_multi_tick.hip"), STEP_FLAGS),
+           (os.path.join(CSRC, "bsx_step_two_wave.hip"), PER_CALL_FLAGS),
            (os.path.join(CSRC, "bsx_step_rollout.hip"), STEP_FLAGS),
            (os.path.join(CSRC, "bsx_actor.hip"), ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form"])]
 

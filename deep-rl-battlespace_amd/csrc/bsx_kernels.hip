@@ -284,13 +284,13 @@ inline bool narrow_offsets_ok(int64_t E, int n, uint32_t flags) {
 // Multi-tick launches (bsx_step_many_discrete) of up to 65 536 games: a GAME wave and an OUTPUTS wave per 64 agents, four waves per SIMD at
 // 65 536 games -- 3.05 -> 2.58 us per tick there, 2.65 -> 1.81 at 32 768; beyond that the SIMDs are full of waves anyway and the one-wave
 // kernel's fewer instructions win (131 072 games: 4.45 against 5.2).
-// Per-call launches (bsx_step_discrete, *_range) of up to 98 304 games: a wave for everything but the observation geometry and a GEOMETRY
-// wave -- 6.08 -> 5.66 us per call at 65 536 games, 4.34 -> 4.02 at 4 096, 7.27 -> 6.90 at 98 304 (131 072: loses).
+// Per-call launches (bsx_step_discrete, *_range) of up to 114 688 games: a wave for everything but the observation geometry and a GEOMETRY
+// wave -- 6.08 -> 5.66 us per call at 65 536 games, 4.34 -> 4.02 at 4 096, 8.11 -> 7.52 at 114 688 (131 072: 8.33 -> 8.84, so not there).
 #ifndef BSX_X_SPLIT_MANY_MAX
 #define BSX_X_SPLIT_MANY_MAX 65536
 #endif
 #ifndef BSX_X_SPLIT_MAX
-#define BSX_X_SPLIT_MAX 98304
+#define BSX_X_SPLIT_MAX 114688
 #endif
 constexpr int64_t SPLIT_MAX_GAMES = BSX_X_SPLIT_MAX, SPLIT_MANY_MAX_GAMES = BSX_X_SPLIT_MANY_MAX;
 template <bool CONT, bool MULTI>

@@ -1,4 +1,4 @@
-// bsx_step_multi_tick.hip -- instantiates the multi-tick step kernels (bsx_step_many_*: T calls in one launch), the two-wave 1v1 form among them: see bsx_step_instances.h.
+// bsx_step_multi_tick.hip -- instantiates the multi-tick step kernels (bsx_step_many_*: T calls in one launch): see bsx_step_instances.h.
 // Same flags as bsx_kernels.hip (build.py): -ffp-contract=off is load-bearing.
 #ifndef BSX_VARIANT            // (a diagnostic variant build is one translation unit: bsx_kernels.hip carries every instance)
 #include "bsx_config.h"
@@ -7,9 +7,7 @@
 #include "bsx_geometry.h"
 #include "bsx_instinct.h"
 #include "bsx_step_kernel.h"
-#include "bsx_step_split.h"
 #define BSX_INST_KW
 #define BSX_INST_MULTI_TICK
-#define BSX_INST_SPLIT_MANY
 #include "bsx_step_instances.h"
 #endif

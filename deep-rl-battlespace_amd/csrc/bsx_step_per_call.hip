@@ -7,9 +7,7 @@
 #include "bsx_geometry.h"
 #include "bsx_instinct.h"
 #include "bsx_step_kernel.h"
-#include "bsx_step_split.h"
 #define BSX_INST_KW
 #define BSX_INST_PER_CALL
-#define BSX_INST_SPLIT
 #include "bsx_step_instances.h"
 #endif

@@ -2,7 +2,7 @@
 envs/battle_env.py:281-381, so every output of every call and the complete game state must be IDENTICAL -- the kernels include the same
 phase files, each wave with the side effects of its role.  The product runs the MULTI-TICK form (a game wave + an outputs wave per 64
 agents) for bsx_step_many_discrete up to 65 536 games and the PER-CALL form 2 (a wave for everything but the observation geometry + a
-geometry wave) for bsx_step_discrete / _range up to 98 304 games; per-call form 1 (a planes wave + a bullets wave) is a measured
+geometry wave) for bsx_step_discrete / _range up to 114 688 games; per-call form 1 (a planes wave + a bullets wave) is a measured
 experiment that loses and lives in variant builds only."""
 import os
 import subprocess
@@ -56,7 +56,7 @@ def _same_state(a, b):
 
 
 @pytest.mark.parametrize("E,enc,wide,auto", [(65536, "int", False, True), (1000, "scores", False, True), (31, "int", True, False),
-                                             (4097, "scores", True, True), (98304, "int", False, True), (131072, "int", False, True)])
+                                             (4097, "scores", True, True), (114688, "int", False, True), (131072, "int", False, True)])
 def test_per_call_two_wave_kernel_equals_the_one_wave_kernel(E, enc, wide, auto):
     """Random play with many shots (so that pools fill, planes die, bases fall, games end and -- auto -- re-spawn in place), masked resets by
     hand otherwise, an empty call in between: outputs equal on every call, state equal at the end and at a few calls in between.

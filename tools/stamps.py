@@ -21,7 +21,7 @@ if True:
     L = _lib.load()
     G = 2 if n == 1 else (4 if n == 2 else 8)
     waves = (E * G + 63) // 64
-    split = mode == "step" and n == 1 and not cont and E <= 98304 and not os.environ.get("BSX_STAMPS_ONE_WAVE")   # the wave-specialised kernel: two rows per workgroup
+    split = mode == "step" and n == 1 and not cont and E <= 114688 and not os.environ.get("BSX_STAMPS_ONE_WAVE")   # the wave-specialised kernel: two rows per workgroup
     if split:
         waves *= 2
     if mode == "rollout":
@@ -55,8 +55,8 @@ if True:
             env.step_batch(acts[t])
         torch.cuda.synchronize()
         s10 = buf.cpu().numpy().reshape(waves, 10).astype(np.float64)
-        if split:                                  # even rows: planes waves, odd rows: bullets waves -- printed one after the other
-            roles = {"planes": s10[0::2], "bullets": s10[1::2]}
+        if split:                                  # even rows: the first wave of each workgroup (everything but the geometry), odd rows: the second (geometry) -- printed one after the other
+            roles = {"first": s10[0::2], "second": s10[1::2]}
             for rn, r in roles.items():
                 seg = np.diff(np.concatenate([r[:, 8:9], r[:, :8]], axis=1), axis=1)
                 acc = split_acc.setdefault(rn, np.zeros(8)); acc += seg.mean(0)
@@ -95,7 +95,7 @@ if True:
             print(f"    {nme:40s} {a_:9.0f} {b_:9.0f}")
     if split:
         print("  wave-specialised kernel, shader cycles x 10 per segment (entry->T0 | T0->STAMP1 | ->move | ->geometry | ->bullets | ->resolve | ->stores | ->end):")
-        for rn in ("planes", "bullets"):
+        for rn in ("first", "second"):
             v = split_acc[rn] / split_acc["n"] * 10
             print(f"    {rn:8s} " + " ".join(f"{x:8.0f}" for x in v) + f"   total {v.sum():8.0f}")
     sp = np.asarray(span).mean(0)
