@@ -310,6 +310,7 @@ def parse_args(argv=None):
     ap.add_argument("--chains", type=int, default=1,
                     help="graph mode: the batch as this many game ranges, each its own chain of launches on a branch of the graph "
                          "(capture_steps(chains=)); 1 = one launch per step over the whole batch (the headline)")
+    ap.add_argument("--one-wave", action="store_true", help="A/B: keep the one-wave 1v1 kernels (BSX_F_ONE_WAVE) where the library would take a two-wave form; same results")
     ap.add_argument("--no-stagger", action="store_true", help="leave all games on the same clock (time-limit ties in lock-step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the extra (non-headline) measurements")
@@ -520,7 +521,7 @@ def main():
         A = 2 * n
         R = R or args.repeats
         env = sharding.make_shard(E * world, rank, world, n_agents=n, device=dev, seed=1234, auto_reset=True,
-                                  continuous_actions=continuous)
+                                  continuous_actions=continuous, one_wave=args.one_wave)
         env.reset()
         G = max(1, min(graph_len, K))                       # steps per graph replay; a remainder runs as plain calls
         lo = env.env_offset
@@ -623,7 +624,7 @@ def main():
     def two_wave(n, continuous, many, E):
         """csrc split_applies(): discrete 1v1 launches run as a two-wave kernel (bsx_step_split.h) -- multi-tick launches of up to 65 536
         games, per-call launches of up to 114 688."""
-        return n == 1 and not continuous and E <= (65536 if many else 114688)
+        return n == 1 and not continuous and E <= (65536 if many else 114688) and not args.one_wave
 
     def kernel_name(n, continuous, many, E):
         narrow = E * 2 * n * 200 <= 0xFFFFFFFF            # csrc narrow_offsets_ok(): 32-bit offsets while every array stays below 4 GB
