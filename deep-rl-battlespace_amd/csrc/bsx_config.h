@@ -33,7 +33,9 @@ constexpr int X_PRIO_BY_SLOT = 0;
 // first wave -- whose chain sets the pace -- runs at s_setprio 1: without that the per-call form loses to the one-wave kernel.
 constexpr bool X_SPLIT_MANY = true;
 constexpr int X_SPLIT_FORM = 2, X_SPLIT_PRIO = 1;
+constexpr bool X_SPLIT_OWN_LOADS = false;
 #define STAMP(i) do { } while (0)
+#define STAMP_HWID() do { } while (0)
 #define FSTAMP(i) do { } while (0)
 #define PSTAMP(i) do { } while (0)
 #endif

@@ -94,6 +94,12 @@ constexpr int X_SPLIT_FORM = BSX_X_SPLIT;
 #define BSX_X_SPLIT_PRIO 1
 #endif
 constexpr int X_SPLIT_PRIO = BSX_X_SPLIT_PRIO;
+// -DBSX_X_SPLIT_OWN_LOADS: per-call two-wave forms, each wave loads its own copy of the records instead of the LDS hand-over (same results)
+#ifdef BSX_X_SPLIT_OWN_LOADS
+constexpr bool X_SPLIT_OWN_LOADS = true;
+#else
+constexpr bool X_SPLIT_OWN_LOADS = false;
+#endif
 // -DBSX_X_PRIO_BY_SLOT=<1|2>: one-wave kernels, s_setprio by the wave's slot on its SIMD (1: slot & 1, 2: slot & 3; same results)
 #ifndef BSX_X_PRIO_BY_SLOT
 #define BSX_X_PRIO_BY_SLOT 0
@@ -118,6 +124,13 @@ __device__ unsigned long long* g_stamps = nullptr;
         __builtin_amdgcn_sched_barrier(0);                                                         \
         if (g_stamps && (threadIdx.x & 63) == 0) g_stamps[size_t(stamp_row) * 10 + (i)] = t_;  \
     } while (0)
+// slot 9 of a two-wave kernel's row: the wave's HW_ID register (which SIMD of which CU it runs on) instead of a time
+#define STAMP_HWID()                                                                               \
+    do {                                                                                           \
+        uint32_t hw_;                                                                              \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                          \
+        if (g_stamps && (threadIdx.x & 63) == 0) g_stamps[size_t(stamp_row) * 10 + 9] = hw_;       \
+    } while (0)
 // where the stamps go (device buffer of 10 * waves uint64)
 extern "C" int bsx_debug_set_stamps(void* buf) {
     unsigned long long* p = static_cast<unsigned long long*>(buf);
@@ -126,6 +139,7 @@ extern "C" int bsx_debug_set_stamps(void* buf) {
 #else
 constexpr int BUILD_FLAGS = int(DIAG & 0xFFu);
 #define STAMP(i) do { } while (0)
+#define STAMP_HWID() do { } while (0)
 #endif
 
 #if defined(BSX_STAMPS) && defined(BSX_STAMPS_FINE)

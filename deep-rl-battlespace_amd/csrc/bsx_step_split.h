@@ -1,9 +1,11 @@
 // bsx_step_split.h -- bsx_step_split_kernel: the 1v1 step() as TWO co-operating wavefronts per 64 agents (round 5); namespace bsxk.
-// Part of the step() path of libbattlespace_hip.so (included after bsx_step_kernel.h).  Two uses:
-//   * MANY = true, PRODUCT: multi-tick launches (bsx_step_many_discrete) of up to 65 536 games -- 3.07 -> 2.84 us per tick at 65 536
-//     games (46.2 G agent-steps/s), 2.65 -> 2.05 at 32 768; instantiated with the multi-tick unit (bsx_step_multi_tick.hip);
-//   * MANY = false, a MEASURED EXPERIMENT THAT LOSES: one call per launch, variant builds only (-DBSX_X_SPLIT=<1|2>) -- kept because its
-//     result is the evidence for DESIGN.md section 6 ("more waves per SIMD by splitting the agent's work").
+// Part of the step() path of libbattlespace_hip.so (included after bsx_step_kernel.h; instantiated in bsx_step_two_wave.hip).  Two uses, both PRODUCT:
+//   * MANY = true: multi-tick launches (bsx_step_many_discrete) of up to 65 536 games -- 3.05 -> 2.54 us per tick at 65 536 games
+//     (51 G agent-steps/s), 2.65 -> 1.75 at 32 768;
+//   * MANY = false: one call per launch (bsx_step_discrete, *_range) of up to 114 688 games, form 2 below -- C2 6.08 -> 5.66 us.
+// In both the wave that carries the game's chain runs at s_setprio 1: a SIMD's arbiter serves its resident waves oldest-first, and
+// without the priority the chain's wave queues behind the wave that has slack -- the per-call forms then LOSE (6.31 / 6.70 us), the
+// multi-tick form gains less (2.85).  DESIGN.md sections 4 and 6; profiles/r05_experiments.json.
 //
 // The idea.  At 65 536 x 1v1 the one-wave kernel (bsx_step_kernel<1, ...>) puts two waves on a SIMD, and its tick is one long chain of
 // dependent latencies: first loads -> classify -> shot (Philox, step code) -> move -> geometry -> bullet round -> resolve -> outcome ->
@@ -19,14 +21,15 @@
 // in which the outputs wave repeats none of the game logic and takes a 16-byte publish per agent and tick instead was measured too:
 // +-1 % at 65 536 games, 7 % slower at 32 768 -- not kept; profiles/r05_experiments.json.)
 //
-// The per-call forms (experiment).  form 1: wave 0 PLANES (move, geometry, outcome, stores), wave 1 BULLETS (shot, pool pass, resolve),
-// three rendezvous (the shared records loaded once and handed over; post-move sprites; counts).  form 2: wave 0 everything but the
-// geometry, wave 1 move + geometry, its four observation values through LDS before the stores.  65 536 games: 6.31 / 6.46 us against 6.09
-// for the one-wave kernel; 32 768: 4.96 / 5.06 against 4.99; 131 072: 9.09 against 8.31.  Stamps say why: the planes wave lives 10.9 k
-// cycles and the bullets wave 9.3 k against 11.05 k of the one wave -- the chain first loads -> shot -> pool pass -> resolve -> outcome ->
-// stores IS the critical path of a single call, the geometry was the only large piece beside it, and the rendezvous, the hand-over and
-// twice the waves to launch cost what taking it off the chain saves.  In the multi-tick form the outputs wave's work overlaps the NEXT
-// tick of the game wave instead, and there is nothing to launch.
+// The per-call forms.  A single call has no next tick to run ahead into; the split is by what the call's chain can shed.
+//   form 2 (PRODUCT): wave 0 everything but the observation geometry (it loads the records once and hands the raw words over through
+//     LDS, so that the launch's first burst of requests stays the one-wave kernel's), wave 1 classify + move (no side effects) + geometry;
+//     the waves meet once before the stores, the four observation values per agent cross in LDS, wave 0 stores everything.
+//   form 1 (variant builds, -DBSX_X_SPLIT=1): wave 0 PLANES (move, geometry, outcome, stores), wave 1 BULLETS (shot, pool pass, resolve),
+//     three rendezvous (records; post-move sprites; counts).
+// 65 536 games, one-wave kernel 6.09 us: form 1 6.31, with the bullets wave at priority 1 6.00; form 2 6.70, with wave 0 at priority 1
+// 5.93, compiled with -amdgpu-sched-strategy=max-ilp 5.66.  Stamps of form 2: wave 0 reaches the hand-over 9 559 cycles after its
+// start, the geometry wave 9 416 -- balanced.  Beyond 114 688 games (3.5 one-wave waves per SIMD) the one-wave kernel wins again.
 //
 // How.  No second copy of the game logic: the kernel includes the SAME phase files as bsx_step_kernel, once per wave, with the R_*
 // constants of the wave's role.  The phases guard their side effects (LDS staging, stores, the pool pass, the rendezvous) by them;
@@ -45,6 +48,9 @@ namespace bsxk {
 // they never exchange state; the outputs wave is up to a tick behind.
 template <bool LG, bool OFF32, bool MANY = false>
 __global__ __launch_bounds__(2 * SPB)
+#ifdef BSX_X_SPLIT_WAVES                                 // variant builds: at most this many waves per SIMD, i.e. more registers for the scheduler to use
+__attribute__((amdgpu_waves_per_eu(1, BSX_X_SPLIT_WAVES)))
+#endif
 void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uint2* const envd_, const uint2* const plane_, const void* const act_,
                            const uint2* const bent_, const uint32_t* const bcnt_, const int kind_, const StepArgs p_) {
     constexpr int N = 1;
@@ -56,9 +62,10 @@ void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uin
     constexpr int WAVES = 1;                             // LDS is sized for ONE set of 64 agents: the two waves share it
     const int n = 1, A = 2, G = 2, EPB = SPB / 2;
     const int wave = 0;                                  // (the phases' LDS offsets: both waves use the set's only slice)
-    const int role_wave = int(threadIdx.x >> 6);         // 0 = planes, 1 = bullets
+    const int role_wave = int(threadIdx.x >> 6);         // the wave's role: see the forms above
     const unsigned stamp_row = blockIdx.x * 2u + unsigned(role_wave); (void)stamp_row;   // (diagnostic builds: a row of stamps per wave)
     STAMP(8);
+    STAMP_HWID();
     const int tid = int(threadIdx.x & 63);
     const ixs_t wblk = ixs_t(blockIdx.x);
     const int a = tid & (G - 1);

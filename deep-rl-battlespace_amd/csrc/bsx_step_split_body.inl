@@ -16,7 +16,7 @@
         (void)eb; (void)u_t; (void)obs_t; (void)rew_t; (void)done_t; (void)EAt;
         RawIn rin_next = {}; DecIn din_next = {-1, 0.0};             // (named by the phases behind `if (MULTI ...)`: never reached in this form)
         (void)rin_next; (void)din_next;
-        // ---- T0: every load this role needs, back to back (what a role does not use -- the pool for the planes wave -- is dead code)
+        // ---- T0: every load this role needs, back to back (what a role does not use -- the pool for a wave without the bullets -- is dead code)
         int x = 0, y = 0, hp = 0;
         uint32_t games = 0;
         double dir = 0.0;
@@ -27,12 +27,12 @@
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, uu_in = 0.0;
         (void)a0; (void)a1; (void)a2;
         STAMP(0);
-        // The game records, the plane record and the action are loaded ONCE per workgroup -- by the planes wave, which hands the raw words to
-        // the bullets wave through LDS (rendezvous 0) -- so that the launch's first burst of requests is the one-wave kernel's, not twice it;
-        // the bullets wave asks for its pool meanwhile.
+        // The game records, the plane record and the action are loaded ONCE per workgroup -- by the first wave, which hands the raw words to
+        // the second through LDS (rendezvous 0) -- so that the launch's first burst of requests is the one-wave kernel's, not twice it;
+        // a second wave with the bullets (form 1) asks for its pool meanwhile.
         {
             uint2 ecw, edw, prw;
-            if constexpr (FIRST) {
+            if constexpr (FIRST || X_SPLIT_OWN_LOADS) {
                 ecw = *elem(envc_, ix_t(ec));
                 edw = *elem(envd_, ix_t(ec));
                 prw = *elem(plane_, gt);
@@ -49,9 +49,11 @@
                     pc = __builtin_amdgcn_readfirstlane(*elem(bcnt_, ix_t(wblk)));
                     if (p.u) uu_in = p.u[g];                                   // (injected jitter: uniform branch)
                 }
+                if constexpr (!X_SPLIT_OWN_LOADS) {      // (variant builds: every wave loads its own copy instead -- twice the first burst of requests, no rendezvous)
                 s_t0[tid] = v4u_t{ecw.x, ecw.y, edw.x, edw.y};
                 s_t1[tid] = v4u_t{prw.x, prw.y, uint32_t(act), 0u};
                 split_rendezvous();
+                }
             } else {
                 if constexpr (R_BULLETS) {
                     pool_first = *elem(bent_, pool0 + ix_t(lane));

@@ -61,6 +61,21 @@ if True:
                 seg = np.diff(np.concatenate([r[:, 8:9], r[:, :8]], axis=1), axis=1)
                 acc = split_acc.setdefault(rn, np.zeros(8)); acc += seg.mean(0)
             split_acc["n"] = split_acc.get("n", 0) + 1
+            if os.environ.get("BSX_STAMPS_PLACEMENT") and "placement" not in split_acc:
+                # slot 9 = HW_ID (gfx9: wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13 [gfx950: se 15:13 + xcc elsewhere]); print what the bits say
+                hw = s10[:, 9].astype(np.int64) if False else buf.cpu().numpy().reshape(waves, 10)[:, 9]
+                role = np.arange(waves) & 1
+                simd = (hw >> 4) & 3
+                cu_key = hw >> 8 & 0xFFFFF                          # everything above the SIMD / pipe bits: CU, SH, SE, ... (one key per CU)
+                import collections
+                per = collections.Counter()
+                for k, sd, r in zip(cu_key.tolist(), simd.tolist(), role.tolist()):
+                    per[(k, sd, r)] += 1
+                hist = collections.Counter()
+                for (k, sd) in {(k, sd) for (k, sd, r) in per}:
+                    hist[(per.get((k, sd, 0), 0), per.get((k, sd, 1), 0))] += 1
+                wg_pair = collections.Counter(((simd[0::2] - simd[1::2]) & 3).tolist())
+                split_acc["placement"] = (sorted(hist.items()), sorted(wg_pair.items()), len({k for (k, sd, r) in per}))
             s10 = s10[0::2]
         s = s10[:, :8]
         if FINE:
@@ -98,5 +113,9 @@ if True:
         for rn in ("first", "second"):
             v = split_acc[rn] / split_acc["n"] * 10
             print(f"    {rn:8s} " + " ".join(f"{x:8.0f}" for x in v) + f"   total {v.sum():8.0f}")
+    if split and "placement" in split_acc:
+        hist, pair, ncu = split_acc["placement"]
+        print(f"  placement of the two roles (HW_ID): {ncu} distinct CU keys; SIMDs by (first-role waves, second-role waves) resident in one launch: {hist}")
+        print(f"  (SIMD of a workgroup's first wave - SIMD of its second wave) mod 4: {pair}")
     sp = np.asarray(span).mean(0)
     print(f"  wave lifetime mean {sp[1]*10:.0f} ns; first-start to last-end {sp[0]*10:.0f} ns; start skew {sp[2]*10:.0f} ns")
