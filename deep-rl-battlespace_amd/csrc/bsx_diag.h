@@ -127,9 +127,10 @@ __device__ unsigned long long* g_stamps = nullptr;
 // slot 9 of a two-wave kernel's row: the wave's HW_ID register (which SIMD of which CU it runs on) instead of a time
 #define STAMP_HWID()                                                                               \
     do {                                                                                           \
-        uint32_t hw_;                                                                              \
+        uint32_t hw_, xcc_;                                                                        \
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                          \
-        if (g_stamps && (threadIdx.x & 63) == 0) g_stamps[size_t(stamp_row) * 10 + 9] = hw_;       \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                        \
+        if (g_stamps && (threadIdx.x & 63) == 0) g_stamps[size_t(stamp_row) * 10 + 9] = (unsigned long long)(hw_) | ((unsigned long long)(xcc_) << 32);       \
     } while (0)
 // where the stamps go (device buffer of 10 * waves uint64)
 extern "C" int bsx_debug_set_stamps(void* buf) {

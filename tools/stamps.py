@@ -66,7 +66,7 @@ if True:
                 hw = s10[:, 9].astype(np.int64) if False else buf.cpu().numpy().reshape(waves, 10)[:, 9]
                 role = np.arange(waves) & 1
                 simd = (hw >> 4) & 3
-                cu_key = hw >> 8 & 0xFFFFF                          # everything above the SIMD / pipe bits: CU, SH, SE, ... (one key per CU)
+                cu_key = ((hw >> 8) & 0xFF) | (((hw >> 32) & 0xF) << 8)  # cu_id 11:8, sh_id 12, se_id 15:13 of HW_ID + XCC_ID 3:0: one key per CU
                 import collections
                 per = collections.Counter()
                 for k, sd, r in zip(cu_key.tolist(), simd.tolist(), role.tolist()):
@@ -75,6 +75,14 @@ if True:
                 for (k, sd) in {(k, sd) for (k, sd, r) in per}:
                     hist[(per.get((k, sd, 0), 0), per.get((k, sd, 1), 0))] += 1
                 wg_pair = collections.Counter(((simd[0::2] - simd[1::2]) & 3).tolist())
+                # does a first-role wave live longer on a SIMD that holds more of them?  lifetime = entry -> last stamp, by (first-role, all) waves on its SIMD
+                raw = buf.cpu().numpy().reshape(waves, 10).astype(np.float64)
+                life_w = raw[:, 7] - raw[:, 8]
+                by = collections.defaultdict(list)
+                for w in range(0, waves, 2):
+                    k, sd = int(cu_key[w]), int(simd[w])
+                    by[(per.get((k, sd, 0), 0), per.get((k, sd, 0), 0) + per.get((k, sd, 1), 0))].append(life_w[w])
+                split_acc["life_by_load"] = sorted((key, len(v), float(np.mean(v)) * 10, float(np.percentile(v, 95)) * 10) for key, v in by.items())
                 split_acc["placement"] = (sorted(hist.items()), sorted(wg_pair.items()), len({k for (k, sd, r) in per}))
             s10 = s10[0::2]
         s = s10[:, :8]
@@ -117,5 +125,8 @@ if True:
         hist, pair, ncu = split_acc["placement"]
         print(f"  placement of the two roles (HW_ID): {ncu} distinct CU keys; SIMDs by (first-role waves, second-role waves) resident in one launch: {hist}")
         print(f"  (SIMD of a workgroup's first wave - SIMD of its second wave) mod 4: {pair}")
+        print("  first-role wave lifetime (ns label = shader cycles x 10) by (first-role waves, all waves) on its SIMD: count, mean, p95")
+        for key, cnt, mean, p95 in split_acc["life_by_load"]:
+            print(f"    {key}: {cnt:5d} {mean:9.0f} {p95:9.0f}")
     sp = np.asarray(span).mean(0)
     print(f"  wave lifetime mean {sp[1]*10:.0f} ns; first-start to last-end {sp[0]*10:.0f} ns; start skew {sp[2]*10:.0f} ns")
