@@ -29,10 +29,11 @@ constexpr int X_OPAQUE_MULTI_MASK = 0x1C18;      // multi-tick kernels that reco
 constexpr int X_PAD_SALU = 0, X_PAD_VALU = 0, X_DEPHASE_SLOT = 0;
 constexpr int X_PRIO_BY_SLOT = 0;
 // The two-wave 1v1 kernels (bsx_step_split.h).  Multi-tick launches of up to 65 536 games: a GAME wave + an OUTPUTS wave per 64 agents.
-// Per-call launches of up to 114 688 games: form 2, a wave for everything but the observation geometry + a GEOMETRY wave.  In both the
-// first wave -- whose chain sets the pace -- runs at s_setprio 1: without that the per-call form loses to the one-wave kernel.
+// Per-call launches of up to 114 688 games: form 4, a wave for everything but the observation geometry + a GEOMETRY wave fed with the
+// post-move poses.  In both the first wave -- whose chain sets the pace -- runs at s_setprio 1: without that the per-call forms lose to
+// the one-wave kernel.
 constexpr bool X_SPLIT_MANY = true;
-constexpr int X_SPLIT_FORM = 2, X_SPLIT_PRIO = 1;
+constexpr int X_SPLIT_FORM = 4, X_SPLIT_PRIO = 1;
 constexpr bool X_SPLIT_OWN_LOADS = false;
 #define STAMP(i) do { } while (0)
 #define STAMP_HWID() do { } while (0)

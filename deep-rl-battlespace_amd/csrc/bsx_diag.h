@@ -81,11 +81,11 @@ constexpr int X_PAD_SALU = BSX_X_PAD_SALU, X_PAD_VALU = BSX_X_PAD_VALU;
 #endif
 constexpr int X_DEPHASE_SLOT = BSX_X_DEPHASE_SLOT;
 
-// -DBSX_X_SPLIT=<0|1|2|3>: the form of the two-wave kernel of bsx_step_split.h that 1v1 per-call launches take (same results): 0 = none (the
-// one-wave kernel), 1 = a planes wave + a bullets wave per 64 agents, 2 (the product) = a wave for everything but the observation geometry
-// + a geometry wave, 3 = the multi-tick kernel as a launch of one tick (unfinished: fails parity)
+// -DBSX_X_SPLIT=<0|1|2|4>: the form of the two-wave kernel of bsx_step_split.h that 1v1 per-call launches take (same results): 0 = none (the
+// one-wave kernel), 1 = a planes wave + a bullets wave per 64 agents, 2 = a wave for everything but the observation geometry + a geometry
+// wave that repeats classify and move, 4 (the product) = the same with the geometry wave fed the post-move poses through LDS
 #ifndef BSX_X_SPLIT
-#define BSX_X_SPLIT 2
+#define BSX_X_SPLIT 4
 #endif
 constexpr int X_SPLIT_FORM = BSX_X_SPLIT;
 // -DBSX_X_SPLIT_PRIO=<-3..3>: s_setprio of the first wave of the two-wave kernels (negative: of the second wave of the per-call forms

@@ -285,7 +285,8 @@ inline bool narrow_offsets_ok(int64_t E, int n, uint32_t flags) {
 // 65 536 games -- 3.05 -> 2.58 us per tick there, 2.65 -> 1.81 at 32 768; beyond that the SIMDs are full of waves anyway and the one-wave
 // kernel's fewer instructions win (131 072 games: 4.45 against 5.2).
 // Per-call launches (bsx_step_discrete, *_range) of up to 114 688 games: a wave for everything but the observation geometry and a GEOMETRY
-// wave -- 6.08 -> 5.66 us per call at 65 536 games, 4.34 -> 4.02 at 4 096, 8.11 -> 7.52 at 114 688 (131 072: 8.33 -> 8.84, so not there).
+// wave that takes the post-move poses from it -- 6.08 -> 5.60 us per call at 65 536 games, 4.34 -> 3.99 at 4 096, 6.99 -> 6.33 at 81 920,
+// 8.11 -> 7.11 at 114 688 (131 072: 8.31 -> 8.85, so not there).
 #ifndef BSX_X_SPLIT_MANY_MAX
 #define BSX_X_SPLIT_MANY_MAX 65536
 #endif
@@ -296,7 +297,7 @@ constexpr int64_t SPLIT_MAX_GAMES = BSX_X_SPLIT_MAX, SPLIT_MANY_MAX_GAMES = BSX_
 template <bool CONT, bool MULTI>
 inline bool split_applies(int n, const StepArgs& a, int64_t bound) {
     if (CONT || n != 1 || (a.flags & BSX_F_ONE_WAVE)) return false;
-    return MULTI ? (X_SPLIT_MANY && bound <= SPLIT_MANY_MAX_GAMES) : ((X_SPLIT_FORM == 1 || X_SPLIT_FORM == 2) && bound <= SPLIT_MAX_GAMES);
+    return MULTI ? (X_SPLIT_MANY && bound <= SPLIT_MANY_MAX_GAMES) : (X_SPLIT_FORM != 0 && bound <= SPLIT_MAX_GAMES);
 }
 template <bool LG, bool OFF32, bool MANY>
 void launch_split(dim3 grid, hipStream_t s, const StepArgs& a, int64_t bound) {
@@ -304,15 +305,6 @@ void launch_split(dim3 grid, hipStream_t s, const StepArgs& a, int64_t bound) {
 }
 template <bool CONT, bool MULTI, bool LG>
 void launch_for_n(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs& a, int64_t bound) {
-    if constexpr (!CONT && !MULTI && X_SPLIT_FORM == 3) {   // variant: one call through the two-wave MULTI-TICK kernel, as a launch of one tick
-        if (n == 1 && !(a.flags & BSX_F_ONE_WAVE) && bound <= SPLIT_MAX_GAMES) {
-            StepArgs b = a;
-            b.T = 1; b.obs_ts = b.rew_ts = b.done_ts = 0;
-            if (narrow_offsets_ok(a.E, n, a.flags)) launch_split<LG, true, true>(grid, s, b, bound);
-            else launch_split<LG, false, true>(grid, s, b, bound);
-            return;
-        }
-    }
     if constexpr (!CONT) {
         if (split_applies<CONT, MULTI>(n, a, bound)) {   // (the grid is the same: one workgroup per 64 agents, of two waves instead of one)
             if (narrow_offsets_ok(a.E, n, a.flags)) launch_split<LG, true, MULTI>(grid, s, a, bound);

@@ -6,7 +6,7 @@
 // @reads   alive0 dir_rot dl mode rw
 // @writes  a0 a1 dir er hp tick x y
 // @exports nhp_ nx_ ny_
-// @lds     s_bhit s_hp s_pq s_x s_y
+// @lds     s_bhit s_hp s_pq s_t0 s_t1 s_x s_y
     STAMP(2);
     if constexpr (R_MOVE) {                              // (split kernels: a wave that only runs bullets does not move planes)
     if (mode == M_RESET) {
@@ -63,3 +63,11 @@
     }
     // split kernel, form A: the planes wave has staged the post-move sprites (s_pq), the bullets wave its shots and owner flags: rendezvous
     if constexpr (R_RDV_MOVE) split_rendezvous();
+    // split kernel, per-call form 4: this wave leaves what the observation geometry needs -- my pose, the enemy's position, the enemy base --
+    // for the geometry wave, which has waited for it (32 bytes per lane; the geometry wave loads nothing and repeats nothing)
+    if constexpr (R_POSE_LDS) {
+        const double dq = dir;
+        s_t0[tid] = v4u_t{uint32_t(x), uint32_t(y), uint32_t(nx_), uint32_t(ny_)};
+        s_t1[tid] = v4u_t{uint32_t(__double2loint(dq)), uint32_t(__double2hiint(dq)), uint32_t(team == 0 ? er.bbx : er.brx), uint32_t(team == 0 ? er.bby : er.bry)};
+        split_rendezvous();
+    }

@@ -10,7 +10,7 @@
     if (MULTI && !ACTOR && tk + 1 < p.T) din_next = decode(rin_next);   // the prefetch has long arrived; no store of this tick is out yet
     // ---- write back (MULTI: plane and game records travel in registers; memory gets them once, after the last tick)
     const bool last_tick = !MULTI || tk == p.T - 1;
-    // split kernel, form G: the two waves meet; the storing wave takes the observation values the geometry wave left in LDS
+    // two-wave kernel, per-call forms with a geometry wave: the two waves meet; the storing wave takes the observation values the geometry wave left in LDS
     if constexpr (R_GEOM_LDS != 0) {
         split_rendezvous();
         if constexpr (R_GEOM_LDS == 2) { const v4f_t gm = s_gm[tid]; ob_d = gm.x; ob_a = gm.y; oe_d[0] = gm.z; oe_a[0] = gm.w; }

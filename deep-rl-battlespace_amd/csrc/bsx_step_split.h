@@ -2,7 +2,7 @@
 // Part of the step() path of libbattlespace_hip.so (included after bsx_step_kernel.h; instantiated in bsx_step_two_wave.hip).  Two uses, both PRODUCT:
 //   * MANY = true: multi-tick launches (bsx_step_many_discrete) of up to 65 536 games -- 3.05 -> 2.54 us per tick at 65 536 games
 //     (51 G agent-steps/s), 2.65 -> 1.75 at 32 768;
-//   * MANY = false: one call per launch (bsx_step_discrete, *_range) of up to 114 688 games, form 2 below -- C2 6.08 -> 5.66 us.
+//   * MANY = false: one call per launch (bsx_step_discrete, *_range) of up to 114 688 games, form 4 below -- C2 6.08 -> 5.60 us.
 // In both the wave that carries the game's chain runs at s_setprio 1: a SIMD's arbiter serves its resident waves oldest-first, and
 // without the priority the chain's wave queues behind the wave that has slack -- the per-call forms then LOSE (6.31 / 6.70 us), the
 // multi-tick form gains less (2.85).  DESIGN.md sections 4 and 6; profiles/r05_experiments.json.
@@ -22,14 +22,19 @@
 // +-1 % at 65 536 games, 7 % slower at 32 768 -- not kept; profiles/r05_experiments.json.)
 //
 // The per-call forms.  A single call has no next tick to run ahead into; the split is by what the call's chain can shed.
-//   form 2 (PRODUCT): wave 0 everything but the observation geometry (it loads the records once and hands the raw words over through
-//     LDS, so that the launch's first burst of requests stays the one-wave kernel's), wave 1 classify + move (no side effects) + geometry;
-//     the waves meet once before the stores, the four observation values per agent cross in LDS, wave 0 stores everything.
+//   form 4 (PRODUCT): wave 0 everything but the observation geometry; after its move it leaves the post-move poses (own pose, enemy position,
+//     enemy base: 32 bytes per lane) in LDS.  Wave 1, GEOMETRY, loads nothing and repeats no game logic: it waits for the poses, works out the
+//     geometry (bsx_step_split_geom_body.inl: the same phase file) and hands the four observation values per agent back; the waves meet
+//     a second time before the stores, wave 0 stores everything.
+//   form 2 (variant builds, -DBSX_X_SPLIT=2): wave 1 takes the raw records from wave 0 right after the first loads and repeats classify +
+//     move itself -- it starts earlier, and issues 45 % more.
 //   form 1 (variant builds, -DBSX_X_SPLIT=1): wave 0 PLANES (move, geometry, outcome, stores), wave 1 BULLETS (shot, pool pass, resolve),
 //     three rendezvous (records; post-move sprites; counts).
 // 65 536 games, one-wave kernel 6.09 us: form 1 6.31, with the bullets wave at priority 1 6.00; form 2 6.70, with wave 0 at priority 1
-// 5.93, compiled with -amdgpu-sched-strategy=max-ilp 5.66.  Stamps of form 2: wave 0 reaches the hand-over 9 559 cycles after its
-// start, the geometry wave 9 416 -- balanced.  Beyond 114 688 games (3.5 one-wave waves per SIMD) the one-wave kernel wins again.
+// 5.93, compiled with -amdgpu-sched-strategy=max-ilp 5.65; form 4 (priority, max-ilp) 5.60.  By size, one-wave / form 2 / form 4:
+// 16 384 games 4.84 / 4.33 / 4.34, 32 768 5.22 / 4.76 / 4.80, 49 152 - / 5.36 / 5.31, 81 920 6.99 / 6.68 / 6.33, 114 688 8.11 / 7.50 /
+// 7.11; beyond that (131 072: 8.31 against 8.85) the one-wave kernel wins again.  (Also measured, not kept: the geometry wave storing the
+// call's outputs itself from an 8-byte publish of the outcome -- 5.62, 5.83 with its priority raised for the stores.)
 //
 // How.  No second copy of the game logic: the kernel includes the SAME phase files as bsx_step_kernel, once per wave, with the R_*
 // constants of the wave's role.  The phases guard their side effects (LDS staging, stores, the pool pass, the rendezvous) by them;
@@ -156,18 +161,17 @@ void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uin
         return d;
     };
     const ix_t pool0 = ix_t(wblk) * ix_t(POOL_CAP);
-    // X_SPLIT_FORM 1 (A): wave 0 = planes (move, geometry, outcome, stores), wave 1 = bullets (shot, pool pass, resolve); three rendezvous
-    // X_SPLIT_FORM 2 (G): wave 0 = everything but the observation geometry, wave 1 = move + geometry only; two rendezvous
+    // (per-call forms 1, 2, 4 and the multi-tick form: the header of this file)
     if constexpr (MANY) {
         if (role_wave == 0) {
             if constexpr (X_SPLIT_PRIO > 0) __builtin_amdgcn_s_setprio(X_SPLIT_PRIO);   // the game wave's tick sets the pace: it goes first at the SIMD's ports
-            constexpr bool R_BULLETS = true, R_MOVE = true, R_STAGE = true, R_GEOM = false, R_OUTCOME = true, R_RDV_MOVE = false;
+            constexpr bool R_BULLETS = true, R_MOVE = true, R_STAGE = true, R_GEOM = false, R_OUTCOME = true, R_RDV_MOVE = false, R_POSE_LDS = false;
             constexpr bool R_ST_STATE = false, R_ST_OUT = false;
             constexpr int R_RDV_COUNTS = 1, R_GEOM_LDS = 0;
             s_ov[tid] = 0ull;                            // (cleared again by whoever finds it set)
 #include "bsx_step_split_many_body.inl"
         } else {
-            constexpr bool R_BULLETS = false, R_MOVE = true, R_STAGE = false, R_GEOM = true, R_OUTCOME = true, R_RDV_MOVE = false;
+            constexpr bool R_BULLETS = false, R_MOVE = true, R_STAGE = false, R_GEOM = true, R_OUTCOME = true, R_RDV_MOVE = false, R_POSE_LDS = false;
             constexpr bool R_ST_STATE = true, R_ST_OUT = true;
             constexpr int R_RDV_COUNTS = 2, R_GEOM_LDS = 0;
 #include "bsx_step_split_many_body.inl"
@@ -177,17 +181,23 @@ void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uin
     if (role_wave == 0) {
         constexpr bool FIRST = true;                     // this wave loads the shared records and hands them over
         if constexpr (X_SPLIT_PRIO > 0) __builtin_amdgcn_s_setprio(X_SPLIT_PRIO);
-        constexpr bool R_BULLETS = X_SPLIT_FORM == 2, R_MOVE = true, R_STAGE = true, R_GEOM = X_SPLIT_FORM == 1, R_OUTCOME = true, R_ST_STATE = true, R_ST_OUT = true, R_RDV_MOVE = X_SPLIT_FORM == 1;
-        constexpr int R_RDV_COUNTS = X_SPLIT_FORM == 1 ? 2 : 0, R_GEOM_LDS = X_SPLIT_FORM == 2 ? 2 : 0;
+        constexpr bool R_BULLETS = X_SPLIT_FORM != 1, R_MOVE = true, R_STAGE = true, R_GEOM = X_SPLIT_FORM == 1, R_OUTCOME = true, R_ST_STATE = true, R_ST_OUT = true, R_RDV_MOVE = X_SPLIT_FORM == 1;
+        constexpr bool R_POSE_LDS = X_SPLIT_FORM == 4;
+        constexpr int R_RDV_COUNTS = X_SPLIT_FORM == 1 ? 2 : 0, R_GEOM_LDS = (X_SPLIT_FORM == 2 || X_SPLIT_FORM == 4) ? 2 : 0;
         if constexpr (R_BULLETS) s_ov[tid] = 0ull;       // (cleared again by whoever finds it set)
 #include "bsx_step_split_body.inl"
     } else {
         constexpr bool FIRST = false;
         if constexpr (X_SPLIT_PRIO < 0) __builtin_amdgcn_s_setprio(-X_SPLIT_PRIO);   // (negative: the second wave is the one raised)
+        if constexpr (X_SPLIT_FORM == 4) {
+#include "bsx_step_split_geom_body.inl"
+        } else {
         constexpr bool R_BULLETS = X_SPLIT_FORM == 1, R_MOVE = X_SPLIT_FORM == 2, R_STAGE = false, R_GEOM = X_SPLIT_FORM == 2, R_OUTCOME = false, R_ST_STATE = false, R_ST_OUT = false, R_RDV_MOVE = X_SPLIT_FORM == 1;
         constexpr int R_RDV_COUNTS = X_SPLIT_FORM == 1 ? 1 : 0, R_GEOM_LDS = X_SPLIT_FORM == 2 ? 1 : 0;
+        constexpr bool R_POSE_LDS = false;
         if constexpr (R_BULLETS) s_ov[tid] = 0ull;
 #include "bsx_step_split_body.inl"
+        }
     }
     }
 }

@@ -49,7 +49,7 @@
                     pc = __builtin_amdgcn_readfirstlane(*elem(bcnt_, ix_t(wblk)));
                     if (p.u) uu_in = p.u[g];                                   // (injected jitter: uniform branch)
                 }
-                if constexpr (!X_SPLIT_OWN_LOADS) {      // (variant builds: every wave loads its own copy instead -- twice the first burst of requests, no rendezvous)
+                if constexpr (!X_SPLIT_OWN_LOADS && X_SPLIT_FORM != 4) {   // (own loads, variant builds: every wave loads its own copy -- twice the first burst of requests, no rendezvous; form 4: the geometry wave needs no records)
                 s_t0[tid] = v4u_t{ecw.x, ecw.y, edw.x, edw.y};
                 s_t1[tid] = v4u_t{prw.x, prw.y, uint32_t(act), 0u};
                 split_rendezvous();

@@ -1,9 +1,9 @@
 """The two-wave 1v1 step kernels (csrc/bsx_step_split.h) against the one-wave kernels (BSX_F_ONE_WAVE / `one_wave=True`): the same step() of
 envs/battle_env.py:281-381, so every output of every call and the complete game state must be IDENTICAL -- the kernels include the same
 phase files, each wave with the side effects of its role.  The product runs the MULTI-TICK form (a game wave + an outputs wave per 64
-agents) for bsx_step_many_discrete up to 65 536 games and the PER-CALL form 2 (a wave for everything but the observation geometry + a
-geometry wave) for bsx_step_discrete / _range up to 114 688 games; per-call form 1 (a planes wave + a bullets wave) is a measured
-experiment that loses and lives in variant builds only."""
+agents) for bsx_step_many_discrete up to 65 536 games and the PER-CALL form 4 (a wave for everything but the observation geometry + a
+geometry wave fed the post-move poses) for bsx_step_discrete / _range up to 114 688 games; per-call forms 1 (a planes wave + a bullets
+wave) and 2 (the geometry wave repeats classify and move from the raw records) are measured experiments in variant builds only."""
 import os
 import subprocess
 import sys
@@ -16,9 +16,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("form", ["1"])                 # (form 2 is the product's; the tests below run against it directly)
-def test_per_call_form_1_variant_equals_the_one_wave_kernel(form):
-    """The experiment's kernel stays correct: a variant library with per-call form 1 (tools/build_variant.py, ~1 min on the GPU box), and
+@pytest.mark.parametrize("form", ["1", "2"])            # (form 4 is the product's; the tests below run against it directly)
+def test_per_call_variant_forms_equal_the_one_wave_kernel(form):
+    """The experiments' kernels stay correct: a variant library with per-call form 1 or 2 (tools/build_variant.py, ~1 min on the GPU box), and
     this file's per-call tests again in a child process with BSX_LIB_PATH pointing at it."""
     if os.environ.get("BSX_SPLIT_CHILD") == "1":
         pytest.skip("this IS the child process")
