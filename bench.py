@@ -622,14 +622,17 @@ def main():
         return dict(env=env, walls=walls, kms=kms, G=G, live=live, Kb=Kb or K, solo=solo)
 
     def two_wave(n, continuous, many, E):
-        """csrc split_applies(): discrete 1v1 launches run as a two-wave kernel (bsx_step_split.h) -- multi-tick launches of up to 65 536
-        games, per-call launches of up to 114 688."""
-        return n == 1 and not continuous and E <= (65536 if many else 114688) and not args.one_wave
+        """csrc split_applies(): 1v1 launches run as a two-wave kernel (bsx_step_split.h) -- discrete multi-tick launches of up to 65 536
+        games, discrete per-call launches of up to 114 688, continuous per-call launches of up to 81 920."""
+        if n != 1 or args.one_wave or (continuous and many):
+            return False
+        return E <= (65536 if many else (81920 if continuous else 114688))
 
     def kernel_name(n, continuous, many, E):
         narrow = E * 2 * n * 200 <= 0xFFFFFFFF            # csrc narrow_offsets_ok(): 32-bit offsets while every array stays below 4 GB
         if two_wave(n, continuous, many, E):
-            return f"bsx_step_split_kernel<false,{'true' if narrow else 'false'},{'true' if many else 'false'}>"      # <LG, OFF32, MANY>
+            return (f"bsx_step_split_kernel<false,{'true' if narrow else 'false'},{'true' if many else 'false'},"
+                    f"{'true' if continuous else 'false'}>")      # <LG, OFF32, MANY, CONT>
         return (f"bsx_step_kernel<{n if n <= 4 else 0},{'true' if continuous else 'false'},{'true' if many else 'false'},false,false,"
                 f"{'true' if narrow else 'false'}>")       # <N, CONT, MULTI, ACTOR, LG, OFF32>
 

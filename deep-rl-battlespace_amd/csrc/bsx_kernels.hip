@@ -46,6 +46,9 @@
 #include "bsx_step_split.h"                              // the two-wave 1v1 kernels
 #define BSX_INST_SPLIT_MANY
 #define BSX_INST_SPLIT
+#if !defined(BSX_VARIANT) || BSX_X_SPLIT == 4
+#define BSX_INST_SPLIT_CONT
+#endif
 #ifdef BSX_VARIANT
 #define BSX_INST_KW
 #else
@@ -286,22 +289,27 @@ inline bool narrow_offsets_ok(int64_t E, int n, uint32_t flags) {
 // kernel's fewer instructions win (131 072 games: 4.45 against 5.2).
 // Per-call launches (bsx_step_discrete, *_range) of up to 114 688 games: a wave for everything but the observation geometry and a GEOMETRY
 // wave that takes the post-move poses from it -- 6.08 -> 5.60 us per call at 65 536 games, 4.34 -> 3.99 at 4 096, 6.99 -> 6.33 at 81 920,
-// 8.11 -> 7.11 at 114 688 (131 072: 8.31 -> 8.85, so not there).
+// 8.11 -> 7.11 at 114 688 (131 072: 8.31 -> 8.85, so not there).  Continuous actions (bsx_step_continuous) take the same form up to 81 920
+// games (84 ... 88 registers: six waves per SIMD at most): 8.07 -> 7.67 us at 65 536 games, 6.26 -> 5.85 at 16 384, 9.49 -> 8.74 at 81 920 (98 304: 9.92 -> 11.95).
 #ifndef BSX_X_SPLIT_MANY_MAX
 #define BSX_X_SPLIT_MANY_MAX 65536
 #endif
 #ifndef BSX_X_SPLIT_MAX
 #define BSX_X_SPLIT_MAX 114688
 #endif
-constexpr int64_t SPLIT_MAX_GAMES = BSX_X_SPLIT_MAX, SPLIT_MANY_MAX_GAMES = BSX_X_SPLIT_MANY_MAX;
+#ifndef BSX_X_SPLIT_CONT_MAX
+#define BSX_X_SPLIT_CONT_MAX 81920
+#endif
+constexpr int64_t SPLIT_MAX_GAMES = BSX_X_SPLIT_MAX, SPLIT_MANY_MAX_GAMES = BSX_X_SPLIT_MANY_MAX, SPLIT_CONT_MAX_GAMES = BSX_X_SPLIT_CONT_MAX;
 template <bool CONT, bool MULTI>
 inline bool split_applies(int n, const StepArgs& a, int64_t bound) {
-    if (CONT || n != 1 || (a.flags & BSX_F_ONE_WAVE)) return false;
+    if (n != 1 || (a.flags & BSX_F_ONE_WAVE)) return false;
+    if (CONT) return !MULTI && X_SPLIT_FORM == 4 && bound <= SPLIT_CONT_MAX_GAMES;   // (continuous actions: the per-call form 4 only)
     return MULTI ? (X_SPLIT_MANY && bound <= SPLIT_MANY_MAX_GAMES) : (X_SPLIT_FORM != 0 && bound <= SPLIT_MAX_GAMES);
 }
-template <bool LG, bool OFF32, bool MANY>
+template <bool LG, bool OFF32, bool MANY, bool CONT = false>
 void launch_split(dim3 grid, hipStream_t s, const StepArgs& a, int64_t bound) {
-    hipLaunchKernelGGL((bsx_step_split_kernel<LG, OFF32, MANY>), grid, dim3(2 * SPB), 0, s, bound, a.st.envc, a.st.envd, a.st.plane, a.actions, a.st.bent, a.st.bcnt, a.action_kind, a);
+    hipLaunchKernelGGL((bsx_step_split_kernel<LG, OFF32, MANY, CONT>), grid, dim3(2 * SPB), 0, s, bound, a.st.envc, a.st.envd, a.st.plane, a.actions, a.st.bent, a.st.bcnt, a.action_kind, a);
 }
 template <bool CONT, bool MULTI, bool LG>
 void launch_for_n(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs& a, int64_t bound) {
@@ -309,6 +317,12 @@ void launch_for_n(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs& a
         if (split_applies<CONT, MULTI>(n, a, bound)) {   // (the grid is the same: one workgroup per 64 agents, of two waves instead of one)
             if (narrow_offsets_ok(a.E, n, a.flags)) launch_split<LG, true, MULTI>(grid, s, a, bound);
             else launch_split<LG, false, MULTI>(grid, s, a, bound);
+            return;
+        }
+    } else if constexpr (!MULTI && X_SPLIT_FORM == 4) {
+        if (split_applies<CONT, MULTI>(n, a, bound)) {
+            if (narrow_offsets_ok(a.E, n, a.flags)) launch_split<false, true, false, true>(grid, s, a, bound);
+            else launch_split<false, false, false, true>(grid, s, a, bound);
             return;
         }
     }

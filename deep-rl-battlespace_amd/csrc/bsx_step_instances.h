@@ -27,19 +27,18 @@ BSX_STEP_FAMILY(0, true) BSX_STEP_FAMILY(1, true) BSX_STEP_FAMILY(2, true) BSX_S
 #ifdef BSX_INST_ROLLOUT
 BSX_ROLLOUT_FAMILY(1) BSX_ROLLOUT_FAMILY(2) BSX_ROLLOUT_FAMILY(3) BSX_ROLLOUT_FAMILY(4)
 #endif
-#ifdef BSX_INST_SPLIT
-#define BSX_SPLIT_INST(LG, OFF32, MANY)                                                                                                  \
-    BSX_INST_KW template __global__ void bsxk::bsx_step_split_kernel<LG, OFF32, MANY>(                                                   \
+#if defined(BSX_INST_SPLIT) || defined(BSX_INST_SPLIT_MANY)
+#define BSX_SPLIT_INST(LG, OFF32, MANY, CONT)                                                                                            \
+    BSX_INST_KW template __global__ void bsxk::bsx_step_split_kernel<LG, OFF32, MANY, CONT>(                                             \
         const int64_t, const uint2* const, const uint2* const, const uint2* const, const void* const, const uint2* const, const uint32_t* const, \
         const int, const bsxk::StepArgs);
-BSX_SPLIT_INST(false, false, false) BSX_SPLIT_INST(false, true, false) BSX_SPLIT_INST(true, false, false) BSX_SPLIT_INST(true, true, false)
+#endif
+#ifdef BSX_INST_SPLIT
+BSX_SPLIT_INST(false, false, false, false) BSX_SPLIT_INST(false, true, false, false) BSX_SPLIT_INST(true, false, false, false) BSX_SPLIT_INST(true, true, false, false)
+#ifdef BSX_INST_SPLIT_CONT                               // (continuous actions: the product's per-call form only; see bsx_step_split.h)
+BSX_SPLIT_INST(false, false, false, true) BSX_SPLIT_INST(false, true, false, true)
+#endif
 #endif
 #ifdef BSX_INST_SPLIT_MANY
-#ifndef BSX_SPLIT_INST
-#define BSX_SPLIT_INST(LG, OFF32, MANY)                                                                                                  \
-    BSX_INST_KW template __global__ void bsxk::bsx_step_split_kernel<LG, OFF32, MANY>(                                                   \
-        const int64_t, const uint2* const, const uint2* const, const uint2* const, const void* const, const uint2* const, const uint32_t* const, \
-        const int, const bsxk::StepArgs);
-#endif
-BSX_SPLIT_INST(false, false, true) BSX_SPLIT_INST(false, true, true) BSX_SPLIT_INST(true, false, true) BSX_SPLIT_INST(true, true, true)
+BSX_SPLIT_INST(false, false, true, false) BSX_SPLIT_INST(false, true, true, false) BSX_SPLIT_INST(true, false, true, false) BSX_SPLIT_INST(true, true, true, false)
 #endif

@@ -2,7 +2,8 @@
 // Part of the step() path of libbattlespace_hip.so (included after bsx_step_kernel.h; instantiated in bsx_step_two_wave.hip).  Two uses, both PRODUCT:
 //   * MANY = true: multi-tick launches (bsx_step_many_discrete) of up to 65 536 games -- 3.05 -> 2.54 us per tick at 65 536 games
 //     (51 G agent-steps/s), 2.65 -> 1.75 at 32 768;
-//   * MANY = false: one call per launch (bsx_step_discrete, *_range) of up to 114 688 games, form 4 below -- C2 6.08 -> 5.60 us.
+//   * MANY = false: one call per launch (bsx_step_discrete, *_range) of up to 114 688 games, form 4 below -- C2 6.08 -> 5.60 us; with
+//     continuous actions (CONT; bsx_step_continuous, *_range) of up to 81 920 games -- 8.07 -> 7.67 us at 65 536 games.
 // In both the wave that carries the game's chain runs at s_setprio 1: a SIMD's arbiter serves its resident waves oldest-first, and
 // without the priority the chain's wave queues behind the wave that has slack -- the per-call forms then LOSE (6.31 / 6.70 us), the
 // multi-tick form gains less (2.85).  DESIGN.md sections 4 and 6; profiles/r05_experiments.json.
@@ -51,7 +52,7 @@ namespace bsxk {
 //   wave 1, OUTPUTS  classify -> move -> geometry -> [rendezvous: the counts] -> outcome -> stores (rows, rewards, flags; state after the last tick)
 // Both waves carry the planes' and the game's records in registers and advance them by the same arithmetic on the same counts, so
 // they never exchange state; the outputs wave is up to a tick behind.
-template <bool LG, bool OFF32, bool MANY = false>
+template <bool LG, bool OFF32, bool MANY = false, bool CONT_ = false>
 __global__ __launch_bounds__(2 * SPB)
 #ifdef BSX_X_SPLIT_WAVES                                 // variant builds: at most this many waves per SIMD, i.e. more registers for the scheduler to use
 __attribute__((amdgpu_waves_per_eu(1, BSX_X_SPLIT_WAVES)))
@@ -59,7 +60,10 @@ __attribute__((amdgpu_waves_per_eu(1, BSX_X_SPLIT_WAVES)))
 void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uint2* const envd_, const uint2* const plane_, const void* const act_,
                            const uint2* const bent_, const uint32_t* const bcnt_, const int kind_, const StepArgs p_) {
     constexpr int N = 1;
-    constexpr bool CONT = false, MULTI = MANY, ACTOR = false;
+    constexpr bool CONT = CONT_, MULTI = MANY, ACTOR = false;
+    // continuous actions (bsx_step_continuous): the per-call form 4 only -- its geometry wave needs nothing but the poses, so only the
+    // first wave's loads differ (the action triple by encoding, the float64 heading beside the plane record)
+    static_assert(!CONT || (!MANY && !LG && X_SPLIT_FORM == 4), "continuous actions: per-call form 4 only");
     const StepArgs& p = p_;
     typedef typename std::conditional<OFF32, uint32_t, size_t>::type ix_t;     // row / element offsets
     typedef typename std::conditional<OFF32, int32_t, int64_t>::type ixs_t;    // game indices

@@ -32,6 +32,7 @@
         // a second wave with the bullets (form 1) asks for its pool meanwhile.
         {
             uint2 ecw, edw, prw;
+            double dirf = 0.0; (void)dirf;
             if constexpr (FIRST || X_SPLIT_OWN_LOADS) {
                 ecw = *elem(envc_, ix_t(ec));
                 edw = *elem(envd_, ix_t(ec));
@@ -39,11 +40,32 @@
                 const char* const abase = static_cast<const char*>(act_);
                 float4 lg = make_float4(0.f, 0.f, 0.f, 0.f);
                 int ai = -1;
-                if constexpr (LG) lg = *reinterpret_cast<const float4*>(elem(abase, has_act ? g * 16 : ix_t(0)));
+                float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+                double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+                if constexpr (CONT) {                    // (as bsx_step_kernel's load_inputs: the triple by encoding, uniform branches)
+                    dirf = *elem(p.st.pdirf, gt);
+                    if (has_act) {
+                        if (kind_ == BSX_ACT_F32) {
+                            const float* ap = static_cast<const float*>(act_) + 3 * g;
+                            f0 = ap[0]; f1 = ap[1]; f2 = ap[2];
+                        } else if (kind_ == BSX_ACT_F32X4) {
+                            const float4 v = static_cast<const float4*>(act_)[g];
+                            f0 = v.x; f1 = v.y; f2 = v.z;
+                        } else {
+                            const double* ap = static_cast<const double*>(act_) + 3 * g;
+                            c0 = ap[0]; c1 = ap[1]; c2 = ap[2];
+                        }
+                    }
+                } else if constexpr (LG) lg = *reinterpret_cast<const float4*>(elem(abase, has_act ? g * 16 : ix_t(0)));
                 else ai = *reinterpret_cast<const int32_t*>(elem(abase, has_act ? g * 4 : ix_t(0)));
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("" : "+s"(seed_t), "+s"(env_offset_t));
-                if (has_act) act = LG ? argmax4(lg.x, lg.y, lg.z, lg.w) : ai;
+                if constexpr (CONT) {
+                    if (has_act) {
+                        if (kind_ == BSX_ACT_F32 || kind_ == BSX_ACT_F32X4) { a0 = double(f0); a1 = double(f1); a2 = double(f2); }
+                        else { a0 = c0; a1 = c1; a2 = c2; }
+                    }
+                } else if (has_act) act = LG ? argmax4(lg.x, lg.y, lg.z, lg.w) : ai;
                 if constexpr (R_BULLETS) {
                     pool_first = *elem(bent_, pool0 + ix_t(lane));
                     pc = __builtin_amdgcn_readfirstlane(*elem(bcnt_, ix_t(wblk)));
@@ -67,6 +89,7 @@
                 act = int(t1.z);
             }
             unpack_plane(prw, x, y, hp, dir);
+            if constexpr (CONT) dir = (prw.y & PLANE_FRAC) ? dirf : dir;
             er = unpack_env(ecw, edw.x);
             games = edw.y;
         }

@@ -87,8 +87,8 @@ class parallel_env:
         rng         "python" (stdlib random, reference draw order; default when n_envs is None) or "philox"
         wide_offsets  take the 64-bit-offset kernels (BSX_F_WIDE_OFFSETS) although the job is small enough for 32-bit offsets;
                     the library switches by itself above 4 GB per array -- same results, for tests
-        one_wave    BSX_F_ONE_WAVE: keep the one-wave kernel where the library would take a two-wave form (discrete 1v1: step_many of up
-                    to 65 536 games, step / step_batch of up to 114 688) -- same results, for the tests that compare the two and for A/B runs
+        one_wave    BSX_F_ONE_WAVE: keep the one-wave kernel where the library would take a two-wave form (1v1: step_many of up to 65 536 games,
+                    step / step_batch of up to 114 688 games, 81 920 with continuous actions) -- same results, for the tests that compare the two and for A/B runs
         """
         if not isinstance(n_agents, (int, np.integer)) or not 1 <= n_agents <= _lib.MAX_N:
             raise ValueError(f"n_agents must be an int in 1..{_lib.MAX_N}, got {n_agents!r}")

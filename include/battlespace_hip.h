@@ -54,7 +54,7 @@ typedef struct BsxRewards {
 /* Flags for bsx_step_* */
 #define BSX_F_AUTO_RESET 1u  /* a call on a finished env re-spawns it (Philox) instead of the inert step of battle_env.py:303-306 */
 #define BSX_F_EMPTY_CALL 2u  /* step({}) : every running env ties (battle_env.py:309-313) */
-#define BSX_F_ONE_WAVE 8u     /* keep the one-wave step kernel where the library would take a two-wave form of it (csrc/bsx_step_split.h): discrete 1v1 launches -- multi-tick ones of up to 65 536 games (bsx_step_many_discrete: a game wave + an outputs wave per 64 agents), per-call ones of up to 114 688 games (bsx_step_discrete, _range: a wave for everything but the observation geometry + a geometry wave).  Same results either way -- for the tests that run the two against each other, and for A/B runs */
+#define BSX_F_ONE_WAVE 8u     /* keep the one-wave step kernel where the library would take a two-wave form of it (csrc/bsx_step_split.h): discrete 1v1 launches -- multi-tick ones of up to 65 536 games (bsx_step_many_discrete: a game wave + an outputs wave per 64 agents), per-call ones of up to 114 688 games (bsx_step_discrete, _range: a wave for everything but the observation geometry + a geometry wave) -- and continuous 1v1 per-call launches of up to 81 920 games (bsx_step_continuous, _range: the same form).  Same results either way -- for the tests that run the two against each other, and for A/B runs */
 #define BSX_F_WIDE_OFFSETS 4u /* take the 64-bit-offset kernels although the job's arrays stay below 4 GB (they are chosen automatically above that; same results -- for tests) */
 
 /* Action encodings for bsx_step_discrete */

@@ -92,6 +92,35 @@ def test_per_call_two_wave_kernel_equals_the_one_wave_kernel(E, enc, wide, auto)
     assert (c == b.counters()).all() and int(c[:, 0].sum()) > 0 and int(c[:, 2:].sum()) > 0        # games ended, some by a base kill
 
 
+@pytest.mark.parametrize("E,dtype,wide,auto", [(65536, torch.float32, False, True), (81920, torch.float32, False, True), (1000, torch.float64, False, True), (31, torch.float32, True, False),
+                                              (4097, torch.float64, True, True), (131072, torch.float32, False, True)])
+def test_per_call_two_wave_kernel_with_continuous_actions_equals_the_one_wave_kernel(E, dtype, wide, auto):
+    """bsx_step_continuous takes the two-wave form too (up to 81 920 games): only the first wave's loads differ -- the action triple in its
+    encodings (float32 / float64 [.,3] here; float32 rows of four come from the policy rollout's graph form, whose tests run against the C
+    oracle) and the float64 heading beside the plane record; the geometry wave is the discrete kernel's.  Fractional headings, sincos moves and shots, clipped actions, masked resets: outputs and state identical."""
+    if os.environ.get("BSX_SPLIT_CHILD") == "1":
+        pytest.skip("variant libraries carry the continuous two-wave kernel only in the product's form")
+    kw = dict(n_agents=1, n_envs=E, seed=17, auto_reset=auto, wide_offsets=wide, continuous_actions=True)
+    a, b = _env(**kw), _env(one_wave=True, **kw)
+    oa, ob = a.reset(), b.reset()
+    assert all(torch.equal(oa[k], ob[k]) for k in oa)
+    g = torch.Generator(device="cuda"); g.manual_seed(9)
+    T = 200 if E <= 65536 else 100
+    for t in range(T):
+        act = (torch.rand((E, 2, 3), generator=g, device="cuda", dtype=torch.float32) * 2.6 - 1.3).to(dtype)   # beyond [-1, 1]: clipped in-kernel
+        act[..., 2] = torch.where(torch.rand((E, 2), generator=g, device="cuda") < 0.5, torch.ones((), device="cuda", dtype=dtype), act[..., 2])
+        ra, rb = a.step_batch(act), b.step_batch(act)
+        for u, v, name in zip(ra, rb, ("obs", "rew", "done")):
+            assert torch.equal(u, v), (t, name)
+        assert torch.equal(a.env_done, b.env_done) and torch.equal(a.winner, b.winner), t
+        if not auto and t % 40 == 39:
+            m = a.env_done.clone()
+            a.reset(mask=m); b.reset(mask=m)
+        if t in (50, T - 1):
+            _same_state(a, b)
+    assert int(a.counters()[:, 0].sum()) > 0
+
+
 def test_per_call_two_wave_kernel_with_injected_jitter_and_as_range_launches():
     """Host-drawn random() values for the shots (the parity traces' form) and the batch as two chains of range launches in one graph
     (bsx_step_discrete_range): the launcher takes the split kernel for each range; same games as the one-wave kernel per call."""

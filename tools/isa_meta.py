@@ -25,9 +25,9 @@ def short_name(mangled):
     m = re.match(r"_ZN(?:12_GLOBAL__N_1|4bsxk)15bsx_step_kernelILi(\d+)ELb([01])ELb([01])ELb([01])ELb([01])ELb([01])E", mangled)
     if m:
         return "bsx_step_kernel<%s,%s>" % (m.group(1), ",".join("FT"[int(b)] for b in m.groups()[1:]))
-    m = re.match(r"_ZN(?:12_GLOBAL__N_1|4bsxk)21bsx_step_split_kernelILb([01])ELb([01])ELb([01])E", mangled)
+    m = re.match(r"_ZN(?:12_GLOBAL__N_1|4bsxk)21bsx_step_split_kernelILb([01])ELb([01])ELb([01])ELb([01])E", mangled)
     if m:
-        return "bsx_step_split_kernel<%s>" % ",".join("FT"[int(b)] for b in m.groups())     # <LG, OFF32, MANY>
+        return "bsx_step_split_kernel<%s>" % ",".join("FT"[int(b)] for b in m.groups())     # <LG, OFF32, MANY, CONT>
     m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", mangled)
     if m:
         n = int(m.group(1))
