@@ -35,6 +35,7 @@ constexpr int X_PRIO_BY_SLOT = 0;
 constexpr bool X_SPLIT_MANY = true;
 constexpr int X_SPLIT_FORM = 4, X_SPLIT_PRIO = 1;
 constexpr bool X_SPLIT_OWN_LOADS = false;
+constexpr int X_SPLIT_GEOM_PRIO = 0;
 #define STAMP(i) do { } while (0)
 #define STAMP_HWID() do { } while (0)
 #define FSTAMP(i) do { } while (0)

@@ -100,6 +100,11 @@ constexpr bool X_SPLIT_OWN_LOADS = true;
 #else
 constexpr bool X_SPLIT_OWN_LOADS = false;
 #endif
+// -DBSX_X_SPLIT_GEOM_PRIO=<0..3>: per-call form 4, the geometry wave's priority once the poses are there (same results)
+#ifndef BSX_X_SPLIT_GEOM_PRIO
+#define BSX_X_SPLIT_GEOM_PRIO 0
+#endif
+constexpr int X_SPLIT_GEOM_PRIO = BSX_X_SPLIT_GEOM_PRIO;
 // -DBSX_X_PRIO_BY_SLOT=<1|2>: one-wave kernels, s_setprio by the wave's slot on its SIMD (1: slot & 1, 2: slot & 3; same results)
 #ifndef BSX_X_PRIO_BY_SLOT
 #define BSX_X_PRIO_BY_SLOT 0

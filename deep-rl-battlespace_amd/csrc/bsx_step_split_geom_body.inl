@@ -3,6 +3,8 @@
 // file, bsx_step_phase_geometry.inl) and hands the four observation values per agent back before the stores.
     {
         split_rendezvous();                              // the first wave has moved its planes (bsx_step_phase_move.inl, R_POSE_LDS)
+        if constexpr (X_SPLIT_GEOM_PRIO > 0) __builtin_amdgcn_s_setprio(X_SPLIT_GEOM_PRIO);   // (variant builds: from here on this wave's work is awaited too)
+        STAMP(0); STAMP(1); STAMP(2);                    // (diagnostic builds: this wave's row of stamps -- waited for the poses | geometry | waited for the stores)
         const v4u_t h0 = s_t0[tid], h1 = s_t1[tid];
         const int x = int(h0.x), y = int(h0.y), nx_ = int(h0.z), ny_ = int(h0.w);
         const double dir = __hiloint2double(int(h1.y), int(h1.x));
@@ -18,5 +20,7 @@
         const ix_t gt = g, EAt = 0;
         (void)lane; (void)ks; (void)shot_exact; (void)spawn; (void)nexact; (void)nbdir; (void)nd; (void)gt; (void)EAt; (void)team; (void)gl; (void)eb;
 #include "bsx_step_phase_geometry.inl"
+        STAMP(4); STAMP(5); STAMP(6);
         split_rendezvous();                              // the hand-over before the stores (bsx_step_phase_stores.inl, R_GEOM_LDS)
+        STAMP(7);
     }
