@@ -105,6 +105,15 @@ constexpr bool X_SPLIT_OWN_LOADS = false;
 #define BSX_X_SPLIT_GEOM_PRIO 0
 #endif
 constexpr int X_SPLIT_GEOM_PRIO = BSX_X_SPLIT_GEOM_PRIO;
+// -DBSX_X_PRIO_LATE=<k> [-DBSX_X_PRIO_LATE_LEVEL=<1..3>]: one-wave kernels, the workgroups of the last (8 - k) eighths of the grid at a raised
+// priority (a launch with more waves than a SIMD holds: its late starters; same results)
+#ifndef BSX_X_PRIO_LATE
+#define BSX_X_PRIO_LATE 0
+#endif
+#ifndef BSX_X_PRIO_LATE_LEVEL
+#define BSX_X_PRIO_LATE_LEVEL 1
+#endif
+constexpr int X_PRIO_LATE = BSX_X_PRIO_LATE, X_PRIO_LATE_LEVEL = BSX_X_PRIO_LATE_LEVEL;
 // -DBSX_X_PRIO_BY_SLOT=<1|2>: one-wave kernels, s_setprio by the wave's slot on its SIMD (1: slot & 1, 2: slot & 3; same results)
 #ifndef BSX_X_PRIO_BY_SLOT
 #define BSX_X_PRIO_BY_SLOT 0

@@ -116,6 +116,9 @@ void bsx_step_kernel(const int64_t E_, const uint2* const envc_, const uint2* co
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         for (uint32_t i = 0; i < (hw & 15u); ++i) __builtin_amdgcn_s_sleep(X_DEPHASE_SLOT);
     }
+    if constexpr (X_PRIO_LATE > 0) {                     // variant builds only: the workgroups dispatched LAST (blockIdx in the last (8 - X_PRIO_LATE) eighths of the
+        if (blockIdx.x * 8u >= gridDim.x * unsigned(X_PRIO_LATE)) __builtin_amdgcn_s_setprio(X_PRIO_LATE_LEVEL);   // grid) at a raised priority: do a launch's late starters catch up?
+    }
     if constexpr (X_PRIO_BY_SLOT > 0) {                  // variant builds only: the waves of a SIMD at different issue priorities, by wave slot
         uint32_t hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
