@@ -631,8 +631,9 @@ def main():
     def kernel_name(n, continuous, many, E):
         narrow = E * 2 * n * 200 <= 0xFFFFFFFF            # csrc narrow_offsets_ok(): 32-bit offsets while every array stays below 4 GB
         if two_wave(n, continuous, many, E):
-            return (f"bsx_step_split_kernel<false,{'true' if narrow else 'false'},{'true' if many else 'false'},"
-                    f"{'true' if continuous else 'false'}>")      # <LG, OFF32, MANY, CONT>
+            form = (2 if E > 32768 else 1) if many else 0     # csrc launch_for_n(): multi-tick launches of more than 32 768 games take form 2
+            return (f"bsx_step_split_kernel<false,{'true' if narrow else 'false'},{form},"
+                    f"{'true' if continuous else 'false'}>")      # <LG, OFF32, MANY (0 per call, 1 / 2 multi-tick forms), CONT>
         return (f"bsx_step_kernel<{n if n <= 4 else 0},{'true' if continuous else 'false'},{'true' if many else 'false'},false,false,"
                 f"{'true' if narrow else 'false'}>")       # <N, CONT, MULTI, ACTOR, LG, OFF32>
 

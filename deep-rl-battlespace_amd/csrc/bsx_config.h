@@ -33,6 +33,7 @@ constexpr int X_PRIO_BY_SLOT = 0, X_PRIO_LATE = 0, X_PRIO_LATE_LEVEL = 1;
 // post-move poses.  In both the first wave -- whose chain sets the pace -- runs at s_setprio 1: without that the per-call forms lose to
 // the one-wave kernel.
 constexpr bool X_SPLIT_MANY = true;
+constexpr int X_SPLIT_MANY_FORM2_FROM = 32768;      // multi-tick launches of MORE games than this (two workgroups on some SIMD) take form 2 of the two-wave kernel
 constexpr int X_SPLIT_FORM = 4, X_SPLIT_PRIO = 1;
 constexpr bool X_SPLIT_OWN_LOADS = false;
 constexpr int X_SPLIT_GEOM_PRIO = 0;

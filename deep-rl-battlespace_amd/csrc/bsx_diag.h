@@ -119,6 +119,12 @@ constexpr int X_PRIO_LATE = BSX_X_PRIO_LATE, X_PRIO_LATE_LEVEL = BSX_X_PRIO_LATE
 #define BSX_X_PRIO_BY_SLOT 0
 #endif
 constexpr int X_PRIO_BY_SLOT = BSX_X_PRIO_BY_SLOT;
+// -DBSX_X_SPLIT_MANY_FORM2_FROM=<games>: multi-tick launches of MORE games than this take form 2 of the two-wave kernel (the outputs wave only
+// takes what the game wave publishes per tick) instead of form 1 (it carries the state too); the product has 32 768; same results
+#ifndef BSX_X_SPLIT_MANY_FORM2_FROM
+#define BSX_X_SPLIT_MANY_FORM2_FROM 32768
+#endif
+constexpr int X_SPLIT_MANY_FORM2_FROM = BSX_X_SPLIT_MANY_FORM2_FROM;
 // -DBSX_X_NO_SPLIT_MANY: multi-tick 1v1 launches keep the one-wave kernel whatever their size (the product takes the two-wave form of
 // bsx_step_split.h up to 65 536 games; same results)
 #ifdef BSX_X_NO_SPLIT_MANY

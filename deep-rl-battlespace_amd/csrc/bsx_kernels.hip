@@ -307,7 +307,7 @@ inline bool split_applies(int n, const StepArgs& a, int64_t bound) {
     if (CONT) return !MULTI && X_SPLIT_FORM == 4 && bound <= SPLIT_CONT_MAX_GAMES;   // (continuous actions: the per-call form 4 only)
     return MULTI ? (X_SPLIT_MANY && bound <= SPLIT_MANY_MAX_GAMES) : (X_SPLIT_FORM != 0 && bound <= SPLIT_MAX_GAMES);
 }
-template <bool LG, bool OFF32, bool MANY, bool CONT = false>
+template <bool LG, bool OFF32, int MANY, bool CONT = false>
 void launch_split(dim3 grid, hipStream_t s, const StepArgs& a, int64_t bound) {
     hipLaunchKernelGGL((bsx_step_split_kernel<LG, OFF32, MANY, CONT>), grid, dim3(2 * SPB), 0, s, bound, a.st.envc, a.st.envd, a.st.plane, a.actions, a.st.bent, a.st.bcnt, a.action_kind, a);
 }
@@ -315,14 +315,20 @@ template <bool CONT, bool MULTI, bool LG>
 void launch_for_n(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs& a, int64_t bound) {
     if constexpr (!CONT) {
         if (split_applies<CONT, MULTI>(n, a, bound)) {   // (the grid is the same: one workgroup per 64 agents, of two waves instead of one)
-            if (narrow_offsets_ok(a.E, n, a.flags)) launch_split<LG, true, MULTI>(grid, s, a, bound);
-            else launch_split<LG, false, MULTI>(grid, s, a, bound);
+            const bool narrow = narrow_offsets_ok(a.E, n, a.flags);
+            if constexpr (!MULTI) {
+                if (narrow) launch_split<LG, true, 0>(grid, s, a, bound); else launch_split<LG, false, 0>(grid, s, a, bound);
+            } else if (bound > X_SPLIT_MANY_FORM2_FROM) {    // two workgroups on some SIMD: the outputs wave that repeats no game logic (form 2)
+                if (narrow) launch_split<LG, true, 2>(grid, s, a, bound); else launch_split<LG, false, 2>(grid, s, a, bound);
+            } else {                                         // one workgroup per SIMD at most: the outputs wave that carries the state too (form 1)
+                if (narrow) launch_split<LG, true, 1>(grid, s, a, bound); else launch_split<LG, false, 1>(grid, s, a, bound);
+            }
             return;
         }
     } else if constexpr (!MULTI && X_SPLIT_FORM == 4) {
         if (split_applies<CONT, MULTI>(n, a, bound)) {
-            if (narrow_offsets_ok(a.E, n, a.flags)) launch_split<false, true, false, true>(grid, s, a, bound);
-            else launch_split<false, false, false, true>(grid, s, a, bound);
+            if (narrow_offsets_ok(a.E, n, a.flags)) launch_split<false, true, 0, true>(grid, s, a, bound);
+            else launch_split<false, false, 0, true>(grid, s, a, bound);
             return;
         }
     }

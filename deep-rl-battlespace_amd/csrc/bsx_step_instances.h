@@ -34,11 +34,12 @@ BSX_ROLLOUT_FAMILY(1) BSX_ROLLOUT_FAMILY(2) BSX_ROLLOUT_FAMILY(3) BSX_ROLLOUT_FA
         const int, const bsxk::StepArgs);
 #endif
 #ifdef BSX_INST_SPLIT
-BSX_SPLIT_INST(false, false, false, false) BSX_SPLIT_INST(false, true, false, false) BSX_SPLIT_INST(true, false, false, false) BSX_SPLIT_INST(true, true, false, false)
+BSX_SPLIT_INST(false, false, 0, false) BSX_SPLIT_INST(false, true, 0, false) BSX_SPLIT_INST(true, false, 0, false) BSX_SPLIT_INST(true, true, 0, false)
 #ifdef BSX_INST_SPLIT_CONT                               // (continuous actions: the product's per-call form only; see bsx_step_split.h)
-BSX_SPLIT_INST(false, false, false, true) BSX_SPLIT_INST(false, true, false, true)
+BSX_SPLIT_INST(false, false, 0, true) BSX_SPLIT_INST(false, true, 0, true)
 #endif
 #endif
 #ifdef BSX_INST_SPLIT_MANY
-BSX_SPLIT_INST(false, false, true, false) BSX_SPLIT_INST(false, true, true, false) BSX_SPLIT_INST(true, false, true, false) BSX_SPLIT_INST(true, true, true, false)
+BSX_SPLIT_INST(false, false, 1, false) BSX_SPLIT_INST(false, true, 1, false) BSX_SPLIT_INST(true, false, 1, false) BSX_SPLIT_INST(true, true, 1, false)
+BSX_SPLIT_INST(false, false, 2, false) BSX_SPLIT_INST(false, true, 2, false) BSX_SPLIT_INST(true, false, 2, false) BSX_SPLIT_INST(true, true, 2, false)
 #endif

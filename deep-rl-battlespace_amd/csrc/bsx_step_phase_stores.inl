@@ -5,7 +5,7 @@
 // @reads   alive cnt_delta mode nhp_ nplane rew
 // @writes  din_next ob_a ob_d oe_a oe_d
 // @exports -
-// @lds -
+// @lds     s_pub
     PSTAMP(6);
     if (MULTI && !ACTOR && tk + 1 < p.T) din_next = decode(rin_next);   // the prefetch has long arrived; no store of this tick is out yet
     // ---- write back (MULTI: plane and game records travel in registers; memory gets them once, after the last tick)
@@ -14,6 +14,15 @@
     if constexpr (R_GEOM_LDS != 0) {
         split_rendezvous();
         if constexpr (R_GEOM_LDS == 2) { const v4f_t gm = s_gm[tid]; ob_d = gm.x; ob_a = gm.y; oe_d[0] = gm.z; oe_a[0] = gm.w; }
+    }
+    // two-wave multi-tick kernel, form 2: the game wave publishes what the outputs wave needs of this tick (one 16-byte word per agent, a buffer
+    // per tick parity): the post-move position, heading, flags, the enemy base, the reward -- and the two waves meet
+    if constexpr (R_PUB == 1) {
+        const bool on_pub = alive && (mode == M_PHYS ? nhp_ - nplane : nhp_) > 0;
+        s_pub[(tk & 1) * SPB + tid] = v4u_t{pack_xy(x, y),
+                                            uint32_t(int(dir)) | (alive ? 512u : 0u) | (on_pub ? 1024u : 0u) | (er.done ? 2048u : 0u),
+                                            __float_as_uint(float(rew)), pack_xy(team == 0 ? er.bbx : er.brx, team == 0 ? er.bby : er.bry)};
+        split_rendezvous();
     }
     if constexpr (R_ST_STATE || R_ST_OUT) {              // (split kernels: which wave stores what of the step's results)
     if (valid) {

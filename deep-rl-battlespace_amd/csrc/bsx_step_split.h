@@ -52,7 +52,7 @@ namespace bsxk {
 //   wave 1, OUTPUTS  classify -> move -> geometry -> [rendezvous: the counts] -> outcome -> stores (rows, rewards, flags; state after the last tick)
 // Both waves carry the planes' and the game's records in registers and advance them by the same arithmetic on the same counts, so
 // they never exchange state; the outputs wave is up to a tick behind.
-template <bool LG, bool OFF32, bool MANY = false, bool CONT_ = false>
+template <bool LG, bool OFF32, int MANY = 0, bool CONT_ = false>
 __global__ __launch_bounds__(2 * SPB)
 #ifdef BSX_X_SPLIT_WAVES                                 // variant builds: at most this many waves per SIMD, i.e. more registers for the scheduler to use
 __attribute__((amdgpu_waves_per_eu(1, BSX_X_SPLIT_WAVES)))
@@ -60,10 +60,11 @@ __attribute__((amdgpu_waves_per_eu(1, BSX_X_SPLIT_WAVES)))
 void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uint2* const envd_, const uint2* const plane_, const void* const act_,
                            const uint2* const bent_, const uint32_t* const bcnt_, const int kind_, const StepArgs p_) {
     constexpr int N = 1;
-    constexpr bool CONT = CONT_, MULTI = MANY, ACTOR = false;
+    constexpr bool CONT = CONT_, MULTI = MANY != 0, ACTOR = false;
+    constexpr int X_SPLIT_MANY_FORM = MANY;              // (0: one call per launch; 1 / 2: the multi-tick forms)
     // continuous actions (bsx_step_continuous): the per-call form 4 only -- its geometry wave needs nothing but the poses, so only the
     // first wave's loads differ (the action triple by encoding, the float64 heading beside the plane record)
-    static_assert(!CONT || (!MANY && !LG && X_SPLIT_FORM == 4), "continuous actions: per-call form 4 only");
+    static_assert(!CONT || (MANY == 0 && !LG && X_SPLIT_FORM == 4), "continuous actions: per-call form 4 only");
     const StepArgs& p = p_;
     typedef typename std::conditional<OFF32, uint32_t, size_t>::type ix_t;     // row / element offsets
     typedef typename std::conditional<OFF32, int32_t, int64_t>::type ixs_t;    // game indices
@@ -100,6 +101,7 @@ void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uin
     __shared__ uint32_t s_agg_all[SPB];
     __shared__ uint32_t s_npl_all[2 * SPB];              // the bullets' counts per shooter (misses | base hits << 8 | plane hits << 16), by tick parity
     __shared__ __attribute__((aligned(16))) v4u_t s_t0_all[SPB], s_t1_all[SPB];   // the first loads' raw words, wave 0 -> wave 1
+    __shared__ __attribute__((aligned(16))) v4u_t s_pub_all[X_SPLIT_MANY_FORM == 2 ? 2 * SPB : 1];   // multi-tick form 2: what a tick's outputs need, game wave -> outputs wave, by tick parity
     __shared__ __attribute__((aligned(16))) v4f_t s_gm_all[SPB];                  // form G: the four observation values, geometry wave -> storing wave
     constexpr bool CORNERS = true;
     typedef u32x2 rect_t;
@@ -121,6 +123,7 @@ void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uin
     auto* const s_agg = BSX_LDS(uint32_t, s_agg_all);
     auto* const s_npl = BSX_LDS(uint32_t, s_npl_all);
     auto* const s_gm = (__attribute__((address_space(3))) volatile v4f_t*)(uintptr_t)(s_gm_all);
+    auto* const s_pub = (__attribute__((address_space(3))) volatile v4u_t*)(uintptr_t)(s_pub_all);
     auto* const s_t0 = (__attribute__((address_space(3))) volatile v4u_t*)(uintptr_t)(s_t0_all);
     auto* const s_t1 = (__attribute__((address_space(3))) volatile v4u_t*)(uintptr_t)(s_t1_all);
     auto* const s_eb = BSX_LDS(rect_t, s_eb_all);
@@ -166,21 +169,26 @@ void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uin
     };
     const ix_t pool0 = ix_t(wblk) * ix_t(POOL_CAP);
     // (per-call forms 1, 2, 4 and the multi-tick form: the header of this file)
-    if constexpr (MANY) {
+    if constexpr (MANY != 0) {
         if (role_wave == 0) {
             if constexpr (X_SPLIT_PRIO > 0) __builtin_amdgcn_s_setprio(X_SPLIT_PRIO);   // the game wave's tick sets the pace: it goes first at the SIMD's ports
             constexpr bool R_BULLETS = true, R_MOVE = true, R_STAGE = true, R_GEOM = false, R_OUTCOME = true, R_RDV_MOVE = false, R_POSE_LDS = false;
-            constexpr bool R_ST_STATE = false, R_ST_OUT = false;
-            constexpr int R_RDV_COUNTS = 1, R_GEOM_LDS = 0;
+            constexpr bool R_ST_STATE = X_SPLIT_MANY_FORM == 2, R_ST_OUT = false;
+            constexpr int R_RDV_COUNTS = X_SPLIT_MANY_FORM == 2 ? 0 : 1, R_GEOM_LDS = 0, R_PUB = X_SPLIT_MANY_FORM == 2 ? 1 : 0;
             s_ov[tid] = 0ull;                            // (cleared again by whoever finds it set)
 #include "bsx_step_split_many_body.inl"
+        } else if constexpr (X_SPLIT_MANY_FORM == 2) {   // (form 2: the outputs wave repeats none of the game logic, the game wave publishes 16 bytes per agent and tick)
+            constexpr bool R_BULLETS = false, R_GEOM = true, R_ST_STATE = false, R_ST_OUT = true;
+            constexpr int R_GEOM_LDS = 0, R_PUB = 0;
+#include "bsx_step_split_out_body.inl"
         } else {
             constexpr bool R_BULLETS = false, R_MOVE = true, R_STAGE = false, R_GEOM = true, R_OUTCOME = true, R_RDV_MOVE = false, R_POSE_LDS = false;
             constexpr bool R_ST_STATE = true, R_ST_OUT = true;
-            constexpr int R_RDV_COUNTS = 2, R_GEOM_LDS = 0;
+            constexpr int R_RDV_COUNTS = 2, R_GEOM_LDS = 0, R_PUB = 0;
 #include "bsx_step_split_many_body.inl"
         }
     } else {
+    constexpr int R_PUB = 0;
     const int tk = 0;
     if (role_wave == 0) {
         constexpr bool FIRST = true;                     // this wave loads the shared records and hands them over

@@ -162,12 +162,15 @@ def test_per_call_two_wave_kernel_runs_the_drop_in_game_too():
     assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1:] == outs[1][1:]
 
 
-@pytest.mark.parametrize("E,enc,auto,inject", [(65536, "int", True, False), (3000, "scores", True, False), (33, "int", False, True), (131072, "int", True, False)])
+@pytest.mark.parametrize("E,enc,auto,inject", [(65536, "int", True, False), (3000, "scores", True, False), (33, "int", False, True), (131072, "int", True, False),
+                                               (32768, "int", True, False), (40000, "scores", False, True), (49152, "int", True, True)])
 def test_two_wave_multi_tick_kernel_equals_the_one_wave_multi_tick_kernel(E, enc, auto, inject):
     """The PRODUCT's multi-tick 1v1 launches of up to 65 536 games (bsx_step_many_discrete; csrc/bsx_step_split.h, MANY): a GAME wave (the
     whole state machine, up to a tick ahead) and an OUTPUTS wave (geometry, rewards, rows, flags) per 64 agents, against the one-wave
-    multi-tick kernel (BSX_F_ONE_WAVE): every tick's outputs, env_done per tick and the complete state identical.  (131 072 games take the
-    one-wave kernel either way: the case checks that the size switch changes nothing.)"""
+    multi-tick kernel (BSX_F_ONE_WAVE): every tick's outputs, env_done per tick and the complete state identical.  Up to 32 768 games the
+    outputs wave carries the state too and repeats classify, move and outcome (form 1); above, it takes 16 bytes per agent and tick from the
+    game wave and repeats nothing (form 2): both are here.  (131 072 games take the one-wave kernel either way: the case checks that the
+    size switch changes nothing.)"""
     kw = dict(n_agents=1, n_envs=E, seed=41, auto_reset=auto)
     a, b = _env(**kw), _env(one_wave=True, **kw)
     a.reset(); b.reset()
