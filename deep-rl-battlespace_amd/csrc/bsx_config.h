@@ -28,7 +28,7 @@ constexpr int X_ATAN_TABLE_MAX_K = 2;
 constexpr int X_OPAQUE_MULTI_MASK = 0x1C18;      // multi-tick kernels that recompute lane-derived addresses per tick (bsx_step_kernel.h)
 constexpr int X_PAD_SALU = 0, X_PAD_VALU = 0, X_DEPHASE_SLOT = 0;
 constexpr int X_PRIO_BY_SLOT = 0, X_PRIO_LATE = 0, X_PRIO_LATE_LEVEL = 1;
-// The two-wave 1v1 kernels (bsx_step_split.h).  Multi-tick launches of up to 65 536 games: a GAME wave + an OUTPUTS wave per 64 agents.
+// The two-wave 1v1 kernels (bsx_step_split.h).  Multi-tick launches of up to 65 536 games: a GAME wave + an OUTPUTS wave per 64 agents (two forms, by size).
 // Per-call launches of up to 114 688 games: form 4, a wave for everything but the observation geometry + a GEOMETRY wave fed with the
 // post-move poses.  In both the first wave -- whose chain sets the pace -- runs at s_setprio 1: without that the per-call forms lose to
 // the one-wave kernel.

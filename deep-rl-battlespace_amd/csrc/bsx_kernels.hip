@@ -285,8 +285,9 @@ inline bool narrow_offsets_ok(int64_t E, int n, uint32_t flags) {
 }
 // The two-wave 1v1 kernels (bsx_step_split.h); in both the first wave runs at s_setprio 1 (bsx_config.h).  BSX_F_ONE_WAVE keeps the one-wave kernel.
 // Multi-tick launches (bsx_step_many_discrete) of up to 65 536 games: a GAME wave and an OUTPUTS wave per 64 agents, four waves per SIMD at
-// 65 536 games -- 3.05 -> 2.58 us per tick there, 2.65 -> 1.81 at 32 768; beyond that the SIMDs are full of waves anyway and the one-wave
-// kernel's fewer instructions win (131 072 games: 4.45 against 5.2).
+// 65 536 games -- 3.05 -> 2.22 us per tick there (form 2: the outputs wave takes 16 bytes per agent and tick and repeats no game logic; launches
+// of more than 32 768 games), 2.65 -> 1.75 at 32 768 (form 1: it carries the state too); beyond 65 536 the SIMDs are full of waves anyway and the
+// one-wave kernel's fewer instructions win (81 920 games: 3.72 against 3.94).
 // Per-call launches (bsx_step_discrete, *_range) of up to 114 688 games: a wave for everything but the observation geometry and a GEOMETRY
 // wave that takes the post-move poses from it -- 6.08 -> 5.60 us per call at 65 536 games, 4.34 -> 3.99 at 4 096, 6.99 -> 6.33 at 81 920,
 // 8.11 -> 7.11 at 114 688 (131 072: 8.31 -> 8.85, so not there).  Continuous actions (bsx_step_continuous) take the same form up to 81 920

@@ -1,8 +1,8 @@
 // bsx_step_split.h -- bsx_step_split_kernel: the 1v1 step() as TWO co-operating wavefronts per 64 agents (round 5); namespace bsxk.
 // Part of the step() path of libbattlespace_hip.so (included after bsx_step_kernel.h; instantiated in bsx_step_two_wave.hip).  Two uses, both PRODUCT:
-//   * MANY = true: multi-tick launches (bsx_step_many_discrete) of up to 65 536 games -- 3.05 -> 2.54 us per tick at 65 536 games
-//     (51 G agent-steps/s), 2.65 -> 1.75 at 32 768;
-//   * MANY = false: one call per launch (bsx_step_discrete, *_range) of up to 114 688 games, form 4 below -- C2 6.08 -> 5.60 us; with
+//   * MANY = 1 / 2: multi-tick launches (bsx_step_many_discrete) of up to 65 536 games -- 3.05 -> 2.22 us per tick at 65 536 games
+//     (59 G agent-steps/s; form 2), 2.65 -> 1.75 at 32 768 (form 1);
+//   * MANY = 0: one call per launch (bsx_step_discrete, *_range) of up to 114 688 games, form 4 below -- C2 6.08 -> 5.60 us; with
 //     continuous actions (CONT; bsx_step_continuous, *_range) of up to 81 920 games -- 8.07 -> 7.67 us at 65 536 games.
 // In both the wave that carries the game's chain runs at s_setprio 1: a SIMD's arbiter serves its resident waves oldest-first, and
 // without the priority the chain's wave queues behind the wave that has slack -- the per-call forms then LOSE (6.31 / 6.70 us), the
@@ -18,9 +18,14 @@
 //                    (in registers), tick after tick; before each tick's outcome it leaves the bullets' counts in LDS (a buffer per tick parity)
 //   wave 1, OUTPUTS  classify -> move -> geometry -> [rendezvous: the counts] -> outcome -> stores (rows, rewards, flags; the state after the last tick)
 // Both waves carry the planes' and the game's records in registers and advance them by the same arithmetic on the same counts, so they
-// never exchange state; the outputs wave runs up to a tick behind, its geometry and stores beside the game wave's next shot.  (A form
-// in which the outputs wave repeats none of the game logic and takes a 16-byte publish per agent and tick instead was measured too:
-// +-1 % at 65 536 games, 7 % slower at 32 768 -- not kept; profiles/r05_experiments.json.)
+// never exchange state; the outputs wave runs up to a tick behind, its geometry and stores beside the game wave's next shot.  That is
+// form 1 (MANY = 1), for launches of up to 32 768 games: one workgroup per SIMD, a tick is a latency chain, and an outputs wave that works
+// beside the game wave from the start of the tick is what shortens it.
+// form 2 (MANY = 2), for launches of more than 32 768 games -- two workgroups on some SIMD, the vector port is the bound: the game wave owns
+// the state alone (and stores it after the last tick); per tick it PUBLISHES what the tick's outputs need (post-move position, heading,
+// flags, enemy base, reward: 16 bytes per agent, a buffer per tick parity) and the outputs wave (bsx_step_split_out_body.inl) does the
+// geometry, the row and the output stores from that, with none of the game logic: half the instructions in the wave that fills the
+// gaps.  65 536 games: 2.55 -> 2.21 us per tick; 32 768: 1.74 -> 1.96 (hence form 1 there).  Without the wave priority form 2 was neutral.
 //
 // The per-call forms.  A single call has no next tick to run ahead into; the split is by what the call's chain can shed.
 //   form 4 (PRODUCT): wave 0 everything but the observation geometry; after its move it leaves the post-move poses (own pose, enemy position,
@@ -45,13 +50,8 @@
 
 namespace bsxk {
 
-// MANY = false: one call per launch (forms 1 and 2 above).  MANY = true: T calls per launch (bsx_step_many_discrete) -- the form in which
-// specialisation can pay, because the waves are persistent (nothing to launch per tick) and ONE rendezvous per tick is enough:
-//   wave 0, GAME     the whole game state machine except the observations and the outputs: classify -> shot -> move -> pool pass -> resolve
-//                    -> outcome (in registers), tick after tick; before each tick's outcome it leaves the bullets' counts in LDS (by tick parity)
-//   wave 1, OUTPUTS  classify -> move -> geometry -> [rendezvous: the counts] -> outcome -> stores (rows, rewards, flags; state after the last tick)
-// Both waves carry the planes' and the game's records in registers and advance them by the same arithmetic on the same counts, so
-// they never exchange state; the outputs wave is up to a tick behind.
+// <LG, OFF32, MANY, CONT>: action encoding (score rows), 32-bit offsets, the launch form -- MANY = 0 one call per launch (per-call form 4;
+// forms 1 / 2 in variant builds), MANY = 1 / 2 the multi-tick forms -- and continuous actions (per call only); all described above.
 template <bool LG, bool OFF32, int MANY = 0, bool CONT_ = false>
 __global__ __launch_bounds__(2 * SPB)
 #ifdef BSX_X_SPLIT_WAVES                                 // variant builds: at most this many waves per SIMD, i.e. more registers for the scheduler to use
