@@ -814,7 +814,7 @@ def main():
                          "form_floor": ({"us": 4.9, "terms_us": {"kernel_boundary": 1.6, "first_loads": 1.06, "vector_port_2_waves": 1.9, "store_drain": 0.3},
                                          "frac": round(4.9 / (km * 1e3), 4), "source": "profiles/r05_issue_coissue.txt, r05_experiments.json, r05_d_pmc_summary.json",
                                          "note": "the vector-port term prices 1.22 M vector instructions per launch: the one-wave kernel's count, and within 1 % the two-wave kernel's that "
-                                                 "runs here (1.23 M: r05_g_pmc_summary.json; its geometry wave repeats nothing)"}
+                                                 "runs here (1.23 M: r05_k_pmc_summary.json; its geometry wave repeats nothing)"}
                                         if (n, E, args.mode, args.action_mix, args.continuous) == (1, 65536, "graph", "uniform", False) else None)},
             "games_finished": int(games[0]), "ties": int(games[1]), "red_wins": int(games[2]), "blue_wins": int(games[3]),
             "tie_tick": head_env_tie_tick,
