@@ -402,10 +402,10 @@ void bsx_step_kernel(const int64_t E_, const uint2* const envc_, const uint2* co
     //   bullets   Bullet.update for every work slot (pool entries + queued shots), pool compaction, ordered plane-hit resolve
     //   outcome   rewards, deaths, base hit points, win / tie
     //   stores    plane / game records, reward, done, observation row, counters, pool length
-    // R_*: which parts of the tick this wave runs -- here all of them.  The wave-specialised 1v1 kernel (bsx_step_split.h, a measured
-    // experiment: variant builds only) includes the same phase files once per wave with different parts switched on; the phases guard
-    // their side effects by these constants and the rest falls to dead-code elimination.  With every part on, every guard is a
-    // compile-time `true` (the ISA of all 76 kernels is unchanged by the guards).
+    // R_*: which parts of the tick this wave runs -- here all of them.  The two-wave 1v1 kernels (bsx_step_split.h: the product's kernels for
+    // discrete 1v1 launches up to 114 688 games per call / 65 536 per multi-tick launch, continuous up to 81 920 per call) include the same
+    // phase files once per wave with different parts switched on; the phases guard their side effects by these constants and the rest falls
+    // to dead-code elimination.  With every part on, every guard is a compile-time `true` (the ISA of all 76 kernels is unchanged by the guards).
     constexpr bool R_BULLETS = true, R_MOVE = true, R_STAGE = true, R_GEOM = true, R_OUTCOME = true, R_ST_STATE = true, R_ST_OUT = true, R_RDV_MOVE = false, R_POSE_LDS = false;
     constexpr int R_RDV_COUNTS = 0, R_GEOM_LDS = 0, R_PUB = 0;
     auto split_rendezvous = [] {};                       // (names of the split kernel's role code: never reached here)
