@@ -468,3 +468,24 @@ def test_phase_files_keep_their_read_write_contract(tmp_path):
     assert r.returncode == 1
     assert "bsx_step_phase_geometry.inl: @writes misses ['hp']" in r.stdout and "bsx_step_phase_geometry.inl: @lds misses ['s_fl']" in r.stdout
     assert "bsx_step_phase_outcome.inl: @exports misses ['alive']" in r.stdout, r.stdout
+
+
+def test_the_size_limits_of_the_two_wave_kernels_are_the_same_in_the_launcher_the_bench_and_the_profile_tool():
+    """csrc/bsx_kernels.hip decides by launch size which 1v1 kernel runs (two-wave per call up to 114 688 games, 81 920 with continuous
+    actions; two-wave multi-tick up to 65 536, its form 2 above 32 768).  bench.py and tools/collect_profile.py NAME the kernel a workload
+    runs -- for the live PMC passes and the roofline's kernel field -- from the same numbers: they must not drift apart."""
+    import re
+    csrc = os.path.join(ROOT, "deep-rl-battlespace_amd", "csrc")
+    k = open(os.path.join(csrc, "bsx_kernels.hip")).read()
+    c = open(os.path.join(csrc, "bsx_config.h")).read()
+    lim = {name: int(re.search(r"#define %s (\d+)" % name, k).group(1)) for name in ("BSX_X_SPLIT_MAX", "BSX_X_SPLIT_CONT_MAX", "BSX_X_SPLIT_MANY_MAX")}
+    form2_from = int(re.search(r"X_SPLIT_MANY_FORM2_FROM = (\d+);", c).group(1))
+    assert lim == {"BSX_X_SPLIT_MAX": 114688, "BSX_X_SPLIT_CONT_MAX": 81920, "BSX_X_SPLIT_MANY_MAX": 65536} and form2_from == 32768
+    b = open(os.path.join(ROOT, "bench.py")).read()
+    t = open(os.path.join(ROOT, "tools", "collect_profile.py")).read()
+    want = "E <= (%d if many else (%d if %s else %d))" % (lim["BSX_X_SPLIT_MANY_MAX"], lim["BSX_X_SPLIT_CONT_MAX"], "%s", lim["BSX_X_SPLIT_MAX"])
+    assert want % "continuous" in b, want
+    assert want % "cont" in t, want
+    assert "(2 if E > %d else 1) if many else 0" % form2_from in b and "(2 if E > %d else 1) if many else 0" % form2_from in t
+    h = open(os.path.join(ROOT, "include", "battlespace_hip.h")).read()
+    assert "114 688" in h and "81 920" in h and "65 536" in h                     # (BSX_F_ONE_WAVE's description names the three limits)
