@@ -216,11 +216,14 @@ def hashed_bits(T, lo, hi, A, k, seed, device):
     return (x >> 20) & 0x7FFFFFFF
 
 
-def live_traffic(args, kernel, grid_threads):
+def live_traffic(args, kernel, grid_threads, dense_file=None):
     """HBM bytes per launch of the headline kernel, measured NOW: two child runs of this script under `rocprofv3 --kernel-trace
     --pmc <counter>` -- FETCH_SIZE and WRITE_SIZE in SEPARATE passes, nothing else traced, as MI355X_MICROARCH.md's HBM section
     prescribes -- on the same workload (eager launches, so every launch is its own dispatch record), per-launch mean over the
-    second half of the run.  Units are KiB; on gfx950 FETCH_SIZE counts half of a wide coalesced read stream, so the read side is
+    second half of the run.  The profiled child issues the step launches and next to nothing else: counters are collected for kernels
+    matching `bsx_step` only, and the bullet-heavy workload replays the trajectory THIS (unprofiled) process recorded (`dense_file`) instead
+    of preparing it under the profiler (~21 000 small dispatches and a 300-node graph replay under per-dispatch counter collection: the one
+    kind of pass that ever hung, profiles/r06_traced_runs.json).  Units are KiB; on gfx950 FETCH_SIZE counts half of a wide coalesced read stream, so the read side is
     doubled (calibrated on this kernel in round 1, profiles/r01_traffic_calibration.json).  Returns (bytes, detail) or (None, why)."""
     import csv
     import glob
@@ -236,12 +239,17 @@ def live_traffic(args, kernel, grid_threads):
     got = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="bsx_pmc_", dir="/tmp")
-        cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
-               "--steps", "100" if many else "200", "--warmup", "20", "--repeats", "1", "--ramp-ms", "0", "--mode", "many" if many else
-               ("graph" if args.action_mix == "dense" else "eager"), "--envs-per-gpu", str(args.envs_per_gpu), "--n-agents", str(args.n_agents),
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--kernel-include-regex", "bsx_step", "--output-format", "csv", "-d", d, "--",
+               sys.executable, os.path.abspath(__file__),
+               "--steps", "100" if many else "200", "--warmup", "20", "--repeats", "1", "--ramp-ms", "0", "--mode", "many" if many else "eager",
+               "--envs-per-gpu", str(args.envs_per_gpu), "--n-agents", str(args.n_agents),
                "--action-mix", args.action_mix, "--no-cpu-baseline", "--no-other-workloads", "--no-live-traffic"]
         if args.continuous:
             cmd.append("--continuous")
+        if args.action_mix == "dense":
+            if not dense_file:
+                return None, "bullet-heavy workload: no recorded trajectory to replay under the profiler (see --dense-record)"
+            cmd += ["--dense-replay", dense_file]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=120)
             files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
@@ -310,6 +318,13 @@ def parse_args(argv=None):
     ap.add_argument("--chains", type=int, default=1,
                     help="graph mode: the batch as this many game ranges, each its own chain of launches on a branch of the graph "
                          "(capture_steps(chains=)); 1 = one launch per step over the whole batch (the headline)")
+    ap.add_argument("--dense-record", default=None, metavar="FILE",
+                    help="--action-mix dense: write the recorded trajectory (state snapshot + the K calls' actions) to FILE after the closed-loop "
+                         "preparation, for a later --dense-replay")
+    ap.add_argument("--dense-replay", default=None, metavar="FILE",
+                    help="--action-mix dense: load the trajectory a --dense-record run wrote instead of preparing it -- the form every run under "
+                         "rocprofv3 --pmc takes (live_traffic, tools/profile_round.sh): the profiled process then issues the step launches and "
+                         "nothing else (profiles/r06_traced_runs.json: why)")
     ap.add_argument("--one-wave", action="store_true", help="A/B: keep the one-wave 1v1 kernels (BSX_F_ONE_WAVE) where the library would take a two-wave form; same results")
     ap.add_argument("--no-stagger", action="store_true", help="leave all games on the same clock (time-limit ties in lock-step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -526,24 +541,39 @@ def main():
         G = max(1, min(graph_len, K))                       # steps per graph replay; a remainder runs as plain calls
         lo = env.env_offset
         restore, live = None, None
+        pos = [0]                                           # which G-tick slice of the table comes next
         if mix == "dense":
-            if continuous or mode != "graph":
-                raise SystemExit("--action-mix dense is a recorded discrete trajectory replayed as one HIP graph")
-            # pre-roll to the steady state of the closed-loop play, snapshot, record the next K calls' actions, rewind
-            stagger(env, lambda k: env.step_batch(dense_policy(env)))
-            for _ in range(60):
-                env.step_batch(dense_policy(env))
-            snap = env.state_dict()
+            if continuous or mode == "many":
+                raise SystemExit("--action-mix dense is a recorded discrete trajectory replayed call by call (as one HIP graph, or eagerly)")
             G = K
-            actions = torch.empty((K, E, A), dtype=torch.int32, device=dev)
-            lv = []
-            for t in range(K):
-                actions[t] = dense_policy(env)
-                env.step_batch(actions[t])
-                if t % 10 == 0:
-                    lv.append(float(env.export_state(("bl_live",))["bl_live"].float().sum()) / (E * A))
-            live = round(sum(lv) / len(lv), 3)
-            restore = lambda: env.load_state_dict(snap)     # noqa: E731
+            if args.dense_replay:
+                # the trajectory an earlier, UNPROFILED run recorded (--dense-record): nothing of the closed-loop preparation -- ~480 ticks of
+                # dense_policy, ~21 000 small dispatches -- is issued by this process
+                rec = torch.load(args.dense_replay, map_location=dev)
+                if rec["actions"].shape[0] < K or tuple(rec["actions"].shape[1:]) != (E, A) or rec["meta"] != [world, rank, n]:
+                    raise SystemExit(f"--dense-replay: {args.dense_replay} holds {tuple(rec['actions'].shape)} for (world, rank, n) = {rec['meta']}, "
+                                     f"this run needs {(K, E, A)} for {[world, rank, n]}")
+                snap, actions, live = rec["snap"], rec["actions"][:K].contiguous(), rec["live"]   # (a shorter run replays the recording's first K calls)
+            else:
+                # pre-roll to the steady state of the closed-loop play, snapshot, record the next K calls' actions, rewind
+                stagger(env, lambda k: env.step_batch(dense_policy(env)))
+                for _ in range(60):
+                    env.step_batch(dense_policy(env))
+                snap = env.state_dict()
+                actions = torch.empty((K, E, A), dtype=torch.int32, device=dev)
+                lv = []
+                for t in range(K):
+                    actions[t] = dense_policy(env)
+                    env.step_batch(actions[t])
+                    if t % 10 == 0:
+                        lv.append(float(env.export_state(("bl_live",))["bl_live"].float().sum()) / (E * A))
+                live = round(sum(lv) / len(lv), 3)
+                if args.dense_record:
+                    torch.save({"snap": snap, "actions": actions, "live": live, "meta": [world, rank, n]}, args.dense_record)
+
+            def restore():
+                env.load_state_dict(snap)
+                pos[0] = 0
             restore()
         # The action table always spans TT >= graph_len ticks (a multiple of G), whatever K is: a short block (the driver's
         # --steps 20) walks through it slice by slice, so the games see the same 100-tick action cycle as in a long run
@@ -560,7 +590,6 @@ def main():
         if mix != "dense" and do_stagger and not args.no_stagger:
             stagger(env, lambda k: env.step_batch(actions[k % TT]))
         run_b, Kb = None, None
-        pos = [0]                                           # which G-tick slice of the table comes next
         if mode == "graph":
             graphs = [env.capture_steps(actions[i * G:(i + 1) * G], chains=chains)[0] for i in range(NG)]
             graph = graphs[0]
@@ -600,7 +629,7 @@ def main():
             run(W)
             ramp(run, args.ramp_ms, K)
         else:
-            ramp(lambda k: (restore(), graph.replay()), args.ramp_ms, K)
+            ramp(lambda k: (restore(), run(k)), args.ramp_ms, K)
         if R is None:                                       # no --repeats: 5 blocks, 25 when a block is shorter than 2 ms (decided by all ranks together)
             R = 5
             if not restore:
@@ -668,6 +697,14 @@ def main():
     K, W = args.steps, args.warmup
     if args.chains != 1 and args.mode != "graph":
         raise SystemExit("--chains is a property of the captured graph (--mode graph)")
+    dense_tmp = None
+    if (args.action_mix == "dense" and world == 1 and not args.no_live_traffic and args.chains == 1 and not args.dense_replay
+            and not args.dense_record and K >= 200):
+        # the counter passes below replay this run's trajectory (live_traffic): recorded here, where no profiler is attached
+        import tempfile
+        fd, dense_tmp = tempfile.mkstemp(prefix="bsx_dense_", suffix=".pt", dir="/tmp")
+        os.close(fd)
+        args.dense_record = dense_tmp
     head = measure(n, E, K, W, args.mode, args.graph_len, mix=args.action_mix, continuous=args.continuous, chains=args.chains, tag="head_")
     env = head["env"]
     games = sharding.reduce_counters(sharding.local_counter_sums(env).to(red_dev), group=tgroup)   # logging only, after the timed region
@@ -764,7 +801,10 @@ def main():
             while Gw < A:
                 Gw *= 2
             grid_threads = ((E + 64 // Gw - 1) // (64 // Gw)) * 64 * (2 if two_wave(n, args.continuous, many, E) else 1)
-            live_b, info = live_traffic(args, kernel_name(n, args.continuous, many, E), grid_threads)
+            live_b, info = live_traffic(args, kernel_name(n, args.continuous, many, E), grid_threads,
+                                        dense_file=args.dense_replay or args.dense_record)
+            if dense_tmp:
+                os.remove(dense_tmp)
             if live_b is not None:
                 traffic, tdetail = live_b, info
                 tsrc = "this run: 2 rocprofv3 --pmc child passes, 2 x FETCH_SIZE + WRITE_SIZE (KiB)"

@@ -68,6 +68,94 @@ def test_C3_65536x4v4_bit_exact_vs_c_oracle():
     _compare_with_c_oracle(65536, 4, 200, seed=99, p_shoot=0.25, check_every=100)
 
 
+def _compare_many_with_c_oracle(E, chunks, seed, p_shoot, inject, one_wave=False, scores=False):
+    """bsx_step_many_discrete against the C oracle: each chunk of T ticks is ONE launch (store=True: every tick's rows, rewards, flags and
+    env_done kept), the oracle walks the same action table a call at a time; every tick's outputs and the state after every launch."""
+    env = _env(n_agents=1, n_envs=E, seed=seed, auto_reset=True, one_wave=one_wave)
+    c = cref.CRefBatch(E, n_agents=1, seed=seed, auto_reset=True)
+    env.reset(); c.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(seed + 5)
+    n_exact = n_vals = 0
+    for k, T in enumerate(chunks):
+        acts = _actions(T, E, 2, seed + 10 + k, p_shoot)
+        if k == 0:
+            acts[T // 2, : E // 3] = 7                          # out-of-range indices: the plane does not move (battle_env.py:399-417)
+        u = torch.rand((T, E, 2), generator=g, device="cuda", dtype=torch.float64) if inject else None
+        arg = acts
+        if scores:                                              # [T, E, A, 4] score rows arg-maxed in-kernel (battle_env.py:327-328)
+            arg = torch.rand((T, E, 2, 4), generator=g, device="cuda") * 0.5
+            arg.scatter_(3, acts.clamp(0, 3).long().unsqueeze(-1), 1.0)
+            acts = acts.clamp(0, 3)
+        ed = torch.zeros((T, E), dtype=torch.uint8, device="cuda")
+        mo, mr, md = env.step_many(arg, store=True, u=u, env_done_out=ed)
+        mo, mr, md, ed = mo.cpu().numpy(), mr.cpu().numpy(), md.cpu().numpy(), ed.cpu().numpy()
+        acts_h = acts.cpu().numpy()
+        u_h = u.cpu().numpy() if inject else None
+        for t in range(T):
+            co, cr, cd = c.step(acts_h[t], u=u_h[t] if inject else None)
+            assert np.array_equal(md[t], cd), f"launch {k} tick {t}: done"
+            assert np.array_equal(mr[t].astype(np.float64), cr), f"launch {k} tick {t}: rew"
+            assert np.array_equal(ed[t], c.env_done), f"launch {k} tick {t}: env_done"
+            np.testing.assert_allclose(mo[t], co, rtol=OBS_RTOL, atol=OBS_ATOL, err_msg=f"launch {k} tick {t}: obs")
+            n_exact += int((mo[t] == co).sum()); n_vals += co.size
+        _same_state_as_c_oracle(env, c, f"launch {k}")
+    assert n_exact >= n_vals * (1 - 1e-3), f"only {n_exact}/{n_vals} observation values bit-identical"
+    assert int(env.counters()[:, 0].sum()) >= E                 # the launches crossed the 121-call tie and the re-spawns
+    return env
+
+
+def _same_state_as_c_oracle(env, c, where):
+    sh = {k: v.cpu().numpy() for k, v in env.export_state().items()}
+    sc = c.export_state()
+    for f in ("px", "py", "pdir", "php", "palive", "base_xy", "bhp", "tick", "env_done", "winner", "bl_live", "counters"):
+        assert np.array_equal(sh[f], sc[f]), f"{where}: {f}"
+    m = sc["bl_live"].astype(bool)
+    for f in ("bl_x", "bl_y", "bl_dir"):
+        assert np.array_equal(sh[f][m], sc[f][m]), f"{where}: {f}"
+
+
+# The launcher picks a 1v1 kernel BY SIZE (csrc/bsx_kernels.hip, split_applies / launch_for_n): each of them restates
+# envs/battle_env.py:281-381, so each is run against the C oracle here, at the sizes where the launcher takes it.
+@pytest.mark.parametrize("E,inject,scores,kernel", [
+    (65536, False, False, "two-wave multi-tick kernel whose outputs wave takes what the game wave publishes (32 768 < games <= 65 536)"),
+    (65536, True, False, "the same with the shots' random() values injected"),
+    (49152, True, True, "the same, score rows, a size that is not a power of two"),
+    (32768, False, False, "two-wave multi-tick kernel whose outputs wave carries the state too (games <= 32 768), at its largest size"),
+    (81920, False, False, "one-wave multi-tick kernel (games > 65 536)"),
+    (81920, True, True, "the same, score rows and injected random() values"),
+], ids=["65536-form2", "65536-form2-injected", "49152-form2-scores-injected", "32768-form1", "81920-one-wave", "81920-one-wave-scores-injected"])
+def test_every_multi_tick_1v1_kernel_the_launcher_selects_vs_c_oracle(E, inject, scores, kernel):
+    """step_many at 1v1: two launches of 130 ticks (across the 121-call tie, the re-spawns and the second game's first shots), shots every
+    other call so that pools fill and planes die; per tick obs / rew / done / env_done, after each launch the whole state."""
+    _compare_many_with_c_oracle(E, (130, 130), seed=700 + E % 1000 + int(inject), p_shoot=0.5, inject=inject, scores=scores)
+
+
+@pytest.mark.parametrize("E,kernel", [
+    (114688, "two-wave per-call kernel at the last size it takes"),
+    (131072, "one-wave per-call kernel (games > 114 688): the kernel of the 262 144- and 1 M-game bench rows"),
+], ids=["114688-two-wave", "131072-one-wave"])
+def test_every_per_call_1v1_kernel_the_launcher_selects_vs_c_oracle(E, kernel):
+    """step() per launch at 1v1 on either side of the size switch: 130 calls, across the tie and the re-spawns."""
+    _compare_with_c_oracle(E, 1, 130, seed=811 + E % 1000, p_shoot=0.4, check_every=65)
+
+
+def test_continuous_two_wave_kernel_at_its_last_size_and_the_one_wave_kernel_above_it_vs_c_oracle():
+    """Continuous actions take the two-wave per-call form up to 81 920 games, the one-wave kernel above: both sizes against the C oracle."""
+    _compare_generic(81920, 1, 125, seed=902, cont=True, f32=True)
+    _compare_generic(98304, 1, 125, seed=903, cont=True, f32=False)
+
+
+@pytest.mark.parametrize("cont", [False, True])
+def test_one_wave_1v1_kernels_kept_by_flag_vs_c_oracle(cont):
+    """BSX_F_ONE_WAVE (`one_wave=True`): the one-wave 1v1 kernels at a size where the launcher would take the two-wave forms -- per call
+    (discrete / continuous) and as a multi-tick launch -- against the C oracle, not only against the two-wave kernels."""
+    if cont:
+        _compare_generic(8192, 1, 130, seed=31, cont=True, f32=True, one_wave=True)
+    else:
+        _compare_generic(8192, 1, 130, seed=32, one_wave=True)
+        _compare_many_with_c_oracle(8192, (130, 40), seed=33, p_shoot=0.5, inject=False, one_wave=True)
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 6])
 def test_shoot_heavy_play_bit_exact_vs_c_oracle(n):
     """Every ring slot in use, same-step multi-hits and kill chains, wins by base kill; incl. the generic-n kernel (6)."""
@@ -334,11 +422,11 @@ def test_step_many_equals_consecutive_step_calls(E, n, mode):
     assert b.tie_tick > 227 or int(b.counters()[:, 0].sum()) > 0     # the 227 ticks crossed game ends (n = 16 ties on call 421 only)
 
 
-def _compare_generic(E, n, T, seed, cont=False, logits=False, f32=False):
+def _compare_generic(E, n, T, seed, cont=False, logits=False, f32=False, one_wave=False):
     """HIP vs C oracle in the production configuration for any action encoding; ragged sizes (E not a multiple of the
     games-per-wave count) exercise the clamped-index lanes and the partial last wavefront."""
     A = 2 * n
-    env = _env(n_agents=n, n_envs=E, seed=seed, auto_reset=True, continuous_actions=cont)
+    env = _env(n_agents=n, n_envs=E, seed=seed, auto_reset=True, continuous_actions=cont, one_wave=one_wave)
     c = cref.CRefBatch(E, n_agents=n, seed=seed, auto_reset=True, continuous_actions=cont)
     env.reset(); c.reset()
     g = torch.Generator(device="cuda"); g.manual_seed(seed)

@@ -49,10 +49,12 @@ for name, extra in VARIANTS.items():
         by_kernel = collections.defaultdict(list)
         for row in csv.DictReader(open(files[0])):
             kn = row["Kernel_Name"]
-            if row["Counter_Name"] == ctr and ("bsx_step_kernel" in kn or "bsx_actor" in kn):
+            if row["Counter_Name"] == ctr and ("bsx_step_" in kn or "bsx_actor" in kn):    # bsx_step_kernel<...> and the two-wave bsx_step_split_kernel<...>
                 by_kernel[kn.split("(")[0]].append(float(row["Counter_Value"]))
         per[ctr] = {k: (sum(v[len(v) // 2:]) / len(v[len(v) // 2:]), len(v)) for k, v in by_kernel.items() if len(v) >= 8}   # (reset-time launches etc. dropped)
         shutil.rmtree(d, ignore_errors=True)
+    if "error" not in per and not any("bsx_step_" in k for k in per["FETCH_SIZE"]):
+        per = {"error": f"no step kernel among the counted kernels of '{name}': {sorted(per['FETCH_SIZE'])}"}    # (a renamed kernel must not silently drop its bytes)
     if "error" in per:
         res[name] = per
         continue
