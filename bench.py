@@ -666,6 +666,18 @@ def main():
         return (f"bsx_step_kernel<{n if n <= 4 else 0},{'true' if continuous else 'false'},{'true' if many else 'false'},false,false,"
                 f"{'true' if narrow else 'false'}>")       # <N, CONT, MULTI, ACTOR, LG, OFF32>
 
+    def form_floor(kernel, km):
+        try:
+            ff = json.load(open(os.path.join(ROOT, "profiles", "form_floor.json")))
+        except Exception:
+            return None
+        w = ff["workload"]
+        here = {"n_agents_per_team": n, "envs_per_gpu": E, "mode": args.mode, "action_mix": args.action_mix, "continuous": bool(args.continuous)}
+        if ff["kernel"] != kernel or w != here or args.chains != 1:
+            return None                                     # another kernel or workload: nothing re-derives the floor for it
+        return {"us": ff["us"], "terms_us": ff["terms_us"], "frac": round(ff["us"] / (km * 1e3), 4), "derived_for_kernel": ff["kernel"],
+                "series": ff["series"], "source": ff["source"], "note": ff["note"]}
+
     def traffic_entry(key):
         try:
             return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
@@ -776,7 +788,12 @@ def main():
             m = measure(n2, E2, K2, 50, "graph", 100, continuous=cont2, R=3, chains=P2)
             km2, wall2 = statistics.median(m["kms"]), statistics.median(m["walls"])
             chained[tag] = {"chains": P2, "us_per_step": round(km2 * 1e3, 3), "agent_steps_per_s": round(E2 * 2 * n2 * K2 / wall2, 1),
-                            "steps": K2, "repeats": len(m["kms"])}
+                            "steps": K2, "repeats": len(m["kms"]),
+                            "is_capture_steps_default": len(sharding.chain_ranges(E2, n2, "auto")) == P2}
+            te2 = traffic_entry(f"E{E2}_n{n2}" + ("_cont" if cont2 else ""))
+            if te2:                                         # the chains run the same kernels over the same games: a step moves the bytes of the one-launch form
+                chained[tag]["frac_claimed"] = round(te2["hbm_bytes_per_launch"] / (km2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                chained[tag]["frac_note"] = f"HBM bytes per step of the one-launch form (profiles/traffic.json[E{E2}_n{n2}{'_cont' if cont2 else ''}]) / this form's time per step"
             del m
             torch.cuda.empty_cache()
         rollouts = rollout_lines(dev, E, min(K, 320))
@@ -847,15 +864,13 @@ def main():
                          "io_only_bytes_per_agent_step": b_io(n, args.continuous),
                          "io_only_frac": round(b_io(n, args.continuous) * E * A / (km * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                          "live_bullets_per_agent": head["live"], "shots_per_agent_step": round(shots, 3),
-                         "regime": "2 waves per SIMD, 48 MB working set inside the 256 MB Infinity Cache" if (n, E) == (1, 65536) and not many else None,
-                         # what bounds THIS launch form at this size (every term from a micro-benchmark or a counter of
-                         # round 5, none from the step's own time): not bytes -- a kernel boundary, the first loads behind it, the vector-port
-                         # time of a SIMD's two waves, the store drain.  floor / measured says how close the kernel stands to it.
-                         "form_floor": ({"us": 4.9, "terms_us": {"kernel_boundary": 1.6, "first_loads": 1.06, "vector_port_2_waves": 1.9, "store_drain": 0.3},
-                                         "frac": round(4.9 / (km * 1e3), 4), "source": "profiles/r05_issue_coissue.txt, r05_experiments.json, r05_d_pmc_summary.json",
-                                         "note": "the vector-port term prices 1.22 M vector instructions per launch: the one-wave kernel's count, and within 1 % the two-wave kernel's that "
-                                                 "runs here (1.23 M: r05_k_pmc_summary.json; its geometry wave repeats nothing)"}
-                                        if (n, E, args.mode, args.action_mix, args.continuous) == (1, 65536, "graph", "uniform", False) else None)},
+                         "regime": ("4 waves per SIMD (two workgroups of the two-wave kernel: a chain wave at priority 1 + a geometry wave each), "
+                                    "48 MB working set inside the 256 MB Infinity Cache") if (n, E) == (1, 65536) and not many and two_wave(n, args.continuous, many, E)
+                         else ("2 waves per SIMD, 48 MB working set inside the 256 MB Infinity Cache" if (n, E) == (1, 65536) and not many else None),
+                         # what bounds THIS launch form at this size: not bytes -- a kernel boundary, the first loads behind it,
+                         # the vector-port time of a SIMD's waves, the store drain.  Constants of round 5 (profiles/form_floor.json), printed only
+                         # while the kernel that runs is the one they were derived for; floor / measured says how close the kernel stands to it.
+                         "form_floor": form_floor(kernel_name(n, args.continuous, many, E), km)},
             "games_finished": int(games[0]), "ties": int(games[1]), "red_wins": int(games[2]), "blue_wins": int(games[3]),
             "tie_tick": head_env_tie_tick,
         }
@@ -867,6 +882,11 @@ def main():
             out.update(multi_rank_fields(per_rank, world, E, A, K, out["value"], args.backend))
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
+        elif world > 1:
+            out["cpu_baseline"] = None
+            out["cpu_baseline_note"] = ("measured on rank 0 at N = 1 only (bench contract): the N = 1 line of the same tree carries it; "
+                                        "at N > 1 every rank is pinned to its card's cores and none is free to time the CPU port")
+            out["roofline"]["traffic_source"] = (tsrc or "none") + " [N > 1: no counter passes -- a rank's launches are the N = 1 shard's, kernel and games; the N = 1 line measures them live]"
         out["other_workloads"] = others
         out["chained_graphs"] = chained
         out["multi_tick_launch"] = multi
@@ -972,6 +992,11 @@ def baseline_summary(out, n, E, world, km, frac_claimed):
             if isinstance(ev.get(k_in), (int, float)):
                 l[k_out] = round(ev[k_in], 4)
         return l
+    def c3_default():
+        l = line(by(ch, "4v4, 3 chains"), "us_per_step")
+        if l is not None:
+            l["form"] = "3 chains of per-step launches in one graph (capture_steps default, chains='auto'); C3_one_launch: one launch per step"
+        return l
     head = {"agent_steps_per_s": round(out["value"]), "us": round(km * 1e3, 3), "frac_claimed": frac_claimed and round(frac_claimed, 3)}
     ow, ro, ch = out.get("other_workloads") or {}, pick(out, "policy_rollouts", "variants") or {}, out.get("chained_graphs") or {}
     cb = out.get("cpu_baseline") or {}
@@ -980,8 +1005,9 @@ def baseline_summary(out, n, E, world, km, frac_claimed):
     s = {"C1_cpu_port_1core": cb.get("value"), "C1_cpu_port_4v4_1core": pick(cb, "port_4v4", "value"),
          "C1_gpu_dropin_1game": pick(out, "drop_in_one_game", "agent_steps_per_s"),
          "C2": head if (n, E, world) == (1, 65536, 1) else None,
-         "C3": head if (n, E, world) == (4, 65536, 1) else line(by(ow, "configs[2]")),
-         "C3_3chains": line(by(ch, "4v4, 3 chains"), "us_per_step"),
+         # configs[2] in the form capture_steps() takes by default there (chains="auto": 3 chains at 4v4) and as ONE launch per step
+         "C3": c3_default(),
+         "C3_one_launch": head if (n, E, world) == (4, 65536, 1) else line(by(ow, "configs[2]")),
          "C4": head if (n, E, world) == (1, 65536, 8) else None,
          "C5_graph": line(by(ro, "graph of 2 kernels per tick, both"), "us_per_tick"),
          "C5_one_launch": line(by(ro, "one launch for all ticks, both"), "us_per_tick"),

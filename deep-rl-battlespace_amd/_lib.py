@@ -53,6 +53,7 @@ SIGNATURES = {
     "bsx_build_flags": (c_int, []),
     "bsx_state_bytes": (c_int, [c_int64, c_int, ctypes.POINTER(c_size_t)]),
     "bsx_state_init": (c_int, [c_void_p, c_int64, c_int, c_void_p]),
+    "bsx_state_release": (c_int, [c_void_p]),
     "bsx_reset": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_uint64, c_uint64, c_int64, c_void_p, c_void_p]),
     "bsx_step_discrete": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, ctypes.POINTER(BsxRewards), c_uint32, c_uint64, c_int64, c_void_p]),

@@ -57,7 +57,7 @@ __device__ inline void atan2_pixels_n(const int (&iy)[K], const int (&ix)[K], do
     BSX_EACH r[k] = __builtin_fma(-u[k], q[k], v[k]);
     BSX_EACH q[k] = __builtin_fma(r[k], y[k], q[k]);
     BSX_EACH t[k] = q[k] * q[k];
-    constexpr bool TABLE = K <= X_ATAN_TABLE_MAX_K;      // measured: 1v1 (K = 2) 7.40 -> 7.34 us; 4v4 (K = 3) 24.0 -> 24.4, so literals there
+    constexpr bool TABLE = K <= ATAN_TABLE_MAX_K;      // measured: 1v1 (K = 2) 7.40 -> 7.34 us; 4v4 (K = 3) 24.0 -> 24.4, so literals there
     if constexpr (TABLE) {
         // The 20 coefficients come from constant memory: three scalar loads (8 + 8 + 4 doubles) instead of forty s_mov.  With two
         // waves per SIMD the step is bound by the SIMD's issue port -- one instruction of ANY class per ~4 cycles

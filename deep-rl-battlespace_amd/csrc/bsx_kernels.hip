@@ -46,9 +46,7 @@
 #include "bsx_step_split.h"                              // the two-wave 1v1 kernels
 #define BSX_INST_SPLIT_MANY
 #define BSX_INST_SPLIT
-#if !defined(BSX_VARIANT) || BSX_X_SPLIT == 4
 #define BSX_INST_SPLIT_CONT
-#endif
 #ifdef BSX_VARIANT
 #define BSX_INST_KW
 #else
@@ -283,7 +281,7 @@ void launch_for_n_w(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs&
 inline bool narrow_offsets_ok(int64_t E, int n, uint32_t flags) {
     return !(flags & BSX_F_WIDE_OFFSETS) && uint64_t(E) * uint64_t(2 * n) * 200ull <= 0xFFFFFFFFull;
 }
-// The two-wave 1v1 kernels (bsx_step_split.h); in both the first wave runs at s_setprio 1 (bsx_config.h).  BSX_F_ONE_WAVE keeps the one-wave kernel.
+// The two-wave 1v1 kernels (bsx_step_split.h); in both the first wave runs at s_setprio 1.  BSX_F_ONE_WAVE keeps the one-wave kernel.
 // Multi-tick launches (bsx_step_many_discrete) of up to 65 536 games: a GAME wave and an OUTPUTS wave per 64 agents, four waves per SIMD at
 // 65 536 games -- 3.05 -> 2.22 us per tick there (form 2: the outputs wave takes 16 bytes per agent and tick and repeats no game logic; launches
 // of more than 32 768 games), 2.65 -> 1.75 at 32 768 (form 1: it carries the state too); beyond 65 536 the SIMDs are full of waves anyway and the
@@ -292,21 +290,13 @@ inline bool narrow_offsets_ok(int64_t E, int n, uint32_t flags) {
 // wave that takes the post-move poses from it -- 6.08 -> 5.60 us per call at 65 536 games, 4.34 -> 3.99 at 4 096, 6.99 -> 6.33 at 81 920,
 // 8.11 -> 7.11 at 114 688 (131 072: 8.31 -> 8.85, so not there).  Continuous actions (bsx_step_continuous) take the same form up to 81 920
 // games (84 ... 88 registers: six waves per SIMD at most): 8.07 -> 7.67 us at 65 536 games, 6.26 -> 5.85 at 16 384, 9.49 -> 8.74 at 81 920 (98 304: 9.92 -> 11.95).
-#ifndef BSX_X_SPLIT_MANY_MAX
-#define BSX_X_SPLIT_MANY_MAX 65536
-#endif
-#ifndef BSX_X_SPLIT_MAX
-#define BSX_X_SPLIT_MAX 114688
-#endif
-#ifndef BSX_X_SPLIT_CONT_MAX
-#define BSX_X_SPLIT_CONT_MAX 81920
-#endif
-constexpr int64_t SPLIT_MAX_GAMES = BSX_X_SPLIT_MAX, SPLIT_MANY_MAX_GAMES = BSX_X_SPLIT_MANY_MAX, SPLIT_CONT_MAX_GAMES = BSX_X_SPLIT_CONT_MAX;
+constexpr int64_t SPLIT_MAX_GAMES = 114688, SPLIT_MANY_MAX_GAMES = 65536, SPLIT_CONT_MAX_GAMES = 81920;
+constexpr int64_t SPLIT_MANY_FORM2_FROM = 32768;           // multi-tick launches of MORE games than this (two workgroups on some SIMD): the outputs wave that repeats no game logic
 template <bool CONT, bool MULTI>
 inline bool split_applies(int n, const StepArgs& a, int64_t bound) {
     if (n != 1 || (a.flags & BSX_F_ONE_WAVE)) return false;
-    if (CONT) return !MULTI && X_SPLIT_FORM == 4 && bound <= SPLIT_CONT_MAX_GAMES;   // (continuous actions: the per-call form 4 only)
-    return MULTI ? (X_SPLIT_MANY && bound <= SPLIT_MANY_MAX_GAMES) : (X_SPLIT_FORM != 0 && bound <= SPLIT_MAX_GAMES);
+    if (CONT) return !MULTI && bound <= SPLIT_CONT_MAX_GAMES;   // (continuous actions: the per-call form only)
+    return bound <= (MULTI ? SPLIT_MANY_MAX_GAMES : SPLIT_MAX_GAMES);
 }
 template <bool LG, bool OFF32, int MANY, bool CONT = false>
 void launch_split(dim3 grid, hipStream_t s, const StepArgs& a, int64_t bound) {
@@ -319,14 +309,14 @@ void launch_for_n(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs& a
             const bool narrow = narrow_offsets_ok(a.E, n, a.flags);
             if constexpr (!MULTI) {
                 if (narrow) launch_split<LG, true, 0>(grid, s, a, bound); else launch_split<LG, false, 0>(grid, s, a, bound);
-            } else if (bound > X_SPLIT_MANY_FORM2_FROM) {    // two workgroups on some SIMD: the outputs wave that repeats no game logic (form 2)
+            } else if (bound > SPLIT_MANY_FORM2_FROM) {    // two workgroups on some SIMD: the outputs wave that repeats no game logic (form 2)
                 if (narrow) launch_split<LG, true, 2>(grid, s, a, bound); else launch_split<LG, false, 2>(grid, s, a, bound);
             } else {                                         // one workgroup per SIMD at most: the outputs wave that carries the state too (form 1)
                 if (narrow) launch_split<LG, true, 1>(grid, s, a, bound); else launch_split<LG, false, 1>(grid, s, a, bound);
             }
             return;
         }
-    } else if constexpr (!MULTI && X_SPLIT_FORM == 4) {
+    } else if constexpr (!MULTI) {
         if (split_applies<CONT, MULTI>(n, a, bound)) {
             if (narrow_offsets_ok(a.E, n, a.flags)) launch_split<false, true, 0, true>(grid, s, a, bound);
             else launch_split<false, false, 0, true>(grid, s, a, bound);
@@ -453,6 +443,12 @@ int bsx_state_init(void* state, int64_t E, int n, void* stream) {
     hipLaunchKernelGGL(bsx_mark_done_kernel, dim3(unsigned((E + TPB - 1) / TPB)), dim3(TPB), 0, s,
                        reinterpret_cast<uint2*>(static_cast<char*>(state) + L.envd), E);
     return int(hipGetLastError());
+}
+
+int bsx_state_release(void* state) {
+    if (!state) return BSX_E_ARG;
+    family_forget(state);
+    return 0;
 }
 
 int bsx_reset(void* state, int64_t E, int n, const uint8_t* reset_mask, const int32_t* spawn, uint64_t seed,

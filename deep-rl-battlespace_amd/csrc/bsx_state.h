@@ -9,10 +9,7 @@ namespace bsxk {
 constexpr int K = BSX_BULLET_SLOTS;
 constexpr int TPB = 256;   // reset / export kernels
 constexpr int SPB = 64;    // step kernel: a game never spans a wavefront, so the waves of a workgroup share nothing and no block barrier is needed
-#ifndef BSX_X_WPB                                       // (variant builds: -DBSX_X_WPB=<2|4|8>)
-#define BSX_X_WPB 1
-#endif
-constexpr int WPB = BSX_X_WPB;     // wavefronts per workgroup of the per-step / multi-tick kernels (the fused rollout has its own: 32 games per workgroup;
+constexpr int WPB = 1;     // wavefronts per workgroup of the per-step / multi-tick kernels (the fused rollout has its own: 32 games per workgroup;
                            // 2 / 4 waves measured slower: 8.54 / 8.39 us against 8.20)
 
 // obs / rew / done leave with the non-temporal hint: nothing on the step path reads them back, so they need not sit dirty in

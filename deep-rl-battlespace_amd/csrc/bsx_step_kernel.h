@@ -102,7 +102,7 @@ template <class T> __device__ inline T* elem(T* base, size_t i) { return base + 
 // (the multi-tick 2v2 kernels are compiled for four waves per SIMD: 65 536 games are 4 096 of their waves = four per SIMD, and at 129 ... 135
 //  registers -- three resident waves -- the launch ran as two rounds: 6.9 us per tick against 6.2 for round 3's 125-register kernel)
 template <int N, bool CONT, bool MULTI, bool ACTOR = false, bool LG = false, bool OFF32 = false>
-__global__ __launch_bounds__(SPB * (ACTOR ? group_width(N > 0 ? N : 1) / 2 : WPB)) __attribute__((amdgpu_waves_per_eu((ACTOR && N > 1) ? 2 : ((!ACTOR && MULTI && N == 2) ? 4 : ((!ACTOR && !MULTI && N >= 2) ? X_MIN_WAVES : 1)))))
+__global__ __launch_bounds__(SPB * (ACTOR ? group_width(N > 0 ? N : 1) / 2 : WPB)) __attribute__((amdgpu_waves_per_eu((ACTOR && N > 1) ? 2 : ((!ACTOR && MULTI && N == 2) ? 4 : 1))))
 void bsx_step_kernel(const int64_t E_, const uint2* const envc_, const uint2* const envd_, const uint2* const plane_, const void* const act_,
                      const uint2* const bent_, const uint32_t* const bcnt_, const int kind_, const StepArgs p_) {
     const StepArgs& p = p_;                              // (the tick loop of the multi-tick forms shadows this name: see there)
@@ -111,22 +111,6 @@ void bsx_step_kernel(const int64_t E_, const uint2* const envc_, const uint2* co
     // from the kernarg segment and do not queue behind its cold scalar-cache fetch.
     const unsigned stamp_row = blockIdx.x; (void)stamp_row;   // (diagnostic builds: where this wave's stamps go)
     STAMP(8);                                            // diagnostic builds: kernel entry, before any kernarg load
-    if constexpr (X_DEPHASE_SLOT > 0) {                  // variant builds only: the wave in slot k of its SIMD starts k x X_DEPHASE_SLOT x 64 cycles late
-        uint32_t hw;                                     // (do the resident waves of a SIMD, all in the same phase at the same moment, get in each other's way?)
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        for (uint32_t i = 0; i < (hw & 15u); ++i) __builtin_amdgcn_s_sleep(X_DEPHASE_SLOT);
-    }
-    if constexpr (X_PRIO_LATE > 0) {                     // variant builds only: the workgroups dispatched LAST (blockIdx in the last (8 - X_PRIO_LATE) eighths of the
-        if (blockIdx.x * 8u >= gridDim.x * unsigned(X_PRIO_LATE)) __builtin_amdgcn_s_setprio(X_PRIO_LATE_LEVEL);   // grid) at a raised priority: do a launch's late starters catch up?
-    }
-    if constexpr (X_PRIO_BY_SLOT > 0) {                  // variant builds only: the waves of a SIMD at different issue priorities, by wave slot
-        uint32_t hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        const uint32_t k = X_PRIO_BY_SLOT == 1 ? (hw & 1u) : (hw & 3u);
-        if (k == 1) __builtin_amdgcn_s_setprio(1);
-        else if (k == 2) __builtin_amdgcn_s_setprio(2);
-        else if (k == 3) __builtin_amdgcn_s_setprio(3);
-    }
     typedef typename std::conditional<OFF32, uint32_t, size_t>::type ix_t;     // row / element offsets
     typedef typename std::conditional<OFF32, int32_t, int64_t>::type ixs_t;    // game indices
     constexpr bool NT_STATE = !MULTI && N >= 2;
@@ -175,7 +159,7 @@ void bsx_step_kernel(const int64_t E_, const uint2* const envc_, const uint2* co
     // 4v4 and the runtime-n kernel: the centre (x | alive << 15 | y << 16) and the margins as constants in the slot -- measured faster there
     // (round 3: 4v4 23.1 us against 24.7 with corners; round 4, with the table shot: 20.5 against 20.8).  2v2 / 3v3 take the corner form
     // since round 4 (with the table shot 10.22 -> 9.67 and 17.97 -> 17.05 us; profiles/r04_experiments.json).
-    constexpr bool CORNERS = (N >= 1 && N <= 3) || X_CORNERS_ALL;
+    constexpr bool CORNERS = N >= 1 && N <= 3;
     typedef typename std::conditional<CORNERS, u32x2, uint32_t>::type rect_t;
     __shared__ __attribute__((aligned(8))) rect_t s_eb_all[WAVES * SPB];        // per owner: the enemy base, dx in [-33, 33], dy in [-32, 31]
     __shared__ __attribute__((aligned(8))) rect_t s_pq_all[WAVES * SPB];        // per plane: its post-move sprite, dx in [-27, 27], dy in [-25, 24]; dead: never hit
@@ -315,10 +299,6 @@ void bsx_step_kernel(const int64_t E_, const uint2* const envc_, const uint2* co
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 
-    if constexpr ((ACTOR || (X_DEPHASE & 512)) && X_DEPHASE != 0) {   // variant builds only: half of the workgroups start late (do the waves of a SIMD fall into anti-phase?)
-        if ((X_DEPHASE & 256) ? (blockIdx.x & 1u) : (blockIdx.x >= gridDim.x / 2))
-            for (int i = 0; i < (X_DEPHASE & 63); ++i) __builtin_amdgcn_s_sleep((X_DEPHASE & 1024) ? 31 : 127);
-    }
     for (int tk = 0; tk < (MULTI ? p.T : 1); ++tk) {
     // In the tick loop the compiler would hoist everything loop-invariant -- 36 row addresses, the Philox key schedule,
     // every fp64 constant -- and run out of registers (256 VGPRs, 1-2 waves per SIMD, SGPR spills).  Passing the three
@@ -341,9 +321,9 @@ void bsx_step_kernel(const int64_t E_, const uint2* const envc_, const uint2* co
     // or continuous actions (compiled for four waves per SIMD = 128 registers) kept 2 ... 7 registers in scratch memory, and 3v3 / 4v4
     // stood at 135 ... 161 registers = three resident waves; recomputed per tick: 2v2 93 ... 106 without scratch, 3v3 / 4v4 104 ... 122 =
     // four waves (per tick, same box: 3v3 12.19 -> 11.56 us, 4v4 16.9 -> 16.8, 2v2 continuous 8.80 -> 8.53, 4v4 continuous 21.5 -> 19.7).
-    // Not 1v1 (3.06 -> 3.10) and not 2v2 with int32 actions (5.03 -> 5.31: that kernel fitted as it was).  X_OPAQUE_MULTI_MASK: bit n =
+    // Not 1v1 (3.06 -> 3.10) and not 2v2 with int32 actions (5.03 -> 5.31: that kernel fitted as it was).  OPAQUE_MULTI_MASK (bsx_config.h): bit n =
     // the n-v-n kernels with int32 actions, bit 8 + n = those with score rows or continuous actions.
-    if constexpr ((ACTOR && N > 1) || (MULTI && !ACTOR && N > 0 && ((X_OPAQUE_MULTI_MASK >> (((LG || CONT) ? 8 : 0) + N)) & 1))) asm volatile("" : "+v"(tid_k));
+    if constexpr ((ACTOR && N > 1) || (MULTI && !ACTOR && N > 0 && ((OPAQUE_MULTI_MASK >> (((LG || CONT) ? 8 : 0) + N)) & 1))) asm volatile("" : "+v"(tid_k));
     // The kernel's arguments likewise: ~60 scalar registers of pointers, strides and reward constants were held across the tick
     // loop, ~40 of them spilled to VGPR lanes before it and read back one v_readlane at a time in every tick (78 of them at
     // 1v1).  Inside a tick the arguments are read through the kernarg segment's own address, made opaque per tick: scalar loads
@@ -406,7 +386,7 @@ void bsx_step_kernel(const int64_t E_, const uint2* const envc_, const uint2* co
     // discrete 1v1 launches up to 114 688 games per call / 65 536 per multi-tick launch, continuous up to 81 920 per call) include the same
     // phase files once per wave with different parts switched on; the phases guard their side effects by these constants and the rest falls
     // to dead-code elimination.  With every part on, every guard is a compile-time `true` (the ISA of all 76 kernels is unchanged by the guards).
-    constexpr bool R_BULLETS = true, R_MOVE = true, R_STAGE = true, R_GEOM = true, R_OUTCOME = true, R_ST_STATE = true, R_ST_OUT = true, R_RDV_MOVE = false, R_POSE_LDS = false;
+    constexpr bool R_BULLETS = true, R_MOVE = true, R_STAGE = true, R_GEOM = true, R_OUTCOME = true, R_ST_STATE = true, R_ST_OUT = true, R_POSE_LDS = false;
     constexpr int R_RDV_COUNTS = 0, R_GEOM_LDS = 0, R_PUB = 0;
     auto split_rendezvous = [] {};                       // (names of the split kernel's role code: never reached here)
     uint32_t* const s_npl = nullptr;

@@ -192,9 +192,9 @@
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if constexpr (R_RDV_COUNTS != 0) {
-        // split kernel, form A: the bullets wave hands its counts to the planes wave -- misses and base hits sit in s_agg (the work slots'
-        // adds), the plane hits of the ordered resolve go beside them -- and the two waves meet once more
-        // (one packed word per shooter in a buffer of the tick's parity: in the multi-tick form the bullets wave is a tick ahead)
+        // two-wave multi-tick kernel, up to 32 768 games: the game wave hands its bullets' counts to the outputs wave -- misses and base hits
+        // sit in s_agg (the work slots' adds), the plane hits of the ordered resolve go beside them -- and the two waves meet
+        // (one packed word per shooter in a buffer of the tick's parity: the game wave runs up to a tick ahead)
         if constexpr (R_RDV_COUNTS == 1) s_npl[(tk & 1) * SPB + tid] = uint32_t(nmiss) | (uint32_t(nbase) << 8) | (uint32_t(nplane) << 16);
         split_rendezvous();
         if constexpr (R_RDV_COUNTS == 2) {

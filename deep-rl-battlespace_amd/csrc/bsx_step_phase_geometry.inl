@@ -7,12 +7,6 @@
 // @exports ob_a ob_d oe_a oe_d
 // @lds     s_gm s_nd s_pd s_pr
     PSTAMP(3);
-    if constexpr (X_PAD_SALU > 0 || X_PAD_VALU > 0) {    // variant builds only: k extra instructions of one class per wave (what does ONE more instruction cost here?)
-        uint32_t padv = uint32_t(lane);
-        if constexpr (X_PAD_SALU > 0) asm volatile(".rept %0\n\ts_add_u32 s20, s20, 1\n\t.endr" ::"n"(X_PAD_SALU) : "s20", "scc");
-        if constexpr (X_PAD_VALU > 0) asm volatile(".rept %1\n\tv_and_or_b32 %0, %0, 3, 5\n\t.endr" : "+v"(padv) : "n"(X_PAD_VALU));
-        asm volatile("" ::"v"(padv));                    // (keeps the chain alive)
-    }
     // ---- observation geometry (battle_env.py:202-244) from the staged block, BEFORE the bullets: poses are final after
     //      the move, only the alive flags can still change; this fp64 math runs while the bullet-step loads are in flight.
     if (R_BULLETS && shot_exact) {                       // wave-uniform and rare: a flagged shot leaves its float64 step in the ring (and in LDS for its first update)
@@ -91,5 +85,5 @@
             }
         }
     }
-    // split kernel, form G: the geometry wave hands its four observation values to the wave that stores the rows, and is done
+    // two-wave per-call kernel: the geometry wave hands its four observation values to the wave that stores the rows, and is done
     if constexpr (R_GEOM_LDS == 1) s_gm[tid] = v4f_t{ob_d, ob_a, oe_d[0], oe_a[0]};

@@ -61,9 +61,7 @@
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    // split kernel, form A: the planes wave has staged the post-move sprites (s_pq), the bullets wave its shots and owner flags: rendezvous
-    if constexpr (R_RDV_MOVE) split_rendezvous();
-    // split kernel, per-call form 4: this wave leaves what the observation geometry needs -- my pose, the enemy's position, the enemy base --
+    // two-wave per-call kernel: this wave leaves what the observation geometry needs -- my pose, the enemy's position, the enemy base --
     // for the geometry wave, which has waited for it (32 bytes per lane; the geometry wave loads nothing and repeats nothing)
     if constexpr (R_POSE_LDS) {
         const double dq = dir;

@@ -10,7 +10,7 @@
     if (MULTI && !ACTOR && tk + 1 < p.T) din_next = decode(rin_next);   // the prefetch has long arrived; no store of this tick is out yet
     // ---- write back (MULTI: plane and game records travel in registers; memory gets them once, after the last tick)
     const bool last_tick = !MULTI || tk == p.T - 1;
-    // two-wave kernel, per-call forms with a geometry wave: the two waves meet; the storing wave takes the observation values the geometry wave left in LDS
+    // two-wave per-call kernel: the two waves meet; the storing wave takes the observation values the geometry wave left in LDS
     if constexpr (R_GEOM_LDS != 0) {
         split_rendezvous();
         if constexpr (R_GEOM_LDS == 2) { const v4f_t gm = s_gm[tid]; ob_d = gm.x; ob_a = gm.y; oe_d[0] = gm.z; oe_a[0] = gm.w; }
@@ -41,8 +41,8 @@
     // Compile-time team sizes outside the fused rollout: the row leaves straight from registers, 16 bytes at a time plus a tail
     // (rows are 4 (3n + 2) bytes apart, so the stores are only dword-aligned -- fine for global_store_dwordx4).  Round 1 staged
     // rows in LDS to emit fully coalesced 16-byte stores; with non-temporal stores that transpose only costs: C2 8.21 -> 7.92 us,
-    // 4v4 28.0 -> 24.9 (-DBSX_X_LDSOBS builds it for A/B).  The fused rollout keeps its rows in LDS (the actor reads them there).
-    constexpr bool DIRECT_OBS = !ACTOR && N > 0 && OBS_FORM == 0;
+    // 4v4 28.0 -> 24.9.  The fused rollout keeps its rows in LDS (the actor reads them there), the runtime-n kernel stages them too.
+    constexpr bool DIRECT_OBS = !ACTOR && N > 0;
     if constexpr (!R_ST_OUT) {
     } else if constexpr (DIRECT_OBS) {
         constexpr int D = 3 * N + 2;
@@ -62,7 +62,7 @@
             //  hint the per-step 4v4 kernel has two modes by process, ~20.3 and ~22.4 us, and any cut of its instruction count makes it SLOWER
             //  (the table shot: 24.5); with ordinary stores + the table shot it runs 20.5, stable; the multi-tick form 15.7 against 19 ... 23.
             //  Every other kernel is faster or equal with the hint; profiles/r04_experiments.json)
-            constexpr bool ROW_PLAIN = N >= X_OBS_PLAIN_FROM || (N == 4 && !CONT);
+            constexpr bool ROW_PLAIN = N == 4 && !CONT;
             auto row_store = [](auto* q, auto v) { if constexpr (ROW_PLAIN) *q = v; else out_store(q, v); };
 #pragma unroll
             for (int i = 0; i + 4 <= D; i += 4) row_store(reinterpret_cast<v4f_t*>(out + i), v4f_t{row[i], row[i + 1], row[i + 2], row[i + 3]});
@@ -97,16 +97,7 @@
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (OBS_FORM == 2 && N == 4 && !ACTOR && (reinterpret_cast<uintptr_t>(obs_t) & 63u) == 0) {
-            // (variant builds, 4v4: a game's 8 rows are 448 contiguous bytes = seven 64-byte segments; lane j < 7 of the game writes
-            //  segment j whole -- four 16-byte stores into ONE aligned 64-byte sector instead of rows that straddle sectors)
-            if (valid && a < 7) {
-                float* gseg = obs_t + (gt - ix_t(a)) * ix_t(D) + 16 * a;
-                const float* sseg = &s_obs[gl * D + 16 * a];
-#pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) out_store(reinterpret_cast<v4f_t*>(gseg + 4 * k4), *reinterpret_cast<const v4f_t*>(sseg + 4 * k4));
-            }
-        } else if (G == A && (reinterpret_cast<uintptr_t>(obs_t) & 15u) == 0) {
+        if (G == A && (reinterpret_cast<uintptr_t>(obs_t) & 15u) == 0) {
             // rows of this wave: global floats [base, base + rows*D); the wave's offset SPB*D*4 bytes is a multiple of 16
             const int64_t e_first = wblk * EPB;
             const int64_t rows = min(int64_t(SPB), (E_ - e_first) * A);

@@ -1,12 +1,13 @@
-// bsx_step_split.h -- bsx_step_split_kernel: the 1v1 step() as TWO co-operating wavefronts per 64 agents (round 5); namespace bsxk.
-// Part of the step() path of libbattlespace_hip.so (included after bsx_step_kernel.h; instantiated in bsx_step_two_wave.hip).  Two uses, both PRODUCT:
+// bsx_step_split.h -- bsx_step_split_kernel: the 1v1 step() as TWO co-operating wavefronts per 64 agents; namespace bsxk.
+// Part of the step() path of libbattlespace_hip.so (included after bsx_step_kernel.h; instantiated in bsx_step_two_wave.hip).  Two uses:
 //   * MANY = 1 / 2: multi-tick launches (bsx_step_many_discrete) of up to 65 536 games -- 3.05 -> 2.22 us per tick at 65 536 games
-//     (59 G agent-steps/s; form 2), 2.65 -> 1.75 at 32 768 (form 1);
-//   * MANY = 0: one call per launch (bsx_step_discrete, *_range) of up to 114 688 games, form 4 below -- C2 6.08 -> 5.60 us; with
-//     continuous actions (CONT; bsx_step_continuous, *_range) of up to 81 920 games -- 8.07 -> 7.67 us at 65 536 games.
+//     (59 G agent-steps/s; MANY = 2), 2.65 -> 1.75 at 32 768 (MANY = 1);
+//   * MANY = 0: one call per launch (bsx_step_discrete, *_range) of up to 114 688 games -- C2 6.08 -> 5.60 us; with continuous actions
+//     (CONT; bsx_step_continuous, *_range) of up to 81 920 games -- 8.07 -> 7.67 us at 65 536 games.
 // In both the wave that carries the game's chain runs at s_setprio 1: a SIMD's arbiter serves its resident waves oldest-first, and
-// without the priority the chain's wave queues behind the wave that has slack -- the per-call forms then LOSE (6.31 / 6.70 us), the
-// multi-tick form gains less (2.85).  DESIGN.md sections 4 and 6; profiles/r05_experiments.json.
+// without the priority the chain's wave queues behind the wave that has slack -- the per-call form then LOSES to the one-wave kernel
+// (6.70 us), the multi-tick form gains less (2.85).  DESIGN.md section 4; the forms that were built and measured against these (a planes
+// wave + a bullets wave; a geometry wave that repeats classify and move; own loads per wave; other priorities): profiles/HISTORY_r05.md.
 //
 // The idea.  At 65 536 x 1v1 the one-wave kernel (bsx_step_kernel<1, ...>) puts two waves on a SIMD, and its tick is one long chain of
 // dependent latencies: first loads -> classify -> shot (Philox, step code) -> move -> geometry -> bullet round -> resolve -> outcome ->
@@ -19,52 +20,41 @@
 //   wave 1, OUTPUTS  classify -> move -> geometry -> [rendezvous: the counts] -> outcome -> stores (rows, rewards, flags; the state after the last tick)
 // Both waves carry the planes' and the game's records in registers and advance them by the same arithmetic on the same counts, so they
 // never exchange state; the outputs wave runs up to a tick behind, its geometry and stores beside the game wave's next shot.  That is
-// form 1 (MANY = 1), for launches of up to 32 768 games: one workgroup per SIMD, a tick is a latency chain, and an outputs wave that works
+// MANY = 1, for launches of up to 32 768 games: one workgroup per SIMD, a tick is a latency chain, and an outputs wave that works
 // beside the game wave from the start of the tick is what shortens it.
-// form 2 (MANY = 2), for launches of more than 32 768 games -- two workgroups on some SIMD, the vector port is the bound: the game wave owns
+// MANY = 2, for launches of more than 32 768 games -- two workgroups on some SIMD, the vector port is the bound: the game wave owns
 // the state alone (and stores it after the last tick); per tick it PUBLISHES what the tick's outputs need (post-move position, heading,
 // flags, enemy base, reward: 16 bytes per agent, a buffer per tick parity) and the outputs wave (bsx_step_split_out_body.inl) does the
 // geometry, the row and the output stores from that, with none of the game logic: half the instructions in the wave that fills the
-// gaps.  65 536 games: 2.55 -> 2.21 us per tick; 32 768: 1.74 -> 1.96 (hence form 1 there).  Without the wave priority form 2 was neutral.
+// gaps.  65 536 games: 2.55 -> 2.21 us per tick; 32 768: 1.74 -> 1.96 (hence MANY = 1 there).
 //
-// The per-call forms.  A single call has no next tick to run ahead into; the split is by what the call's chain can shed.
-//   form 4 (PRODUCT): wave 0 everything but the observation geometry; after its move it leaves the post-move poses (own pose, enemy position,
-//     enemy base: 32 bytes per lane) in LDS.  Wave 1, GEOMETRY, loads nothing and repeats no game logic: it waits for the poses, works out the
-//     geometry (bsx_step_split_geom_body.inl: the same phase file) and hands the four observation values per agent back; the waves meet
-//     a second time before the stores, wave 0 stores everything.
-//   form 2 (variant builds, -DBSX_X_SPLIT=2): wave 1 takes the raw records from wave 0 right after the first loads and repeats classify +
-//     move itself -- it starts earlier, and issues 45 % more.
-//   form 1 (variant builds, -DBSX_X_SPLIT=1): wave 0 PLANES (move, geometry, outcome, stores), wave 1 BULLETS (shot, pool pass, resolve),
-//     three rendezvous (records; post-move sprites; counts).
-// 65 536 games, one-wave kernel 6.09 us: form 1 6.31, with the bullets wave at priority 1 6.00; form 2 6.70, with wave 0 at priority 1
-// 5.93, compiled with -amdgpu-sched-strategy=max-ilp 5.65; form 4 (priority, max-ilp) 5.60.  By size, one-wave / form 2 / form 4:
-// 16 384 games 4.84 / 4.33 / 4.34, 32 768 5.22 / 4.76 / 4.80, 49 152 - / 5.36 / 5.31, 81 920 6.99 / 6.68 / 6.33, 114 688 8.11 / 7.50 /
-// 7.11; beyond that (131 072: 8.31 against 8.85) the one-wave kernel wins again.  (Also measured, not kept: the geometry wave storing the
-// call's outputs itself from an 8-byte publish of the outcome -- 5.62, 5.83 with its priority raised for the stores.)
+// The per-call form (MANY = 0).  A single call has no next tick to run ahead into; the split is by what the call's chain can shed.
+// Wave 0 does everything but the observation geometry; after its move it leaves the post-move poses (own pose, enemy position, enemy
+// base: 32 bytes per lane) in LDS.  Wave 1, GEOMETRY, loads nothing and repeats no game logic: it waits for the poses, works out the
+// geometry (bsx_step_split_geom_body.inl: the same phase file) and hands the four observation values per agent back; the waves meet a
+// second time before the stores, wave 0 stores everything.  By size, one-wave / two-wave: 16 384 games 4.84 / 4.34 us, 32 768 5.22 / 4.80,
+// 65 536 6.09 / 5.60, 81 920 6.99 / 6.33, 114 688 8.11 / 7.11; beyond that (131 072: 8.31 against 8.85) the one-wave kernel wins again.
 //
 // How.  No second copy of the game logic: the kernel includes the SAME phase files as bsx_step_kernel, once per wave, with the R_*
 // constants of the wave's role.  The phases guard their side effects (LDS staging, stores, the pool pass, the rendezvous) by them;
 // everything that only feeds a guarded-off side effect is dead code to the compiler.  Results are those of the one-wave kernels bit
-// for bit (tests/test_hip_split.py runs them against each other; every multi-tick 1v1 test, fuzz case and soak runs the two-wave form).
+// for bit: every size the launcher gives to one of these kernels is run against the C oracle (tests/test_hip_fullsize.py), and
+// tests/test_hip_split.py runs them against the one-wave kernels.
 #pragma once
 
 namespace bsxk {
 
-// <LG, OFF32, MANY, CONT>: action encoding (score rows), 32-bit offsets, the launch form -- MANY = 0 one call per launch (per-call form 4;
-// forms 1 / 2 in variant builds), MANY = 1 / 2 the multi-tick forms -- and continuous actions (per call only); all described above.
+// <LG, OFF32, MANY, CONT>: action encoding (score rows), 32-bit offsets, the launch form -- MANY = 0 one call per launch, MANY = 1 / 2 the
+// multi-tick forms -- and continuous actions (per call only); all described above.
 template <bool LG, bool OFF32, int MANY = 0, bool CONT_ = false>
 __global__ __launch_bounds__(2 * SPB)
-#ifdef BSX_X_SPLIT_WAVES                                 // variant builds: at most this many waves per SIMD, i.e. more registers for the scheduler to use
-__attribute__((amdgpu_waves_per_eu(1, BSX_X_SPLIT_WAVES)))
-#endif
 void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uint2* const envd_, const uint2* const plane_, const void* const act_,
                            const uint2* const bent_, const uint32_t* const bcnt_, const int kind_, const StepArgs p_) {
     constexpr int N = 1;
     constexpr bool CONT = CONT_, MULTI = MANY != 0, ACTOR = false;
-    constexpr int X_SPLIT_MANY_FORM = MANY;              // (0: one call per launch; 1 / 2: the multi-tick forms)
-    // continuous actions (bsx_step_continuous): the per-call form 4 only -- its geometry wave needs nothing but the poses, so only the
+    // continuous actions (bsx_step_continuous): the per-call form only -- its geometry wave needs nothing but the poses, so only the
     // first wave's loads differ (the action triple by encoding, the float64 heading beside the plane record)
-    static_assert(!CONT || (MANY == 0 && !LG && X_SPLIT_FORM == 4), "continuous actions: per-call form 4 only");
+    static_assert(!CONT || (MANY == 0 && !LG), "continuous actions: the per-call form only");
     const StepArgs& p = p_;
     typedef typename std::conditional<OFF32, uint32_t, size_t>::type ix_t;     // row / element offsets
     typedef typename std::conditional<OFF32, int32_t, int64_t>::type ixs_t;    // game indices
@@ -100,9 +90,9 @@ void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uin
     __shared__ __attribute__((aligned(8))) u32x2 s_new_all[SPB];
     __shared__ uint32_t s_agg_all[SPB];
     __shared__ uint32_t s_npl_all[2 * SPB];              // the bullets' counts per shooter (misses | base hits << 8 | plane hits << 16), by tick parity
-    __shared__ __attribute__((aligned(16))) v4u_t s_t0_all[SPB], s_t1_all[SPB];   // the first loads' raw words, wave 0 -> wave 1
-    __shared__ __attribute__((aligned(16))) v4u_t s_pub_all[X_SPLIT_MANY_FORM == 2 ? 2 * SPB : 1];   // multi-tick form 2: what a tick's outputs need, game wave -> outputs wave, by tick parity
-    __shared__ __attribute__((aligned(16))) v4f_t s_gm_all[SPB];                  // form G: the four observation values, geometry wave -> storing wave
+    __shared__ __attribute__((aligned(16))) v4u_t s_t0_all[SPB], s_t1_all[SPB];   // per call: the post-move poses, wave 0 -> geometry wave
+    __shared__ __attribute__((aligned(16))) v4u_t s_pub_all[MANY == 2 ? 2 * SPB : 1];   // MANY = 2: what a tick's outputs need, game wave -> outputs wave, by tick parity
+    __shared__ __attribute__((aligned(16))) v4f_t s_gm_all[SPB];                  // per call: the four observation values, geometry wave -> storing wave
     constexpr bool CORNERS = true;
     typedef u32x2 rect_t;
     __shared__ __attribute__((aligned(8))) rect_t s_eb_all[SPB];
@@ -168,49 +158,38 @@ void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uin
         return d;
     };
     const ix_t pool0 = ix_t(wblk) * ix_t(POOL_CAP);
-    // (per-call forms 1, 2, 4 and the multi-tick form: the header of this file)
+    // (the roles: the header of this file)
     if constexpr (MANY != 0) {
         if (role_wave == 0) {
-            if constexpr (X_SPLIT_PRIO > 0) __builtin_amdgcn_s_setprio(X_SPLIT_PRIO);   // the game wave's tick sets the pace: it goes first at the SIMD's ports
-            constexpr bool R_BULLETS = true, R_MOVE = true, R_STAGE = true, R_GEOM = false, R_OUTCOME = true, R_RDV_MOVE = false, R_POSE_LDS = false;
-            constexpr bool R_ST_STATE = X_SPLIT_MANY_FORM == 2, R_ST_OUT = false;
-            constexpr int R_RDV_COUNTS = X_SPLIT_MANY_FORM == 2 ? 0 : 1, R_GEOM_LDS = 0, R_PUB = X_SPLIT_MANY_FORM == 2 ? 1 : 0;
+            __builtin_amdgcn_s_setprio(1);               // the game wave's tick sets the pace: it goes first at the SIMD's ports
+            constexpr bool R_BULLETS = true, R_MOVE = true, R_STAGE = true, R_GEOM = false, R_OUTCOME = true, R_POSE_LDS = false;
+            constexpr bool R_ST_STATE = MANY == 2, R_ST_OUT = false;
+            constexpr int R_RDV_COUNTS = MANY == 2 ? 0 : 1, R_GEOM_LDS = 0, R_PUB = MANY == 2 ? 1 : 0;
             s_ov[tid] = 0ull;                            // (cleared again by whoever finds it set)
 #include "bsx_step_split_many_body.inl"
-        } else if constexpr (X_SPLIT_MANY_FORM == 2) {   // (form 2: the outputs wave repeats none of the game logic, the game wave publishes 16 bytes per agent and tick)
+        } else if constexpr (MANY == 2) {                // (the outputs wave repeats none of the game logic, the game wave publishes 16 bytes per agent and tick)
             constexpr bool R_BULLETS = false, R_GEOM = true, R_ST_STATE = false, R_ST_OUT = true;
             constexpr int R_GEOM_LDS = 0, R_PUB = 0;
 #include "bsx_step_split_out_body.inl"
         } else {
-            constexpr bool R_BULLETS = false, R_MOVE = true, R_STAGE = false, R_GEOM = true, R_OUTCOME = true, R_RDV_MOVE = false, R_POSE_LDS = false;
+            constexpr bool R_BULLETS = false, R_MOVE = true, R_STAGE = false, R_GEOM = true, R_OUTCOME = true, R_POSE_LDS = false;
             constexpr bool R_ST_STATE = true, R_ST_OUT = true;
             constexpr int R_RDV_COUNTS = 2, R_GEOM_LDS = 0, R_PUB = 0;
 #include "bsx_step_split_many_body.inl"
         }
     } else {
-    constexpr int R_PUB = 0;
-    const int tk = 0;
-    if (role_wave == 0) {
-        constexpr bool FIRST = true;                     // this wave loads the shared records and hands them over
-        if constexpr (X_SPLIT_PRIO > 0) __builtin_amdgcn_s_setprio(X_SPLIT_PRIO);
-        constexpr bool R_BULLETS = X_SPLIT_FORM != 1, R_MOVE = true, R_STAGE = true, R_GEOM = X_SPLIT_FORM == 1, R_OUTCOME = true, R_ST_STATE = true, R_ST_OUT = true, R_RDV_MOVE = X_SPLIT_FORM == 1;
-        constexpr bool R_POSE_LDS = X_SPLIT_FORM == 4;
-        constexpr int R_RDV_COUNTS = X_SPLIT_FORM == 1 ? 2 : 0, R_GEOM_LDS = (X_SPLIT_FORM == 2 || X_SPLIT_FORM == 4) ? 2 : 0;
-        if constexpr (R_BULLETS) s_ov[tid] = 0ull;       // (cleared again by whoever finds it set)
+        constexpr int R_PUB = 0;
+        const int tk = 0;
+        if (role_wave == 0) {
+            __builtin_amdgcn_s_setprio(1);               // this wave's chain is the call's: it goes first at the SIMD's ports
+            constexpr bool R_BULLETS = true, R_MOVE = true, R_STAGE = true, R_GEOM = false, R_OUTCOME = true, R_ST_STATE = true, R_ST_OUT = true;
+            constexpr bool R_POSE_LDS = true;
+            constexpr int R_RDV_COUNTS = 0, R_GEOM_LDS = 2;
+            s_ov[tid] = 0ull;                            // (cleared again by whoever finds it set)
 #include "bsx_step_split_body.inl"
-    } else {
-        constexpr bool FIRST = false;
-        if constexpr (X_SPLIT_PRIO < 0) __builtin_amdgcn_s_setprio(-X_SPLIT_PRIO);   // (negative: the second wave is the one raised)
-        if constexpr (X_SPLIT_FORM == 4) {
-#include "bsx_step_split_geom_body.inl"
         } else {
-        constexpr bool R_BULLETS = X_SPLIT_FORM == 1, R_MOVE = X_SPLIT_FORM == 2, R_STAGE = false, R_GEOM = X_SPLIT_FORM == 2, R_OUTCOME = false, R_ST_STATE = false, R_ST_OUT = false, R_RDV_MOVE = X_SPLIT_FORM == 1;
-        constexpr int R_RDV_COUNTS = X_SPLIT_FORM == 1 ? 1 : 0, R_GEOM_LDS = X_SPLIT_FORM == 2 ? 1 : 0;
-        constexpr bool R_POSE_LDS = false;
-        if constexpr (R_BULLETS) s_ov[tid] = 0ull;
-#include "bsx_step_split_body.inl"
+#include "bsx_step_split_geom_body.inl"
         }
-    }
     }
 }
 

@@ -1,5 +1,6 @@
-// bsx_step_split_body.inl -- one wave's tick of bsx_step_split_kernel (bsx_step_split.h includes it twice, with the R_* constants of the
-// wave's role): the first loads of the role, the decode, and the seven phase files of bsx_step_kernel in tick order.
+// bsx_step_split_body.inl -- the FIRST wave's call in bsx_step_split_kernel's per-call form (bsx_step_split.h includes it with that wave's R_*
+// constants): the first loads, the decode, and the seven phase files of bsx_step_kernel in tick order -- everything but the observation
+// geometry, which the second wave works out from the post-move poses this wave leaves in LDS (bsx_step_split_geom_body.inl).
     {
         ix_t gt = g, EAt = ix_t(p.E) * ix_t(A);
         uint64_t seed_t = p.seed;
@@ -16,7 +17,7 @@
         (void)eb; (void)u_t; (void)obs_t; (void)rew_t; (void)done_t; (void)EAt;
         RawIn rin_next = {}; DecIn din_next = {-1, 0.0};             // (named by the phases behind `if (MULTI ...)`: never reached in this form)
         (void)rin_next; (void)din_next;
-        // ---- T0: every load this role needs, back to back (what a role does not use -- the pool for a wave without the bullets -- is dead code)
+        // ---- T0: every load of the call, back to back
         int x = 0, y = 0, hp = 0;
         uint32_t games = 0;
         double dir = 0.0;
@@ -27,67 +28,44 @@
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, uu_in = 0.0;
         (void)a0; (void)a1; (void)a2;
         STAMP(0);
-        // The game records, the plane record and the action are loaded ONCE per workgroup -- by the first wave, which hands the raw words to
-        // the second through LDS (rendezvous 0) -- so that the launch's first burst of requests is the one-wave kernel's, not twice it;
-        // a second wave with the bullets (form 1) asks for its pool meanwhile.
         {
             uint2 ecw, edw, prw;
             double dirf = 0.0; (void)dirf;
-            if constexpr (FIRST || X_SPLIT_OWN_LOADS) {
-                ecw = *elem(envc_, ix_t(ec));
-                edw = *elem(envd_, ix_t(ec));
-                prw = *elem(plane_, gt);
-                const char* const abase = static_cast<const char*>(act_);
-                float4 lg = make_float4(0.f, 0.f, 0.f, 0.f);
-                int ai = -1;
-                float f0 = 0.f, f1 = 0.f, f2 = 0.f;
-                double c0 = 0.0, c1 = 0.0, c2 = 0.0;
-                if constexpr (CONT) {                    // (as bsx_step_kernel's load_inputs: the triple by encoding, uniform branches)
-                    dirf = *elem(p.st.pdirf, gt);
-                    if (has_act) {
-                        if (kind_ == BSX_ACT_F32) {
-                            const float* ap = static_cast<const float*>(act_) + 3 * g;
-                            f0 = ap[0]; f1 = ap[1]; f2 = ap[2];
-                        } else if (kind_ == BSX_ACT_F32X4) {
-                            const float4 v = static_cast<const float4*>(act_)[g];
-                            f0 = v.x; f1 = v.y; f2 = v.z;
-                        } else {
-                            const double* ap = static_cast<const double*>(act_) + 3 * g;
-                            c0 = ap[0]; c1 = ap[1]; c2 = ap[2];
-                        }
+            ecw = *elem(envc_, ix_t(ec));
+            edw = *elem(envd_, ix_t(ec));
+            prw = *elem(plane_, gt);
+            const char* const abase = static_cast<const char*>(act_);
+            float4 lg = make_float4(0.f, 0.f, 0.f, 0.f);
+            int ai = -1;
+            float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+            double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+            if constexpr (CONT) {                        // (as bsx_step_kernel's load_inputs: the triple by encoding, uniform branches)
+                dirf = *elem(p.st.pdirf, gt);
+                if (has_act) {
+                    if (kind_ == BSX_ACT_F32) {
+                        const float* ap = static_cast<const float*>(act_) + 3 * g;
+                        f0 = ap[0]; f1 = ap[1]; f2 = ap[2];
+                    } else if (kind_ == BSX_ACT_F32X4) {
+                        const float4 v = static_cast<const float4*>(act_)[g];
+                        f0 = v.x; f1 = v.y; f2 = v.z;
+                    } else {
+                        const double* ap = static_cast<const double*>(act_) + 3 * g;
+                        c0 = ap[0]; c1 = ap[1]; c2 = ap[2];
                     }
-                } else if constexpr (LG) lg = *reinterpret_cast<const float4*>(elem(abase, has_act ? g * 16 : ix_t(0)));
-                else ai = *reinterpret_cast<const int32_t*>(elem(abase, has_act ? g * 4 : ix_t(0)));
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("" : "+s"(seed_t), "+s"(env_offset_t));
-                if constexpr (CONT) {
-                    if (has_act) {
-                        if (kind_ == BSX_ACT_F32 || kind_ == BSX_ACT_F32X4) { a0 = double(f0); a1 = double(f1); a2 = double(f2); }
-                        else { a0 = c0; a1 = c1; a2 = c2; }
-                    }
-                } else if (has_act) act = LG ? argmax4(lg.x, lg.y, lg.z, lg.w) : ai;
-                if constexpr (R_BULLETS) {
-                    pool_first = *elem(bent_, pool0 + ix_t(lane));
-                    pc = __builtin_amdgcn_readfirstlane(*elem(bcnt_, ix_t(wblk)));
-                    if (p.u) uu_in = p.u[g];                                   // (injected jitter: uniform branch)
                 }
-                if constexpr (!X_SPLIT_OWN_LOADS && X_SPLIT_FORM != 4) {   // (own loads, variant builds: every wave loads its own copy -- twice the first burst of requests, no rendezvous; form 4: the geometry wave needs no records)
-                s_t0[tid] = v4u_t{ecw.x, ecw.y, edw.x, edw.y};
-                s_t1[tid] = v4u_t{prw.x, prw.y, uint32_t(act), 0u};
-                split_rendezvous();
+            } else if constexpr (LG) lg = *reinterpret_cast<const float4*>(elem(abase, has_act ? g * 16 : ix_t(0)));
+            else ai = *reinterpret_cast<const int32_t*>(elem(abase, has_act ? g * 4 : ix_t(0)));
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" : "+s"(seed_t), "+s"(env_offset_t));
+            if constexpr (CONT) {
+                if (has_act) {
+                    if (kind_ == BSX_ACT_F32 || kind_ == BSX_ACT_F32X4) { a0 = double(f0); a1 = double(f1); a2 = double(f2); }
+                    else { a0 = c0; a1 = c1; a2 = c2; }
                 }
-            } else {
-                if constexpr (R_BULLETS) {
-                    pool_first = *elem(bent_, pool0 + ix_t(lane));
-                    pc = __builtin_amdgcn_readfirstlane(*elem(bcnt_, ix_t(wblk)));
-                    if (p.u) uu_in = p.u[g];                                   // (injected jitter: uniform branch)
-                }
-                asm volatile("" : "+s"(seed_t), "+s"(env_offset_t));
-                split_rendezvous();
-                const v4u_t t0 = s_t0[tid], t1 = s_t1[tid];
-                ecw = make_uint2(t0.x, t0.y); edw = make_uint2(t0.z, t0.w); prw = make_uint2(t1.x, t1.y);
-                act = int(t1.z);
-            }
+            } else if (has_act) act = LG ? argmax4(lg.x, lg.y, lg.z, lg.w) : ai;
+            pool_first = *elem(bent_, pool0 + ix_t(lane));
+            pc = __builtin_amdgcn_readfirstlane(*elem(bcnt_, ix_t(wblk)));
+            if (p.u) uu_in = p.u[g];                     // (injected jitter: uniform branch)
             unpack_plane(prw, x, y, hp, dir);
             if constexpr (CONT) dir = (prw.y & PLANE_FRAC) ? dirf : dir;
             er = unpack_env(ecw, edw.x);

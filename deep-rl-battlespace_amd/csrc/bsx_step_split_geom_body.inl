@@ -1,9 +1,8 @@
-// bsx_step_split_geom_body.inl -- the GEOMETRY wave of bsx_step_split_kernel's per-call form 4 (bsx_step_split.h includes it): no loads, no game
+// bsx_step_split_geom_body.inl -- the GEOMETRY wave of bsx_step_split_kernel's per-call form (bsx_step_split.h includes it): no loads, no game
 // logic -- it waits until the first wave has moved the planes, takes the poses from LDS, works out the observation geometry (the SAME phase
 // file, bsx_step_phase_geometry.inl) and hands the four observation values per agent back before the stores.
     {
         split_rendezvous();                              // the first wave has moved its planes (bsx_step_phase_move.inl, R_POSE_LDS)
-        if constexpr (X_SPLIT_GEOM_PRIO > 0) __builtin_amdgcn_s_setprio(X_SPLIT_GEOM_PRIO);   // (variant builds: from here on this wave's work is awaited too)
         STAMP(0); STAMP(1); STAMP(2);                    // (diagnostic builds: this wave's row of stamps -- waited for the poses | geometry | waited for the stores)
         const v4u_t h0 = s_t0[tid], h1 = s_t1[tid];
         const int x = int(h0.x), y = int(h0.y), nx_ = int(h0.z), ny_ = int(h0.w);

@@ -501,7 +501,7 @@ class parallel_env:
         from ..sharding import chain_ranges
         return chain_ranges(self.n_envs, self.n_agents, chains)
 
-    def capture_steps(self, actions, store=False, chains=1):
+    def capture_steps(self, actions, store=False, chains="auto"):
         """Capture T consecutive step() launches into ONE HIP graph (the launch-bound inner loop of a rollout).
 
         actions: static device tensor [T, E, A] int32 (discrete), [T, E, A, 4] float32 score vectors, or
@@ -512,11 +512,14 @@ class parallel_env:
         chains:  > 1 = the batch as that many contiguous game ranges, each a chain of T launches on its own branch of the graph (forked
                  from and joined into the capture stream).  The reference's games share nothing (battle_env.py:281-381), so the results
                  are those of chains=1 bit for bit; what changes is that a range's step t+1 waits for ITS step t only, and one chain's
-                 kernel boundary (launch, first loads, store drain) runs under the other chains' arithmetic.  Measured: nothing to
-                 gain at 1v1; two chains take 13 ... 26 % off a step for 2v2, 3v3, 6v6 ... 16v16, three chains 16 % at 4v4; more
-                 branches than that cost more in graph bookkeeping than they hide -- as do any with fewer than ~260 k agents per
-                 step (16 384 x 4v4: 10.7 -> 9.8 us on the device but 10.8 -> 10.9 on the wall clock; 8 192 games: slower either
-                 way).  "auto" picks by team size and batch size accordingly.
+                 kernel boundary (launch, first loads, store drain) runs under the other chains' arithmetic.  Measured: two chains
+                 take 13 ... 26 % off a step for 2v2, 3v3, 6v6 ... 16v16, three chains 17 % at 4v4 (20.3 -> 16.8 us at 65 536 games);
+                 at 1v1 nothing at 65 536 games (5.58 -> 6.0 ... 7.3 us: the two-wave kernel's launch is too short to hide a
+                 second branch's bookkeeping) and -14 % at 131 072 (8.30 -> 7.1: each half also fits the two-wave kernel;
+                 profiles/r06_chains_1v1.json); more branches than that cost more in graph bookkeeping than they hide -- as do any
+                 with fewer than ~260 k agents per step (16 384 x 4v4: 10.7 -> 9.8 us on the device but 10.8 -> 10.9 on the wall
+                 clock; 8 192 games: slower either way).  "auto" (the default) picks by team size and batch size accordingly
+                 (sharding.chain_ranges); chains=1 is ONE launch per step over the whole batch.
         Returns (graph, outputs): graph.replay() runs the T steps; outputs = (obs, rew, done) tensors.
         Needs rng='philox' (no host draws inside a graph)."""
         if self.rng != "philox" or self._compat:
@@ -814,4 +817,15 @@ class parallel_env:
         pass
 
     def close(self):
-        pass
+        """battle_env.py:457.  Tells the library that the state block is going away (bsx_state_release: the host-side record of the
+        block's action family is dropped, so a later allocation at the same address starts unclaimed)."""
+        st, self._released = getattr(self, "_state", None), True
+        if st is not None and getattr(self, "_lib", None) is not None:
+            self._lib.bsx_state_release(st.data_ptr())
+
+    def __del__(self):
+        try:
+            if not getattr(self, "_released", False):
+                self.close()
+        except Exception:                                   # noqa: BLE001 -- interpreter shutdown: the library may be gone already
+            pass

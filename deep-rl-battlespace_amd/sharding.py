@@ -28,12 +28,12 @@ def env_range(total_envs, rank, world_size):
 def chain_ranges(n_envs, n_agents_per_team, chains):
     """The batch as contiguous game ranges [(first, count), ...] in whole 256-game blocks -- what bsx_step_*_range takes and
     parallel_env.capture_steps(chains=) runs as independent chains of launches; fewer ranges than asked when there are not that many
-    blocks.  chains="auto": by what was measured (profiles/r03_4v4_issue_bound.json) -- nothing to gain at 1v1 or below ~260 k agents
-    per step (short launches: a multi-branch graph's bookkeeping, ~1 us per step, costs more than it hides), else 3 chains at 4v4, 2
-    for every other team size."""
+    blocks.  chains="auto": by what was measured (profiles/r03_4v4_issue_bound.json; 1v1 again with the two-wave kernels,
+    profiles/r06_chains_1v1.json) -- nothing to gain below ~260 k agents per step (short launches: a multi-branch graph's bookkeeping,
+    ~1 us per step, costs more than it hides; that includes 65 536 x 1v1), else 3 chains at 4v4, 2 for every other team size."""
     blocks = -(-int(n_envs) // 256)
     if chains == "auto":
-        chains = {1: 1, 4: 3}.get(int(n_agents_per_team), 2) if int(n_envs) * 2 * int(n_agents_per_team) >= (1 << 18) else 1
+        chains = {4: 3}.get(int(n_agents_per_team), 2) if int(n_envs) * 2 * int(n_agents_per_team) >= (1 << 18) else 1
     chains = max(1, min(int(chains), blocks))
     cuts = [(blocks * r // chains) * 256 for r in range(chains)] + [int(n_envs)]
     return [(cuts[r], cuts[r + 1] - cuts[r]) for r in range(chains)]

@@ -84,6 +84,13 @@ int bsx_state_bytes(int64_t E, int n, size_t* bytes);
  * Counters start at 0.  Every env starts "finished"; call bsx_reset before stepping. */
 int bsx_state_init(void* state, int64_t E, int n, void* stream);
 
+/* parallel_env.close (battle_env.py:457): the caller is about to free (or re-use for something else) a state block.  Forgets what the
+ * library keeps on the HOST per state address -- which action family has advanced the block (see bsx_step_continuous) -- so that a
+ * long-lived process that cycles allocations does not accumulate entries, and a later allocation at the same address does not inherit
+ * the claim.  bsx_state_init is mandatory on every (re)allocated block anyway and forgets the claim too; this call is for the
+ * address that is NOT initialised again.  Touches no device memory; 0, or BSX_E_ARG for a null pointer. */
+int bsx_state_release(void* state);
+
 /* parallel_env.reset (battle_env.py:246-279; Plane.reset sprites.py:74-91; Base.reset sprites.py:238-252).
  *   reset_mask  nullable uint8[E]: only envs with a non-zero byte are reset (null = all).
  *   spawn       nullable int32[E][4+3A]: base_red x,y, base_blue x,y, then x,y,dir per plane in id order (parity runs
@@ -111,7 +118,9 @@ int bsx_step_discrete(void* state, int64_t E, int n, const void* actions, int ac
  * continuous kernels keep them as float64 beside it.  bsx_state_init and a bsx_reset of ALL games (reset_mask == NULL) may be followed
  * by either family; the first step / rollout call after that claims the block for its family, and a call of the OTHER family on it is
  * refused with BSX_E_FAMILY (it would read headings truncated to whole degrees).  The claim is kept on the host per state address --
- * nothing on the step path touches device memory for it; a block whose bytes the caller copied elsewhere is unclaimed there. */
+ * nothing on the step path touches device memory for it; a block whose bytes the caller copied elsewhere is unclaimed there, a
+ * snapshot loaded into a block takes the block's claim (the Python surface checks a snapshot's action mode itself: state_dict meta);
+ * bsx_state_release drops the claim when the block is freed. */
 int bsx_step_continuous(void* state, int64_t E, int n, const void* actions, int action_kind, const double* u,
                         float* obs, float* rew, uint8_t* done, uint8_t* env_done, uint8_t* winner,
                         const BsxRewards* cfg, uint32_t flags, uint64_t seed, int64_t env_offset, void* stream);

@@ -251,3 +251,11 @@ def test_a_state_block_belongs_to_one_action_family_and_the_abi_says_so():
     torch.cuda.synchronize()
     with pytest.raises(ValueError, match="BSX_E_FAMILY"):                    # ... and now the block is a discrete one
         env.step_batch(act)
+    # bsx_state_release (env.close()): the host-side claim goes with the block -- an allocation that lands on the same address starts unclaimed
+    env.reset()
+    env.step_batch(act)                                                      # continuous again after the full reset
+    assert discrete_call() == -3
+    env.close()
+    env.reset()
+    assert discrete_call() == 0                                              # (the address is unclaimed; the full reset made every heading a whole degree)
+    assert lib.bsx_state_release(None) == -1

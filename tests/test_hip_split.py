@@ -1,43 +1,16 @@
 """The two-wave 1v1 step kernels (csrc/bsx_step_split.h) against the one-wave kernels (BSX_F_ONE_WAVE / `one_wave=True`): the same step() of
 envs/battle_env.py:281-381, so every output of every call and the complete game state must be IDENTICAL -- the kernels include the same
 phase files, each wave with the side effects of its role.  The product runs the MULTI-TICK form (a game wave + an outputs wave per 64
-agents) for bsx_step_many_discrete up to 65 536 games and the PER-CALL form 4 (a wave for everything but the observation geometry + a
-geometry wave fed the post-move poses) for bsx_step_discrete / _range up to 114 688 games; per-call forms 1 (a planes wave + a bullets
-wave) and 2 (the geometry wave repeats classify and move from the raw records) are measured experiments in variant builds only."""
-import os
-import subprocess
-import sys
+agents) for bsx_step_many_discrete up to 65 536 games and the PER-CALL form (a wave for everything but the observation geometry + a
+geometry wave fed the post-move poses) for bsx_step_discrete / _range up to 114 688 games.  These are EQUIVALENCE tests between two
+kernels of this build; the parity tests of each kernel against the C oracle, at every size the launcher gives it, are in
+tests/test_hip_fullsize.py (test_every_*_kernel_the_launcher_selects_vs_c_oracle, test_one_wave_1v1_kernels_kept_by_flag_vs_c_oracle)."""
 
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-@pytest.mark.parametrize("form", ["1", "2"])            # (form 4 is the product's; the tests below run against it directly)
-def test_per_call_variant_forms_equal_the_one_wave_kernel(form):
-    """The experiments' kernels stay correct: a variant library with per-call form 1 or 2 (tools/build_variant.py, ~1 min on the GPU box), and
-    this file's per-call tests again in a child process with BSX_LIB_PATH pointing at it."""
-    if os.environ.get("BSX_SPLIT_CHILD") == "1":
-        pytest.skip("this IS the child process")
-    flag = f"-DBSX_X_SPLIT={form}"
-    try:                                                 # (an experiment's test must not cost the suite: no compiler on the box, or a slow one, skips it)
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "build_variant.py"), f"citest_split{form}", flag],
-                             capture_output=True, text=True, timeout=600)
-    except (OSError, subprocess.TimeoutExpired) as exc:
-        pytest.skip(f"could not build the variant library here: {type(exc).__name__}")
-    if out.returncode != 0:
-        pytest.skip("could not build the variant library here: " + out.stderr[-300:])
-    lib = out.stdout.strip().splitlines()[-1]
-    try:
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k", "per_call_two_wave"],
-                           capture_output=True, text=True, timeout=900, cwd=ROOT,
-                           env=dict(os.environ, BSX_LIB_PATH=lib, BSX_SPLIT_CHILD="1"))
-        assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-3000:], r.stderr[-1500:])
-    finally:
-        os.remove(lib)
 
 
 def _env(**kw):
@@ -98,8 +71,6 @@ def test_per_call_two_wave_kernel_with_continuous_actions_equals_the_one_wave_ke
     """bsx_step_continuous takes the two-wave form too (up to 81 920 games): only the first wave's loads differ -- the action triple in its
     encodings (float32 / float64 [.,3] here; float32 rows of four come from the policy rollout's graph form, whose tests run against the C
     oracle) and the float64 heading beside the plane record; the geometry wave is the discrete kernel's.  Fractional headings, sincos moves and shots, clipped actions, masked resets: outputs and state identical."""
-    if os.environ.get("BSX_SPLIT_CHILD") == "1":
-        pytest.skip("variant libraries carry the continuous two-wave kernel only in the product's form")
     kw = dict(n_agents=1, n_envs=E, seed=17, auto_reset=auto, wide_offsets=wide, continuous_actions=True)
     a, b = _env(**kw), _env(one_wave=True, **kw)
     oa, ob = a.reset(), b.reset()

@@ -49,6 +49,7 @@ def test_bad_arguments_are_rejected_before_any_launch():
     assert lib.bsx_reset(None, 4, 1, None, None, 0, 0, 0, None, None) == -1
     assert lib.bsx_observe(None, 4, 1, None, None) == -1
     assert lib.bsx_state_init(ctypes.c_void_p(4096 + 8), 4, 1, None) == -2      # misaligned state base
+    assert lib.bsx_state_release(None) == -1 and lib.bsx_state_release(ctypes.c_void_p(4096)) == 0   # (host-side bookkeeping only: no device call)
     # the multi-tick and rollout entry points: T out of range, team sizes the one-launch rollout is not built for, unknown precision
     ok = ctypes.c_void_p(4096)
     assert lib.bsx_step_many_discrete(ok, 4, 1, 0, ok, 0, None, ok, ok, ok, None, None, None, ctypes.byref(cfg), 0, 1, 0, 0, None) == -1
@@ -470,6 +471,24 @@ def test_phase_files_keep_their_read_write_contract(tmp_path):
     assert "bsx_step_phase_outcome.inl: @exports misses ['alive']" in r.stdout, r.stdout
 
 
+def test_the_product_sources_carry_no_experiment_switches():
+    """Round 5's measured-and-rejected forms (per-call two-wave forms 1 / 2, own loads, de-phased waves, priorities by slot, padding
+    instructions, row-store forms ...) are history (profiles/HISTORY_r05.md, profiles/r05_experiments.json), not product source: no
+    `X_*` / `-DBSX_X_*` switch is left in csrc/ -- what remains configurable at build time is the measuring instrument (DIAG bits and
+    stamps, csrc/bsx_diag.h) -- and the GPU suite builds nothing on the box."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "deep-rl-battlespace_amd", "csrc")
+    left = {}
+    for f in sorted(glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.inl")) + glob.glob(os.path.join(csrc, "*.hip"))):
+        hits = re.findall(r"\b(?:BSX_X_\w+|X_[A-Z][A-Z0-9_]+)\b", open(f).read())
+        if hits:
+            left[os.path.basename(f)] = sorted(set(hits))
+    assert not left, left
+    for f in glob.glob(os.path.join(ROOT, "tests", "test_hip_*.py")):
+        assert "build_variant" not in open(f).read(), f
+
+
 def test_the_size_limits_of_the_two_wave_kernels_are_the_same_in_the_launcher_the_bench_and_the_profile_tool():
     """csrc/bsx_kernels.hip decides by launch size which 1v1 kernel runs (two-wave per call up to 114 688 games, 81 920 with continuous
     actions; two-wave multi-tick up to 65 536, its form 2 above 32 768).  bench.py and tools/collect_profile.py NAME the kernel a workload
@@ -477,9 +496,9 @@ def test_the_size_limits_of_the_two_wave_kernels_are_the_same_in_the_launcher_th
     import re
     csrc = os.path.join(ROOT, "deep-rl-battlespace_amd", "csrc")
     k = open(os.path.join(csrc, "bsx_kernels.hip")).read()
-    c = open(os.path.join(csrc, "bsx_config.h")).read()
-    lim = {name: int(re.search(r"#define %s (\d+)" % name, k).group(1)) for name in ("BSX_X_SPLIT_MAX", "BSX_X_SPLIT_CONT_MAX", "BSX_X_SPLIT_MANY_MAX")}
-    form2_from = int(re.search(r"X_SPLIT_MANY_FORM2_FROM = (\d+);", c).group(1))
+    m = re.search(r"SPLIT_MAX_GAMES = (\d+), SPLIT_MANY_MAX_GAMES = (\d+), SPLIT_CONT_MAX_GAMES = (\d+);", k)
+    lim = {"BSX_X_SPLIT_MAX": int(m.group(1)), "BSX_X_SPLIT_MANY_MAX": int(m.group(2)), "BSX_X_SPLIT_CONT_MAX": int(m.group(3))}
+    form2_from = int(re.search(r"SPLIT_MANY_FORM2_FROM = (\d+);", k).group(1))
     assert lim == {"BSX_X_SPLIT_MAX": 114688, "BSX_X_SPLIT_CONT_MAX": 81920, "BSX_X_SPLIT_MANY_MAX": 65536} and form2_from == 32768
     b = open(os.path.join(ROOT, "bench.py")).read()
     t = open(os.path.join(ROOT, "tools", "collect_profile.py")).read()

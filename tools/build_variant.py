@@ -35,7 +35,7 @@ def build_variant(name, extra, drop=()):
         # -DBSX_VARIANT: bsx_kernels.hip takes its diagnostic switches from csrc/bsx_diag.h instead of the product constants
         # bsx_kernels.hip carries every step-kernel instance in a variant build; the three instance units compile to nothing
         step_tu = os.path.basename(src).startswith(("bsx_kernels", "bsx_step_"))
-        more = ["-DBSX_VARIANT", *extra] if step_tu else [f for f in extra if f.startswith("-DBSX_X_ACTOR")]
+        more = ["-DBSX_VARIANT", *extra] if step_tu else []
         subprocess.run([hipcc, *B.COMMON, *fl, *more, "-I", B.INCLUDE, "-c", src, "-o", obj], check=True)
         objs.append(obj)
     lib = os.path.join(out_dir, f"lib_{name}.so")
