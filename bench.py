@@ -661,8 +661,9 @@ def main():
         narrow = E * 2 * n * 200 <= 0xFFFFFFFF            # csrc narrow_offsets_ok(): 32-bit offsets while every array stays below 4 GB
         if two_wave(n, continuous, many, E):
             form = (2 if E > 32768 else 1) if many else 0     # csrc launch_for_n(): multi-tick launches of more than 32 768 games take form 2
+            draw = not many and (continuous or E <= 98304)    # ... per-call launches of up to 98 304 games the kernel whose geometry wave draws
             return (f"bsx_step_split_kernel<false,{'true' if narrow else 'false'},{form},"
-                    f"{'true' if continuous else 'false'}>")      # <LG, OFF32, MANY (0 per call, 1 / 2 multi-tick forms), CONT>
+                    f"{'true' if continuous else 'false'},{'true' if draw else 'false'}>")      # <LG, OFF32, MANY (0 per call, 1 / 2 multi-tick forms), CONT, DRAW>
         return (f"bsx_step_kernel<{n if n <= 4 else 0},{'true' if continuous else 'false'},{'true' if many else 'false'},false,false,"
                 f"{'true' if narrow else 'false'}>")       # <N, CONT, MULTI, ACTOR, LG, OFF32>
 

@@ -291,6 +291,7 @@ inline bool narrow_offsets_ok(int64_t E, int n, uint32_t flags) {
 // 8.11 -> 7.11 at 114 688 (131 072: 8.31 -> 8.85, so not there).  Continuous actions (bsx_step_continuous) take the same form up to 81 920
 // games (84 ... 88 registers: six waves per SIMD at most): 8.07 -> 7.67 us at 65 536 games, 6.26 -> 5.85 at 16 384, 9.49 -> 8.74 at 81 920 (98 304: 9.92 -> 11.95).
 constexpr int64_t SPLIT_MAX_GAMES = 114688, SPLIT_MANY_MAX_GAMES = 65536, SPLIT_CONT_MAX_GAMES = 81920;
+constexpr int64_t SPLIT_DRAW_MAX_GAMES = 98304;            // per-call discrete launches of up to this many games: the geometry wave also computes the call's Philox block (round 6)
 constexpr int64_t SPLIT_MANY_FORM2_FROM = 32768;           // multi-tick launches of MORE games than this (two workgroups on some SIMD): the outputs wave that repeats no game logic
 template <bool CONT, bool MULTI>
 inline bool split_applies(int n, const StepArgs& a, int64_t bound) {
@@ -298,9 +299,9 @@ inline bool split_applies(int n, const StepArgs& a, int64_t bound) {
     if (CONT) return !MULTI && bound <= SPLIT_CONT_MAX_GAMES;   // (continuous actions: the per-call form only)
     return bound <= (MULTI ? SPLIT_MANY_MAX_GAMES : SPLIT_MAX_GAMES);
 }
-template <bool LG, bool OFF32, int MANY, bool CONT = false>
+template <bool LG, bool OFF32, int MANY, bool CONT = false, bool DRAW = false>
 void launch_split(dim3 grid, hipStream_t s, const StepArgs& a, int64_t bound) {
-    hipLaunchKernelGGL((bsx_step_split_kernel<LG, OFF32, MANY, CONT>), grid, dim3(2 * SPB), 0, s, bound, a.st.envc, a.st.envd, a.st.plane, a.actions, a.st.bent, a.st.bcnt, a.action_kind, a);
+    hipLaunchKernelGGL((bsx_step_split_kernel<LG, OFF32, MANY, CONT, DRAW>), grid, dim3(2 * SPB), 0, s, bound, a.st.envc, a.st.envd, a.st.plane, a.actions, a.st.bent, a.st.bcnt, a.action_kind, a);
 }
 template <bool CONT, bool MULTI, bool LG>
 void launch_for_n(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs& a, int64_t bound) {
@@ -308,7 +309,11 @@ void launch_for_n(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs& a
         if (split_applies<CONT, MULTI>(n, a, bound)) {   // (the grid is the same: one workgroup per 64 agents, of two waves instead of one)
             const bool narrow = narrow_offsets_ok(a.E, n, a.flags);
             if constexpr (!MULTI) {
-                if (narrow) launch_split<LG, true, 0>(grid, s, a, bound); else launch_split<LG, false, 0>(grid, s, a, bound);
+                if (bound <= SPLIT_DRAW_MAX_GAMES) {
+                    if (narrow) launch_split<LG, true, 0, false, true>(grid, s, a, bound); else launch_split<LG, false, 0, false, true>(grid, s, a, bound);
+                } else {                                     // seven waves per SIMD: no room beside the first waves for the geometry wave's draw
+                    if (narrow) launch_split<LG, true, 0>(grid, s, a, bound); else launch_split<LG, false, 0>(grid, s, a, bound);
+                }
             } else if (bound > SPLIT_MANY_FORM2_FROM) {    // two workgroups on some SIMD: the outputs wave that repeats no game logic (form 2)
                 if (narrow) launch_split<LG, true, 2>(grid, s, a, bound); else launch_split<LG, false, 2>(grid, s, a, bound);
             } else {                                         // one workgroup per SIMD at most: the outputs wave that carries the state too (form 1)
@@ -318,8 +323,8 @@ void launch_for_n(int n, dim3 grid, dim3 block, hipStream_t s, const StepArgs& a
         }
     } else if constexpr (!MULTI) {
         if (split_applies<CONT, MULTI>(n, a, bound)) {
-            if (narrow_offsets_ok(a.E, n, a.flags)) launch_split<false, true, 0, true>(grid, s, a, bound);
-            else launch_split<false, false, 0, true>(grid, s, a, bound);
+            if (narrow_offsets_ok(a.E, n, a.flags)) launch_split<false, true, 0, true, true>(grid, s, a, bound);
+            else launch_split<false, false, 0, true, true>(grid, s, a, bound);
             return;
         }
     }

@@ -28,18 +28,20 @@ BSX_STEP_FAMILY(0, true) BSX_STEP_FAMILY(1, true) BSX_STEP_FAMILY(2, true) BSX_S
 BSX_ROLLOUT_FAMILY(1) BSX_ROLLOUT_FAMILY(2) BSX_ROLLOUT_FAMILY(3) BSX_ROLLOUT_FAMILY(4)
 #endif
 #if defined(BSX_INST_SPLIT) || defined(BSX_INST_SPLIT_MANY)
-#define BSX_SPLIT_INST(LG, OFF32, MANY, CONT)                                                                                            \
-    BSX_INST_KW template __global__ void bsxk::bsx_step_split_kernel<LG, OFF32, MANY, CONT>(                                             \
+#define BSX_SPLIT_INST(LG, OFF32, MANY, CONT, DRAW)                                                                                      \
+    BSX_INST_KW template __global__ void bsxk::bsx_step_split_kernel<LG, OFF32, MANY, CONT, DRAW>(                                       \
         const int64_t, const uint2* const, const uint2* const, const uint2* const, const void* const, const uint2* const, const uint32_t* const, \
         const int, const bsxk::StepArgs);
 #endif
 #ifdef BSX_INST_SPLIT
-BSX_SPLIT_INST(false, false, 0, false) BSX_SPLIT_INST(false, true, 0, false) BSX_SPLIT_INST(true, false, 0, false) BSX_SPLIT_INST(true, true, 0, false)
-#ifdef BSX_INST_SPLIT_CONT                               // (continuous actions: the product's per-call form only; see bsx_step_split.h)
-BSX_SPLIT_INST(false, false, 0, true) BSX_SPLIT_INST(false, true, 0, true)
+// (per call, discrete: with the geometry wave's draw -- launches of up to 98 304 games -- and without it, up to 114 688; continuous: with it)
+BSX_SPLIT_INST(false, false, 0, false, true) BSX_SPLIT_INST(false, true, 0, false, true) BSX_SPLIT_INST(true, false, 0, false, true) BSX_SPLIT_INST(true, true, 0, false, true)
+BSX_SPLIT_INST(false, false, 0, false, false) BSX_SPLIT_INST(false, true, 0, false, false) BSX_SPLIT_INST(true, false, 0, false, false) BSX_SPLIT_INST(true, true, 0, false, false)
+#ifdef BSX_INST_SPLIT_CONT                               // (continuous actions: the per-call form only; see bsx_step_split.h)
+BSX_SPLIT_INST(false, false, 0, true, true) BSX_SPLIT_INST(false, true, 0, true, true)
 #endif
 #endif
 #ifdef BSX_INST_SPLIT_MANY
-BSX_SPLIT_INST(false, false, 1, false) BSX_SPLIT_INST(false, true, 1, false) BSX_SPLIT_INST(true, false, 1, false) BSX_SPLIT_INST(true, true, 1, false)
-BSX_SPLIT_INST(false, false, 2, false) BSX_SPLIT_INST(false, true, 2, false) BSX_SPLIT_INST(true, false, 2, false) BSX_SPLIT_INST(true, true, 2, false)
+BSX_SPLIT_INST(false, false, 1, false, false) BSX_SPLIT_INST(false, true, 1, false, false) BSX_SPLIT_INST(true, false, 1, false, false) BSX_SPLIT_INST(true, true, 1, false, false)
+BSX_SPLIT_INST(false, false, 2, false, false) BSX_SPLIT_INST(false, true, 2, false, false) BSX_SPLIT_INST(true, false, 2, false, false) BSX_SPLIT_INST(true, true, 2, false, false)
 #endif

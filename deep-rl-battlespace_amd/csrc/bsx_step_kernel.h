@@ -387,11 +387,11 @@ void bsx_step_kernel(const int64_t E_, const uint2* const envc_, const uint2* co
     // phase files once per wave with different parts switched on; the phases guard their side effects by these constants and the rest falls
     // to dead-code elimination.  With every part on, every guard is a compile-time `true` (the ISA of all 76 kernels is unchanged by the guards).
     constexpr bool R_BULLETS = true, R_MOVE = true, R_STAGE = true, R_GEOM = true, R_OUTCOME = true, R_ST_STATE = true, R_ST_OUT = true, R_POSE_LDS = false;
-    constexpr int R_RDV_COUNTS = 0, R_GEOM_LDS = 0, R_PUB = 0;
+    constexpr int R_RDV_COUNTS = 0, R_GEOM_LDS = 0, R_PUB = 0, R_DRAW_LDS = 0;
     auto split_rendezvous = [] {};                       // (names of the split kernel's role code: never reached here)
     uint32_t* const s_npl = nullptr;
     v4f_t* const s_gm = nullptr;
-    v4u_t* const s_t0 = nullptr; v4u_t* const s_t1 = nullptr; v4u_t* const s_pub = nullptr;
+    v4u_t* const s_t0 = nullptr; v4u_t* const s_pub = nullptr; v4u_t* const s_rw = nullptr;
 #include "bsx_step_phase_actor.inl"
 #include "bsx_step_phase_shot.inl"
 #include "bsx_step_phase_move.inl"

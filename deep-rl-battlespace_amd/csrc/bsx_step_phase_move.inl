@@ -3,29 +3,18 @@
 // (1v1: DPP; larger teams: wave-private LDS) and the planes' sprites as rectangles for the work slots.  Writes: x, y, dir, hp, er (re-spawn),
 // nx_, ny_, nhp_ (1v1), s_x, s_y, s_hp, s_bhit, s_pq.
 // The contract (tools/check_phase_contract.py checks it against this file's text in the CPU suite; names are the kernel's locals):
-// @reads   alive0 dir_rot dl mode rw
-// @writes  a0 a1 dir er hp tick x y
+// @reads   CHEAP_SHOT alive0 d0 dir_rot dl ks mode nexact spawn srank sx0 sy0
+// @writes  a0 a1 dir er hp nbdir ncode nd rw shot_exact tick x y
 // @exports nhp_ nx_ ny_
-// @lds     s_bhit s_hp s_pq s_t0 s_t1 s_x s_y
+// @lds     s_bhit s_hp s_new s_pq s_t0 s_x s_y
     STAMP(2);
+    // re-spawn in place of the inert call; episode id = games played so far.  My block holds my pose and (first plane of a team) my
+    // team's base; the two bases travel to every lane of the game (all lanes of a game are here together)
     if constexpr (R_MOVE) {                              // (split kernels: a wave that only runs bullets does not move planes)
     if (mode == M_RESET) {
-        // re-spawn in place of the inert call; episode id = games played so far.  My block holds my pose and (first plane of a team) my
-        // team's base; the two bases travel to every lane of the game (all lanes of a game are here together)
-        const SpawnDraw sd = spawn_from_words(rw, a < A ? a : A - 1, n);
-        if constexpr (N == 1) {
-            const int ox = lane_xor1(sd.bx), oy = lane_xor1(sd.by);
-            er.brx = team == 0 ? sd.bx : ox; er.bry = team == 0 ? sd.by : oy;
-            er.bbx = team == 0 ? ox : sd.bx; er.bby = team == 0 ? oy : sd.by;
-        } else {
-            er.brx = __shfl(sd.bx, gl); er.bry = __shfl(sd.by, gl);
-            er.bbx = __shfl(sd.bx, gl + n); er.bby = __shfl(sd.by, gl + n);
+        if constexpr (R_DRAW_LDS != 2) {                 // (R_DRAW_LDS == 2: after the pose hand-over, below -- the block comes from the geometry wave)
+#include "bsx_step_phase_respawn.inl"
         }
-        er.bhp_r = er.bhp_b = 5 * n;
-        er.tick = 0; er.done = 0; er.winner = BSX_WINNER_NONE;
-        tick = 0;
-        x = sd.x; y = sd.y; dir = double(sd.dir);
-        hp = PLANE_HP;
     } else if (mode == M_PHYS && alive0) {
         // ---- process_action (battle_env.py:383-424)
         if (!CONT) {
@@ -62,10 +51,24 @@
         __builtin_amdgcn_wave_barrier();
     }
     // two-wave per-call kernel: this wave leaves what the observation geometry needs -- my pose, the enemy's position, the enemy base --
-    // for the geometry wave, which has waited for it (32 bytes per lane; the geometry wave loads nothing and repeats nothing)
+    // for the geometry wave, which has waited for it (16 bytes per lane; the geometry wave repeats no game logic)
     if constexpr (R_POSE_LDS) {
         const double dq = dir;
-        s_t0[tid] = v4u_t{uint32_t(x), uint32_t(y), uint32_t(nx_), uint32_t(ny_)};
-        s_t1[tid] = v4u_t{uint32_t(__double2loint(dq)), uint32_t(__double2hiint(dq)), uint32_t(team == 0 ? er.bbx : er.brx), uint32_t(team == 0 ? er.bby : er.bry)};
+        // (one 16-byte word per lane: position, heading, enemy base; the enemy's position is the lane next door's -- the geometry wave takes it by DPP)
+        s_t0[tid] = v4u_t{pack_xy(x, y), uint32_t(__double2loint(dq)), uint32_t(__double2hiint(dq)), pack_xy(team == 0 ? er.bbx : er.brx, team == 0 ? er.bby : er.bry)};
         split_rendezvous();
+        if constexpr (R_DRAW_LDS == 2) {
+            // The call's Philox block -- the shot's jitter, or the pose of a plane whose game this call re-spawns -- was computed by the geometry
+            // wave while this wave classified and moved (the same block from the same key: bit-identical), and is in LDS since before that wave
+            // arrived at the rendezvous above.  A re-spawned game's lanes take their new pose HERE: nothing between the move and this point reads
+            // it (their sprites and enemy base are staged for work slots that a re-spawn drops; the geometry wave works the new pose out itself).
+            const v4u_t w4 = s_rw[tid];
+            rw = make_uint4(w4.x, w4.y, w4.z, w4.w);
+            if (mode == M_RESET) {
+#include "bsx_step_phase_respawn.inl"
+            }
+            nhp_ = lane_xor1(valid ? hp : 0);
+#include "bsx_step_phase_shot_entry.inl"
+            shot_exact = any64(spawn && nexact);
+        }
     }

@@ -5,7 +5,7 @@
 // The contract (tools/check_phase_contract.py checks it against this file's text in the CPU suite; names are the kernel's locals):
 // @reads -
 // @writes  a2 rin_next
-// @exports CHEAP_SHOT alive0 cnt_delta dir_rot dl ks mode nbdir nd nexact pool_pass rw shot_exact slots spawn tick
+// @exports CHEAP_SHOT alive0 cnt_delta d0 dir_rot dl ks mode nbdir ncode nd nexact pool_pass rw shot_exact slots spawn srank sx0 sy0 tick
 // @lds     s_agg s_eb s_fl s_new
     // ================= T1: the heading-table entry -- the one dependent load of the common path =====================
     // The heading table (361 x 16 B, read by every wave of every launch) stays hot in each CU's L1: the entry for the
@@ -77,38 +77,17 @@
     // (episode, plane); the first plane of each team also draws its base)
     const bool respawn = mode == M_RESET;
     uint4 rw = make_uint4(0u, 0u, 0u, 0u);
-    // (split kernels: the wave that runs the bullets draws the jitter, a wave that moves planes the re-spawn -- the same block, whoever computes it)
-    if ((R_BULLETS && spawn && !u_t && !(DIAG & 8u)) || (R_MOVE && respawn))
+    // (split kernels: the wave that runs the bullets draws the jitter, a wave that moves planes the re-spawn -- the same block, whoever computes it.
+    //  R_DRAW_LDS == 2, the per-call two-wave kernel's first wave: NEITHER -- its geometry wave, idle until the planes have moved, computes the
+    //  block from the game's record and leaves it in LDS (bsx_step_split_geom_body.inl); this wave takes it after the pose hand-over and
+    //  makes the shot there: bsx_step_phase_move.inl)
+    if (R_DRAW_LDS != 2 && ((R_BULLETS && spawn && !u_t && !(DIAG & 8u)) || (R_MOVE && respawn)))
         rw = draw4(seed_t, genv, respawn ? STREAM_AUTORESET : STREAM_JITTER, games, respawn ? uint32_t(a < A ? a : A - 1) : ((uint32_t(tick) << 8) | uint32_t(a)));
-    if (R_BULLETS && spawn) {
-        double uu = uu_in;
-        if (!u_t && !(DIAG & 8u)) uu = uniform53(rw.x, rw.y);
-        const double jit = uu * 8.0 - 4.0;
-        nbdir = d0 + jit;
-        if constexpr (CHEAP_SHOT) {
-            // Discrete headings are whole degrees and a shooter does not turn, so (21.5 cos d0, -21.5 sin d0) is the heading-table
-            // entry `dl` this lane gathered for its move; the jitter is at most 4 degrees.  The integer step code only needs the
-            // step to ~2^-18 (step_code's guard is wider than any error here), so the common path takes it from the angle-addition
-            // formulas with two-term series for the jitter -- |error| < 1e-8 on 45 cos -- instead of a float64 sincos of ~110
-            // instructions.  A shot the code flags as not provably exact (one in ~30 000) gets the library sincos below, behind the
-            // wave-uniform branch of the exact path; every other shot's integer moves are those of the exact step (same floor, the
-            // fraction far from 0 and 1), so the results do not change.
-            const double jr = jit * DEG2RAD, t = jr * jr;
-            const double cj = __builtin_fma(t, __builtin_fma(t, 1.0 / 24.0, -0.5), 1.0);
-            const double sj = jr * __builtin_fma(t, __builtin_fma(t, 1.0 / 120.0, -1.0 / 6.0), 1.0);
-            constexpr double K45 = BULLET_STEP / 21.5;
-            nd = make_double2(K45 * __builtin_fma(dl.x, cj, dl.y * sj), K45 * __builtin_fma(dl.y, cj, -(dl.x * sj)));
-        } else {
-            double sn, cs;
-            sincos(-(nbdir * DEG2RAD), &sn, &cs);
-            nd = make_double2(BULLET_STEP * cs, BULLET_STEP * sn);
-        }
-        ncode = step_code(nd.x, nd.y, nexact);
-        st_store<NT_STATE>(elem(p.st.bdir, ix_t(ks) * EAt + gt), nbdir);      // ring by birth tick: never moves, read only by bsx_export_state
-        // the shot as a pool entry, queued by shot rank: age 0, the PRE-move pose, my lane as its owner
-        s_new[srank] = u32x2{pack_bullet(x, y, 0) | (nexact ? ENT_EXACT : 0u) | (uint32_t(lane) << ENT_OWNER_SHIFT), ncode};
+    const int sx0 = x, sy0 = y;                          // the PRE-move position: the shot's origin wherever the block below runs
+    if constexpr (R_DRAW_LDS != 2) {
+#include "bsx_step_phase_shot_entry.inl"
     }
     // rare (step_code): a shot that moves by the float64 sum.  Asked once per wave, here, long before anything branches on it
-    const bool shot_exact = any64(spawn && nexact);
+    bool shot_exact = any64(spawn && nexact);
     FSTAMP(6);
 

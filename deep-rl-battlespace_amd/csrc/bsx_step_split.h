@@ -29,11 +29,20 @@
 // gaps.  65 536 games: 2.55 -> 2.21 us per tick; 32 768: 1.74 -> 1.96 (hence MANY = 1 there).
 //
 // The per-call form (MANY = 0).  A single call has no next tick to run ahead into; the split is by what the call's chain can shed.
-// Wave 0 does everything but the observation geometry; after its move it leaves the post-move poses (own pose, enemy position, enemy
-// base: 32 bytes per lane) in LDS.  Wave 1, GEOMETRY, loads nothing and repeats no game logic: it waits for the poses, works out the
-// geometry (bsx_step_split_geom_body.inl: the same phase file) and hands the four observation values per agent back; the waves meet a
-// second time before the stores, wave 0 stores everything.  By size, one-wave / two-wave: 16 384 games 4.84 / 4.34 us, 32 768 5.22 / 4.80,
+// Wave 0 does everything but the observation geometry; after its move it leaves the post-move poses (position, heading, enemy base:
+// 16 bytes per lane) in LDS.  Wave 1, GEOMETRY, repeats no game logic: it waits for the poses, works out the geometry
+// (bsx_step_split_geom_body.inl: the same phase file) and hands the four observation values per agent back; the waves meet a second time
+// before the stores, wave 0 stores everything.  By size, one-wave / two-wave (round 5): 16 384 games 4.84 / 4.34 us, 32 768 5.22 / 4.80,
 // 65 536 6.09 / 5.60, 81 920 6.99 / 6.33, 114 688 8.11 / 7.11; beyond that (131 072: 8.31 against 8.85) the one-wave kernel wins again.
+// DRAW (round 6; launches of up to 98 304 games, and every continuous launch): until the planes have moved wave 1 has nothing to do --
+// so it loads the game's record itself and computes the call's ONE Philox block per lane (the shot's jitter, or the pose of a plane whose
+// game the call re-spawns: the key is in the record and the kernel's arguments), ~65 of the ~100 vector instructions of wave 0's shot,
+// and leaves it in LDS before the pose rendezvous.  Wave 0 takes it there: the shot's entry and a re-spawned game's new pose are made
+// AFTER the hand-over (bsx_step_phase_move.inl; nothing between the move and that point reads them), the geometry wave works a
+// re-spawned plane's pose out of the block itself.  The same block from the same key: bit-identical.  65 536 games 5.60 -> 5.39 us,
+// 16 384 4.36 -> 4.22, 32 768 4.84 -> 4.65, 98 304 6.55 -> 6.40, bullet-heavy play 9.64 -> 9.45, continuous 7.65 -> 7.60
+// (profiles/r06_experiments.json).  At 114 688 games -- seven waves on a SIMD -- there is no room for the draw beside the first waves
+// (7.13 -> 7.5 ... 8.1): above 98 304 games the launcher takes DRAW = false, the first wave draws itself.
 //
 // How.  No second copy of the game logic: the kernel includes the SAME phase files as bsx_step_kernel, once per wave, with the R_*
 // constants of the wave's role.  The phases guard their side effects (LDS staging, stores, the pool pass, the rendezvous) by them;
@@ -46,7 +55,8 @@ namespace bsxk {
 
 // <LG, OFF32, MANY, CONT>: action encoding (score rows), 32-bit offsets, the launch form -- MANY = 0 one call per launch, MANY = 1 / 2 the
 // multi-tick forms -- and continuous actions (per call only); all described above.
-template <bool LG, bool OFF32, int MANY = 0, bool CONT_ = false>
+// DRAW (per call only): the geometry wave also computes the call's Philox block (below); without it the first wave draws itself, as in round 5.
+template <bool LG, bool OFF32, int MANY = 0, bool CONT_ = false, bool DRAW = false>
 __global__ __launch_bounds__(2 * SPB)
 void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uint2* const envd_, const uint2* const plane_, const void* const act_,
                            const uint2* const bent_, const uint32_t* const bcnt_, const int kind_, const StepArgs p_) {
@@ -55,6 +65,7 @@ void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uin
     // continuous actions (bsx_step_continuous): the per-call form only -- its geometry wave needs nothing but the poses, so only the
     // first wave's loads differ (the action triple by encoding, the float64 heading beside the plane record)
     static_assert(!CONT || (MANY == 0 && !LG), "continuous actions: the per-call form only");
+    static_assert(!DRAW || MANY == 0, "the geometry wave's draw: the per-call form only");
     const StepArgs& p = p_;
     typedef typename std::conditional<OFF32, uint32_t, size_t>::type ix_t;     // row / element offsets
     typedef typename std::conditional<OFF32, int32_t, int64_t>::type ixs_t;    // game indices
@@ -90,9 +101,10 @@ void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uin
     __shared__ __attribute__((aligned(8))) u32x2 s_new_all[SPB];
     __shared__ uint32_t s_agg_all[SPB];
     __shared__ uint32_t s_npl_all[2 * SPB];              // the bullets' counts per shooter (misses | base hits << 8 | plane hits << 16), by tick parity
-    __shared__ __attribute__((aligned(16))) v4u_t s_t0_all[SPB], s_t1_all[SPB];   // per call: the post-move poses, wave 0 -> geometry wave
+    __shared__ __attribute__((aligned(16))) v4u_t s_t0_all[MANY == 0 ? SPB : 1];  // per call: the post-move poses (position, heading, enemy base), wave 0 -> geometry wave
     __shared__ __attribute__((aligned(16))) v4u_t s_pub_all[MANY == 2 ? 2 * SPB : 1];   // MANY = 2: what a tick's outputs need, game wave -> outputs wave, by tick parity
     __shared__ __attribute__((aligned(16))) v4f_t s_gm_all[SPB];                  // per call: the four observation values, geometry wave -> storing wave
+    __shared__ __attribute__((aligned(16))) v4u_t s_rw_all[DRAW ? SPB : 1];  // per call: the call's Philox block per lane (jitter or re-spawn), geometry wave -> first wave
     constexpr bool CORNERS = true;
     typedef u32x2 rect_t;
     __shared__ __attribute__((aligned(8))) rect_t s_eb_all[SPB];
@@ -115,7 +127,7 @@ void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uin
     auto* const s_gm = (__attribute__((address_space(3))) volatile v4f_t*)(uintptr_t)(s_gm_all);
     auto* const s_pub = (__attribute__((address_space(3))) volatile v4u_t*)(uintptr_t)(s_pub_all);
     auto* const s_t0 = (__attribute__((address_space(3))) volatile v4u_t*)(uintptr_t)(s_t0_all);
-    auto* const s_t1 = (__attribute__((address_space(3))) volatile v4u_t*)(uintptr_t)(s_t1_all);
+    auto* const s_rw = (__attribute__((address_space(3))) volatile v4u_t*)(uintptr_t)(s_rw_all);
     auto* const s_eb = BSX_LDS(rect_t, s_eb_all);
     auto* const s_pq = BSX_LDS(rect_t, s_pq_all);
     auto* const s_fl = BSX_LDS(uint32_t, s_fl_all);
@@ -164,7 +176,7 @@ void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uin
             __builtin_amdgcn_s_setprio(1);               // the game wave's tick sets the pace: it goes first at the SIMD's ports
             constexpr bool R_BULLETS = true, R_MOVE = true, R_STAGE = true, R_GEOM = false, R_OUTCOME = true, R_POSE_LDS = false;
             constexpr bool R_ST_STATE = MANY == 2, R_ST_OUT = false;
-            constexpr int R_RDV_COUNTS = MANY == 2 ? 0 : 1, R_GEOM_LDS = 0, R_PUB = MANY == 2 ? 1 : 0;
+            constexpr int R_RDV_COUNTS = MANY == 2 ? 0 : 1, R_GEOM_LDS = 0, R_PUB = MANY == 2 ? 1 : 0, R_DRAW_LDS = 0;
             s_ov[tid] = 0ull;                            // (cleared again by whoever finds it set)
 #include "bsx_step_split_many_body.inl"
         } else if constexpr (MANY == 2) {                // (the outputs wave repeats none of the game logic, the game wave publishes 16 bytes per agent and tick)
@@ -174,7 +186,7 @@ void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uin
         } else {
             constexpr bool R_BULLETS = false, R_MOVE = true, R_STAGE = false, R_GEOM = true, R_OUTCOME = true, R_POSE_LDS = false;
             constexpr bool R_ST_STATE = true, R_ST_OUT = true;
-            constexpr int R_RDV_COUNTS = 2, R_GEOM_LDS = 0, R_PUB = 0;
+            constexpr int R_RDV_COUNTS = 2, R_GEOM_LDS = 0, R_PUB = 0, R_DRAW_LDS = 0;
 #include "bsx_step_split_many_body.inl"
         }
     } else {
@@ -184,7 +196,7 @@ void bsx_step_split_kernel(const int64_t E_, const uint2* const envc_, const uin
             __builtin_amdgcn_s_setprio(1);               // this wave's chain is the call's: it goes first at the SIMD's ports
             constexpr bool R_BULLETS = true, R_MOVE = true, R_STAGE = true, R_GEOM = false, R_OUTCOME = true, R_ST_STATE = true, R_ST_OUT = true;
             constexpr bool R_POSE_LDS = true;
-            constexpr int R_RDV_COUNTS = 0, R_GEOM_LDS = 2;
+            constexpr int R_RDV_COUNTS = 0, R_GEOM_LDS = 2, R_DRAW_LDS = DRAW ? 2 : 0;
             s_ov[tid] = 0ull;                            // (cleared again by whoever finds it set)
 #include "bsx_step_split_body.inl"
         } else {

@@ -515,7 +515,7 @@ class parallel_env:
                  kernel boundary (launch, first loads, store drain) runs under the other chains' arithmetic.  Measured: two chains
                  take 13 ... 26 % off a step for 2v2, 3v3, 6v6 ... 16v16, three chains 17 % at 4v4 (20.3 -> 16.8 us at 65 536 games);
                  at 1v1 nothing at 65 536 games (5.58 -> 6.0 ... 7.3 us: the two-wave kernel's launch is too short to hide a
-                 second branch's bookkeeping) and -14 % at 131 072 (8.30 -> 7.1: each half also fits the two-wave kernel;
+                 second branch's bookkeeping), from 196 608 games up -5 ... -14 % (10.27 -> 8.85 us; 1 M games 45.9 -> 43.6;
                  profiles/r06_chains_1v1.json); more branches than that cost more in graph bookkeeping than they hide -- as do any
                  with fewer than ~260 k agents per step (16 384 x 4v4: 10.7 -> 9.8 us on the device but 10.8 -> 10.9 on the wall
                  clock; 8 192 games: slower either way).  "auto" (the default) picks by team size and batch size accordingly

@@ -30,10 +30,12 @@ def chain_ranges(n_envs, n_agents_per_team, chains):
     parallel_env.capture_steps(chains=) runs as independent chains of launches; fewer ranges than asked when there are not that many
     blocks.  chains="auto": by what was measured (profiles/r03_4v4_issue_bound.json; 1v1 again with the two-wave kernels,
     profiles/r06_chains_1v1.json) -- nothing to gain below ~260 k agents per step (short launches: a multi-branch graph's bookkeeping,
-    ~1 us per step, costs more than it hides; that includes 65 536 x 1v1), else 3 chains at 4v4, 2 for every other team size."""
+    ~1 us per step, costs more than it hides), else 3 chains at 4v4, 2 for every other team size; at 1v1, whose launches are the
+    shortest, from 196 608 games (-5 ... -14 % up to 1 M games; at 131 072 four runs of five gain, one loses: not taken; 65 536: loses)."""
     blocks = -(-int(n_envs) // 256)
     if chains == "auto":
-        chains = {4: 3}.get(int(n_agents_per_team), 2) if int(n_envs) * 2 * int(n_agents_per_team) >= (1 << 18) else 1
+        n, agents = int(n_agents_per_team), int(n_envs) * 2 * int(n_agents_per_team)
+        chains = {4: 3}.get(n, 2) if agents >= ((3 << 17) if n == 1 else (1 << 18)) else 1
     chains = max(1, min(int(chains), blocks))
     cuts = [(blocks * r // chains) * 256 for r in range(chains)] + [int(n_envs)]
     return [(cuts[r], cuts[r + 1] - cuts[r]) for r in range(chains)]

@@ -131,9 +131,10 @@ def test_every_multi_tick_1v1_kernel_the_launcher_selects_vs_c_oracle(E, inject,
 
 
 @pytest.mark.parametrize("E,kernel", [
-    (114688, "two-wave per-call kernel at the last size it takes"),
+    (98304, "two-wave per-call kernel whose geometry wave also computes the call's Philox block, at the last size it takes"),
+    (114688, "two-wave per-call kernel without that (98 304 < games <= 114 688), at the last size it takes"),
     (131072, "one-wave per-call kernel (games > 114 688): the kernel of the 262 144- and 1 M-game bench rows"),
-], ids=["114688-two-wave", "131072-one-wave"])
+], ids=["98304-two-wave-draw", "114688-two-wave", "131072-one-wave"])
 def test_every_per_call_1v1_kernel_the_launcher_selects_vs_c_oracle(E, kernel):
     """step() per launch at 1v1 on either side of the size switch: 130 calls, across the tie and the re-spawns."""
     _compare_with_c_oracle(E, 1, 130, seed=811 + E % 1000, p_shoot=0.4, check_every=65)

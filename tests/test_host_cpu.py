@@ -139,7 +139,7 @@ def test_chain_ranges_partition_the_batch_in_256_game_blocks():
             assert all(r[i][0] + r[i][1] == r[i + 1][0] for i in range(len(r) - 1)) and len(r) == min(P, -(-E // 256))
             assert max(c for _, c in r) - min(c for _, c in r[:-1] or r) <= 256 + 255     # balanced to a block (the last range takes the ragged rest)
     auto = lambda E, n: len(sh.chain_ranges(E, n, "auto"))   # noqa: E731
-    assert auto(65536, 1) == 1 and auto(1048576, 1) == 1                 # 1v1: nothing to gain
+    assert auto(65536, 1) == 1 and auto(131072, 1) == 1 and auto(196608, 1) == 2 and auto(1048576, 1) == 2   # 1v1: from 196 608 games (profiles/r06_chains_1v1.json)
     assert auto(65536, 2) == 2 and auto(65536, 3) == 2 and auto(65536, 4) == 3 and auto(16384, 16) == 2
     assert auto(16384, 4) == 1 and auto(8192, 2) == 1 and auto(100, 8) == 1   # short launches: the branches cost more than they hide
 
@@ -433,7 +433,7 @@ def test_no_kernel_of_the_product_build_keeps_registers_in_scratch_memory():
     """round 4's `amdgpu_waves_per_eu(4)` on the multi-tick 2v2 kernels left three of them with 2 ... 7 vector
     registers in scratch memory, touched every tick, and nothing noticed.  The product's translation units are compiled to assembly
     here (hipcc cross-compiles without a GPU; tools/isa_meta.py) and every kernel's metadata must say: no spilled VGPR, no private
-    segment.  The committed table (profiles/r05_isa_meta.json) must be the one this tree compiles to."""
+    segment.  The committed table (profiles/r06_isa_meta.json) must be the one this tree compiles to."""
     with __import__("tempfile").TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "meta.json")
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_meta.py"), "--json", out], capture_output=True, text=True, timeout=900)
@@ -443,7 +443,7 @@ def test_no_kernel_of_the_product_build_keeps_registers_in_scratch_memory():
     bad = {k: v for k, v in meta.items() if v["vgpr_spill_count"] or v["private_segment_fixed_size"]}
     assert not bad, bad
     assert all(v["vgpr_count"] <= 256 for v in meta.values())
-    committed = json.load(open(os.path.join(ROOT, "profiles", "r05_isa_meta.json")))
+    committed = json.load(open(os.path.join(ROOT, "profiles", "r06_isa_meta.json")))
     assert committed == meta, sorted(k for k in set(meta) | set(committed) if meta.get(k) != committed.get(k))[:6]
 
 
@@ -499,12 +499,14 @@ def test_the_size_limits_of_the_two_wave_kernels_are_the_same_in_the_launcher_th
     m = re.search(r"SPLIT_MAX_GAMES = (\d+), SPLIT_MANY_MAX_GAMES = (\d+), SPLIT_CONT_MAX_GAMES = (\d+);", k)
     lim = {"BSX_X_SPLIT_MAX": int(m.group(1)), "BSX_X_SPLIT_MANY_MAX": int(m.group(2)), "BSX_X_SPLIT_CONT_MAX": int(m.group(3))}
     form2_from = int(re.search(r"SPLIT_MANY_FORM2_FROM = (\d+);", k).group(1))
-    assert lim == {"BSX_X_SPLIT_MAX": 114688, "BSX_X_SPLIT_CONT_MAX": 81920, "BSX_X_SPLIT_MANY_MAX": 65536} and form2_from == 32768
+    draw_max = int(re.search(r"SPLIT_DRAW_MAX_GAMES = (\d+);", k).group(1))
+    assert lim == {"BSX_X_SPLIT_MAX": 114688, "BSX_X_SPLIT_CONT_MAX": 81920, "BSX_X_SPLIT_MANY_MAX": 65536} and form2_from == 32768 and draw_max == 98304
     b = open(os.path.join(ROOT, "bench.py")).read()
     t = open(os.path.join(ROOT, "tools", "collect_profile.py")).read()
     want = "E <= (%d if many else (%d if %s else %d))" % (lim["BSX_X_SPLIT_MANY_MAX"], lim["BSX_X_SPLIT_CONT_MAX"], "%s", lim["BSX_X_SPLIT_MAX"])
     assert want % "continuous" in b, want
     assert want % "cont" in t, want
     assert "(2 if E > %d else 1) if many else 0" % form2_from in b and "(2 if E > %d else 1) if many else 0" % form2_from in t
+    assert "draw = not many and (continuous or E <= %d)" % draw_max in b and "draw = not many and (cont or E <= %d)" % draw_max in t
     h = open(os.path.join(ROOT, "include", "battlespace_hip.h")).read()
     assert "114 688" in h and "81 920" in h and "65 536" in h                     # (BSX_F_ONE_WAVE's description names the three limits)

@@ -155,7 +155,15 @@ def main(argv):
     if len(argv) >= 2 and argv[0] == "--csrc":              # (the test of this tool points it at a doctored copy)
         CSRC, argv = argv[1], argv[2:]
     files = {ph: os.path.join(CSRC, f"bsx_step_phase_{ph}.inl") for ph in PHASES}
-    raw = {ph: open(f).read() for ph, f in files.items()}
+    def expand(path, depth=0):
+        """A phase file's text with the part-files it includes (bsx_step_phase_shot_entry.inl, bsx_step_phase_respawn.inl) in place of the
+        #include lines, as the compiler sees it: a part is text of the phase that includes it (a part included twice -- in place, and at the
+        per-call two-wave kernel's deferred position -- counts for both includers)."""
+        text = open(path).read()
+        if depth > 2:
+            return text
+        return re.sub(r'^#include "(bsx_step_phase_\w+\.inl)"[^\n]*$', lambda m: expand(os.path.join(CSRC, m.group(1)), depth + 1), text, flags=re.M)
+    raw = {ph: expand(f) for ph, f in files.items()}
     sc = {ph: scan(raw[ph]) for ph in PHASES}
     kernel = open(os.path.join(CSRC, "bsx_step_kernel.h")).read()
     after = strip(kernel.split('#include "bsx_step_phase_stores.inl"', 1)[1])

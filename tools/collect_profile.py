@@ -55,7 +55,9 @@ def kernel_filter(key):
     name = (f"bsx_step_kernel<{n if n <= 4 else 0}, {'true' if cont else 'false'}, {'true' if many else 'false'}, false, false, "
             f"{'true' if narrow else 'false'}>")   # <N, CONT, MULTI, ACTOR, LG, OFF32>
     if n == 1 and not (cont and many) and E <= (65536 if many else (81920 if cont else 114688)):   # the two-wave 1v1 kernels (bsx_step_split.h): <LG, OFF32, MANY, CONT>, two waves per workgroup
-        name, grid = f"bsx_step_split_kernel<false, {'true' if narrow else 'false'}, {(2 if E > 32768 else 1) if many else 0}, {'true' if cont else 'false'}>", grid * 2
+        draw = not many and (cont or E <= 98304)               # <LG, OFF32, MANY, CONT, DRAW>: per-call launches of up to 98 304 games take the kernel whose geometry wave draws
+        name, grid = (f"bsx_step_split_kernel<false, {'true' if narrow else 'false'}, {(2 if E > 32768 else 1) if many else 0}, {'true' if cont else 'false'}, "
+                      f"{'true' if draw else 'false'}>"), grid * 2
     return name, grid, many
 
 

@@ -25,10 +25,10 @@ def short_name(mangled):
     m = re.match(r"_ZN(?:12_GLOBAL__N_1|4bsxk)15bsx_step_kernelILi(\d+)ELb([01])ELb([01])ELb([01])ELb([01])ELb([01])E", mangled)
     if m:
         return "bsx_step_kernel<%s,%s>" % (m.group(1), ",".join("FT"[int(b)] for b in m.groups()[1:]))
-    m = re.match(r"_ZN(?:12_GLOBAL__N_1|4bsxk)21bsx_step_split_kernelILb([01])ELb([01])ELi(\d)ELb([01])E", mangled)
+    m = re.match(r"_ZN(?:12_GLOBAL__N_1|4bsxk)21bsx_step_split_kernelILb([01])ELb([01])ELi(\d)ELb([01])ELb([01])E", mangled)
     if m:
         g = m.groups()
-        return "bsx_step_split_kernel<%s,%s,%s,%s>" % ("FT"[int(g[0])], "FT"[int(g[1])], g[2], "FT"[int(g[3])])     # <LG, OFF32, MANY (0 per call, 1 / 2 multi-tick forms), CONT>
+        return "bsx_step_split_kernel<%s,%s,%s,%s,%s>" % ("FT"[int(g[0])], "FT"[int(g[1])], g[2], "FT"[int(g[3])], "FT"[int(g[4])])     # <LG, OFF32, MANY (0 per call, 1 / 2 multi-tick forms), CONT, DRAW>
     m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", mangled)
     if m:
         n = int(m.group(1))
