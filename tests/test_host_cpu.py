@@ -489,6 +489,30 @@ def test_the_product_sources_carry_no_experiment_switches():
         assert "build_variant" not in open(f).read(), f
 
 
+def test_the_traffic_constants_the_bench_quotes_belong_to_the_series_they_name():
+    """bench.py quotes HBM bytes per launch from profiles/traffic.json wherever it does not measure them live (the non-headline rows, the
+    N > 1 line, runs under a profiler) and names the entry's `series` beside the number.  The file must be ONE step-kernel series, that
+    series' PMC summary must be committed and say the same bytes (2 x FETCH_SIZE + WRITE_SIZE KiB), and the rollout entries must name
+    kernels of this tree."""
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    step = {k: v for k, v in t.items() if k.startswith("E")}
+    series = {v["series"] for v in step.values()}
+    assert len(series) == 1, series
+    tag = series.pop()
+    pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json")))
+    for k, v in step.items():
+        f, w = pmc[k]["FETCH_SIZE"]["mean_per_launch"], pmc[k]["WRITE_SIZE"]["mean_per_launch"]
+        assert v["hbm_bytes_per_launch"] == int((2 * f + w) * 1024), k
+        if "ticks_per_launch" in v:
+            assert v["hbm_bytes_per_tick"] == v["hbm_bytes_per_launch"] // v["ticks_per_launch"], k
+    b = open(os.path.join(ROOT, "bench.py")).read()
+    assert "series {te.get('series')}" in b                  # the line names the series it read
+    roll = {k: v for k, v in t.items() if k.startswith("rollout_")}
+    assert len({v["series"] for v in roll.values()}) == 1
+    names = [kn for kn in roll["rollout_graph"]["kernels"]["FETCH_SIZE"] if "bsx_step_" in kn]
+    assert names and all("bsx_step_split_kernel<true, true, 0, false, true>" in kn for kn in names), names   # the graph rollout's step kernel at 65 536 x 1v1, score rows
+
+
 def test_the_size_limits_of_the_two_wave_kernels_are_the_same_in_the_launcher_the_bench_and_the_profile_tool():
     """csrc/bsx_kernels.hip decides by launch size which 1v1 kernel runs (two-wave per call up to 114 688 games, 81 920 with continuous
     actions; two-wave multi-tick up to 65 536, its form 2 above 32 768).  bench.py and tools/collect_profile.py NAME the kernel a workload
