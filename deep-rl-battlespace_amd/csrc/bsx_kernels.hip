@@ -290,6 +290,9 @@ inline bool narrow_offsets_ok(int64_t E, int n, uint32_t flags) {
 // wave that takes the post-move poses from it -- 6.08 -> 5.60 us per call at 65 536 games, 4.34 -> 3.99 at 4 096, 6.99 -> 6.33 at 81 920,
 // 8.11 -> 7.11 at 114 688 (131 072: 8.31 -> 8.85, so not there).  Continuous actions (bsx_step_continuous) take the same form up to 81 920
 // games (84 ... 88 registers: six waves per SIMD at most): 8.07 -> 7.67 us at 65 536 games, 6.26 -> 5.85 at 16 384, 9.49 -> 8.74 at 81 920 (98 304: 9.92 -> 11.95).
+// Round 6: in per-call launches of up to 98 304 games (and every continuous one) the geometry wave, idle until the planes have moved, also
+// computes the call's Philox block for the first wave (template parameter DRAW): 5.60 -> 5.36 us at 65 536 games, 4.01 -> 3.86 at 4 096,
+// 6.55 -> 6.40 at 98 304; at seven waves per SIMD it finds no room (114 688: 7.13 -> 7.5 ... 8.1), so above 98 304 games DRAW = false.
 constexpr int64_t SPLIT_MAX_GAMES = 114688, SPLIT_MANY_MAX_GAMES = 65536, SPLIT_CONT_MAX_GAMES = 81920;
 constexpr int64_t SPLIT_DRAW_MAX_GAMES = 98304;            // per-call discrete launches of up to this many games: the geometry wave also computes the call's Philox block (round 6)
 constexpr int64_t SPLIT_MANY_FORM2_FROM = 32768;           // multi-tick launches of MORE games than this (two workgroups on some SIMD): the outputs wave that repeats no game logic
