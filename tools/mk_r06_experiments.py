@@ -1,0 +1,35 @@
+import json,glob,re,statistics,collections,os
+def table(tag,names):
+    t=collections.defaultdict(list)
+    for f in glob.glob(f"gpurun_out/{tag}/*.out"):
+        m=re.match(r".*/(%s)_(\w+?)_\d+\.out" % "|".join(names),f)
+        if not m: continue
+        try: d=json.loads(open(f).read().strip().splitlines()[-1])
+        except Exception: continue
+        t[m.group(2)].append((m.group(1), d["roofline"]["avg_launch_us"]))
+    out={}
+    for w,v in sorted(t.items()):
+        out[w]={n: sorted(x for nn,x in v if nn==n) for n in names if any(nn==n for nn,_ in v)}
+        out[w]["median"]={n: round(statistics.median(out[w][n]),3) for n in out[w] if n!="median"}
+    return out
+d={"what":"Round 6, VERDICT r5 item 6: the shot's Philox off the critical wave of the per-call two-wave 1v1 kernel (csrc/bsx_step_split.h, DRAW). us per step() by HIP events (bench.py --steps 1000 --warmup 50 --repeats 3 --no-cpu-baseline --no-other-workloads --no-live-traffic [--envs-per-gpu E | --action-mix dense | --continuous]; a run's figure is the median of its 3 blocks); libraries of the forms alternate within ONE gpurun call (BSX_LIB_PATH), every run listed; workload keys: E<games>, c2 = E65536, dense = bullet-heavy, cont = continuous actions at 65 536 games, s20 = the driver's --steps 20 form.",
+ "forms":{"base":"round 5's kernel (the first wave draws): lib_r06base.so = the tree at commit 'Product sources without the laboratory'",
+          "new":"the geometry wave loads the game's record and computes the call's Philox block (jitter or re-spawn) before the pose rendezvous; the first wave makes the shot entry / applies the re-spawn after it; pose hand-over still 32 B per lane, LDS 9 216 B per workgroup, 72 VGPRs",
+          "prio":"new + the geometry wave at s_setprio 1 while it computes the block (every launch size)",
+          "m":"new + the pose hand-over merged into ONE 16-byte word per lane (packed position, heading, packed enemy base; the enemy's position by DPP in the geometry wave): LDS 8 192 B, 73 VGPRs; priority raised only in launches of more than 65 536 games",
+          "m7":"m compiled with amdgpu_waves_per_eu(7): the scheduler settles at 63 ... 64 VGPRs",
+          "prod":"the committed kernel: m's code as template parameter DRAW = true for launches of up to 98 304 games (and every continuous launch), DRAW = false (the first wave draws, merged hand-over: 72 VGPRs, LDS 7 168 B) above"},
+ "r06c_base_vs_new":table("r06c",["base","new"]),
+ "r06d_base_new_prio":table("r06d",["base","new","prio"]),
+ "r06e_base_m_m7":table("r06e",["base","m","m7"]),
+ "r06f_base_vs_product":table("r06f",["base","prod"]),
+ "r06h_more_work_in_the_geometry_wave":{"what":"p1 = the product; p2 = the geometry wave ALSO works the shot out (its own load of the plane record, the heading-table gather, jitter, angle-addition step, step code: ~40 more vector instructions before the pose rendezvous) and hands (step code, flag, heading) over in place of the block; same results (68 + 27 GPU tests). Not kept: the code is not in the tree.","runs":table("r06h",["p1","p2"])},
+ "r06i_pool_entries_requested_after_the_count":{"what":"p1 = the product (the pool's first 64 entries are requested unconditionally with the first batch of loads); lp = the first wave requests them once the pool's count has arrived, live entries only (`if (lane < pc)`): 1 MB of the 3.6 MB the launch's waves request in their first burst leaves it, at the price of a dependent load.  Is the cold first burst (2 550 cycles to the first record) a bandwidth burst?  No: slower by 0.1 ... 1.0 % in every regime.  Not kept; same results (57 GPU tests).","runs":table("r06i",["p1","lp"])},
+ "reading":["the draw in the idle wave pays wherever a SIMD holds at most six waves: C2 5.60 -> 5.38 ... 5.40 us (-3.9 %: VERDICT r5's bar of 5.45 is met), 16 384 games 4.36 -> 4.20 ... 4.24, 32 768 4.84 -> 4.65, bullet-heavy 9.64 -> 9.42 ... 9.47, continuous 7.65 -> 7.60 (its first wave's sincos shot and move dominate)",
+  "from 81 920 games the block must be computed at the first waves' priority or its first wave waits for it at the rendezvous: 81 920 6.35 -> 6.50 (new) / 6.14 (prio, m), 98 304 6.55 -> 6.75 / 6.40; at 65 536 and below the raise only costs (5.42 -> 5.44), hence the size gate",
+  "at 114 688 games (seven waves per SIMD) every form with the draw in the geometry wave loses: 7.13 -> 8.03 (new: 9 216 B of LDS), 8.08 (m: 73 VGPRs = six waves per SIMD, a second round), 7.48 (m7: no cliff, but the 64-register schedule is slower everywhere: C2 5.57): the launcher keeps the first wave's own draw above 98 304 games",
+  "the geometry wave's room before the pose rendezvous is the Philox block and no more: with the shot's arithmetic added (r06h) C2 goes 5.38 -> 5.77, bullet-heavy 9.43 -> 9.70, all-shoot 6.78 -> 7.16 -- its first wave now waits for it; at 16 384 / 32 768 games (one or two waves per SIMD) it is neutral",
+  "the kernel without the draw (DRAW = false: launches of 98 305 ... 114 688 games) carries the merged 16-byte pose hand-over: 106 496 games 7.01 -> 7.06, 114 688 7.12 -> 7.16 (+0.6 % against round 5's kernel)",
+  "parity: the GPU suite's trace, split, rng-pin, fuzz and full-size tests on 'new' (r06c: 80 + 52 passed) and the whole suite + a 240 s fuzz run on the product (r06f)"]}
+json.dump(d,open("profiles/r06_experiments.json","w"),indent=1)
+print({k:v.get("median") for k,v in d["r06e_base_m_m7"].items()})
