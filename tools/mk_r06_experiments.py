@@ -1,3 +1,6 @@
+"""Regenerates profiles/r06_experiments.json from the bench lines the A/B calls of round 6 left under gpurun_out/ (r06c ... r06i; tools/steps/steps_r06*.txt are the
+commands): per call and workload every run of every form (us per step() by HIP events) and the medians.  gpurun_out/ is scratch: this is the record of how the
+table was made, runnable only where those directories still exist."""
 import json,glob,re,statistics,collections,os
 def table(tag,names):
     t=collections.defaultdict(list)
