@@ -29,6 +29,7 @@ d={"what":"Round 6, VERDICT r5 item 6: the shot's Philox off the critical wave o
  "r06h_more_work_in_the_geometry_wave":{"what":"p1 = the product; p2 = the geometry wave ALSO works the shot out (its own load of the plane record, the heading-table gather, jitter, angle-addition step, step code: ~40 more vector instructions before the pose rendezvous) and hands (step code, flag, heading) over in place of the block; same results (68 + 27 GPU tests). Not kept: the code is not in the tree.","runs":table("r06h",["p1","p2"])},
  "r06i_pool_entries_requested_after_the_count":{"what":"p1 = the product (the pool's first 64 entries are requested unconditionally with the first batch of loads); lp = the first wave requests them once the pool's count has arrived, live entries only (`if (lane < pc)`): 1 MB of the 3.6 MB the launch's waves request in their first burst leaves it, at the price of a dependent load.  Is the cold first burst (2 550 cycles to the first record) a bandwidth burst?  No: slower by 0.1 ... 1.0 % in every regime.  Not kept; same results (57 GPU tests).","runs":table("r06i",["p1","lp"])},
  "r06k_heading_table_touched_early":{"what":"p1 = the product; pf = the geometry wave touches every 128-byte line of the heading table (46 lanes, one dword each) at kernel entry, so that the first wave's one dependent load (the gather of its heading's entry, ~1 us later) finds the table in the CU's L1.  Slower by 0.1 ... 3 % (C2 5.39 -> 5.55): the extra request delays that wave's record load and with it the block its first wave waits for.  Not kept; same results (57 GPU tests).","runs":table("r06k",["p1","pf"])},
+ "r06o_shot_arithmetic_without_the_branch":{"what":"p1 = the product; bf = the DRAW kernels' first wave does the shot's arithmetic for every lane (only the two stores stay under `if (spawn)`), so that the scheduler may interleave it with the first bullet round's LDS round trips.  Discrete: +0.3 ... 1.4 %; continuous (a sincos shot): -1.1 %.  Not kept.","runs":table("r06o",["p1","bf"])},
  "reading":["the draw in the idle wave pays wherever a SIMD holds at most six waves: C2 5.60 -> 5.38 ... 5.40 us (-3.9 %: VERDICT r5's bar of 5.45 is met), 16 384 games 4.36 -> 4.20 ... 4.24, 32 768 4.84 -> 4.65, bullet-heavy 9.64 -> 9.42 ... 9.47, continuous 7.65 -> 7.60 (its first wave's sincos shot and move dominate)",
   "from 81 920 games the block must be computed at the first waves' priority or its first wave waits for it at the rendezvous: 81 920 6.35 -> 6.50 (new) / 6.14 (prio, m), 98 304 6.55 -> 6.75 / 6.40; at 65 536 and below the raise only costs (5.42 -> 5.44), hence the size gate",
   "at 114 688 games (seven waves per SIMD) every form with the draw in the geometry wave loses: 7.13 -> 8.03 (new: 9 216 B of LDS), 8.08 (m: 73 VGPRs = six waves per SIMD, a second round), 7.48 (m7: no cliff, but the 64-register schedule is slower everywhere: C2 5.57): the launcher keeps the first wave's own draw above 98 304 games",
