@@ -512,14 +512,14 @@ class parallel_env:
         chains:  > 1 = the batch as that many contiguous game ranges, each a chain of T launches on its own branch of the graph (forked
                  from and joined into the capture stream).  The reference's games share nothing (battle_env.py:281-381), so the results
                  are those of chains=1 bit for bit; what changes is that a range's step t+1 waits for ITS step t only, and one chain's
-                 kernel boundary (launch, first loads, store drain) runs under the other chains' arithmetic.  Measured: two chains
-                 take 13 ... 26 % off a step for 2v2, 3v3, 6v6 ... 16v16, three chains 17 % at 4v4 (20.3 -> 16.8 us at 65 536 games);
-                 at 1v1 nothing at 65 536 games (5.58 -> 6.0 ... 7.3 us: the two-wave kernel's launch is too short to hide a
-                 second branch's bookkeeping), from 196 608 games up -5 ... -14 % (10.27 -> 8.85 us; 1 M games 45.9 -> 43.6;
-                 profiles/r06_chains_1v1.json); more branches than that cost more in graph bookkeeping than they hide -- as do any
-                 with fewer than ~260 k agents per step (16 384 x 4v4: 10.7 -> 9.8 us on the device but 10.8 -> 10.9 on the wall
-                 clock; 8 192 games: slower either way).  "auto" (the default) picks by team size and batch size accordingly
-                 (sharding.chain_ranges); chains=1 is ONE launch per step over the whole batch.
+                 kernel boundary (launch, first loads, store drain) runs under the other chains' arithmetic.  Measured with replays
+                 queued back to back: two chains take 13 ... 26 % off a step for 2v2, 3v3, 6v6 ... 16v16, three chains 17 % at 4v4
+                 (20.3 -> 16.8 us at 65 536 games); at 1v1 nothing at 65 536 games, -5 ... -14 % from 196 608 games up
+                 (profiles/r06_chains_1v1.json).  A multi-branch graph is launched node by node at ~6 us each, though, and a replay
+                 that is synchronised before the next one pays for that: there 4v4 is a tie, 2v2 and 1v1 below 1 M games LOSE.
+                 "auto" (the default) takes chains only where neither use loses (sharding.chain_ranges: 4v4, 3v3, 5v5 and larger,
+                 1v1 from 1 M games); chains=2 / 3 is for the caller who queues replays; chains=1 is ONE launch per step over
+                 the whole batch.
         Returns (graph, outputs): graph.replay() runs the T steps; outputs = (obs, rew, done) tensors.
         Needs rng='philox' (no host draws inside a graph)."""
         if self.rng != "philox" or self._compat:

@@ -249,28 +249,33 @@ class PolicyRollout:
     kernel and restarted per game; then clamp(-1, 1) as maddpg/agent.py:31 does."""
 
     def __init__(self, env, actor, T, noise_std=0.0, fused=True, seed=0, opponent=None, ou_scale=0.0, one_launch=False,
-                 precision="f32", ou_restart=True, sample=None, temperature=1.0, value_actor=None, chains=1):
+                 precision="f32", ou_restart=True, sample=None, temperature=1.0, value_actor=None, chains="auto"):
         """actor: a StackedActor.  fused=True evaluates it with the hand-written HIP kernel (FusedActor), False with
         torch ops (the fp32 reference of the same op).  opponent: an `instinct.Team` that plays its team's planes
         instead of the actor (the reference's training setup, main.py:119-122: learned red vs scripted blue): its
         one-hot scores overwrite that team's rows of the score tensor each tick, on device."""
         # chains > 1 (graph form, fused actor, no scripted opponent): the games as that many ranges, each its own chain of
         # (actor -> step) launch pairs on a branch of the graph (battle_env.capture_steps(chains=)): one range's matrix-core actor
-        # pass runs under another range's step kernel.  Same transitions bit for bit.
+        # pass runs under another range's step kernel.  Same transitions bit for bit.  chains="auto" (the default) takes two chains where
+        # they pay in EITHER use -- replays queued back to back, or every replay synchronised (a rollout, then the learner): 2v2 and larger
+        # from ~260 k agents per tick (65 536 x 2v2: 43.1 -> 38.4 us per tick back to back, 42.8 -> 40.3 synchronised).  Not 1v1: back to
+        # back 23.0 -> 21.3, but a multi-branch graph is launched node by node at ~6 us each and a synchronised replay pays for that --
+        # 23.5 -> 26.3 (profiles/r06_chains_1v1.json); chains=2 is there for the caller who queues replays.
         # one_launch beyond 4v4 (an MFMA tile per plane id and a workgroup of 32 games stop fitting: the fused kernels exist for 1v1 ... 4v4):
         # the rollout falls through to the graph of (actor -> step) pairs, as chains over game ranges where those pay -- the same
         # transitions; `form_note` says so
         self.form_note = None
         if one_launch and fused and env.n_agents > 4:
             one_launch = False
-            if chains == 1 and opponent is None:
+            if chains in (1, "auto") and opponent is None:
                 chains = "auto"
             self.form_note = (f"one_launch asked for {env.n_agents}v{env.n_agents}: the fused kernels cover 1v1 ... 4v4, "
                               "this rollout runs as the two-kernel graph (chains over game ranges where they pay)")
             import warnings
             warnings.warn(self.form_note, RuntimeWarning, stacklevel=2)      # the caller asked for a form that is not the one running
-        if chains == "auto":                           # two chains where they were measured to pay: 2v2 and larger, from ~260 k agents per tick
-            chains = 2 if (env.n_agents >= 2 and env.n_envs * 2 * env.n_agents >= (1 << 18) and not one_launch and fused and opponent is None) else 1
+        if chains == "auto":                           # two chains where they were measured to pay (above)
+            agents = env.n_envs * 2 * env.n_agents
+            chains = 2 if (env.n_agents >= 2 and agents >= (1 << 18) and not one_launch and fused and opponent is None) else 1
         self.chains = int(chains)
         if self.chains > 1 and (one_launch or not fused or opponent is not None):
             raise ValueError("chains > 1 is for the graph form with the fused actor and no scripted opponent")

@@ -28,14 +28,22 @@ def env_range(total_envs, rank, world_size):
 def chain_ranges(n_envs, n_agents_per_team, chains):
     """The batch as contiguous game ranges [(first, count), ...] in whole 256-game blocks -- what bsx_step_*_range takes and
     parallel_env.capture_steps(chains=) runs as independent chains of launches; fewer ranges than asked when there are not that many
-    blocks.  chains="auto": by what was measured (profiles/r03_4v4_issue_bound.json; 1v1 again with the two-wave kernels,
-    profiles/r06_chains_1v1.json) -- nothing to gain below ~260 k agents per step (short launches: a multi-branch graph's bookkeeping,
-    ~1 us per step, costs more than it hides), else 3 chains at 4v4, 2 for every other team size; at 1v1, whose launches are the
-    shortest, from 196 608 games (-5 ... -14 % up to 1 M games; at 131 072 four runs of five gain, one loses: not taken; 65 536: loses)."""
+    blocks.  chains="auto" (capture_steps' default) takes chains only where they do not lose in EITHER use of the graph -- replays queued
+    back to back (what the chains were built for: profiles/r03_4v4_issue_bound.json, r06_chains_1v1.json), or every replay synchronised.
+    A multi-branch graph is launched node by node at ~6 us each, which a synchronised replay pays for in full: chained steps run at
+    (chains x ~6 us) per step at best.  So: 3 chains at 4v4 (back to back 20.2 -> 16.5 us per step, synchronised 21.0 -> 20.9), 2 for
+    3v3 and for 5v5 ... 16v16 (steps of 17 ... 97 us), from ~260 k agents per step; 1v1 from 1 M games (-4 ... -5 % in both uses);
+    NOT 2v2 (back to back 9.7 -> 8.6, synchronised 9.5 -> 10.8) and not 1v1 below that (196 608 games: 10.3 -> 8.9 against 10.7 -> 12.0):
+    ask for those (chains=2) when replays are queued."""
     blocks = -(-int(n_envs) // 256)
     if chains == "auto":
         n, agents = int(n_agents_per_team), int(n_envs) * 2 * int(n_agents_per_team)
-        chains = {4: 3}.get(n, 2) if agents >= ((3 << 17) if n == 1 else (1 << 18)) else 1
+        if n == 1:
+            chains = 2 if agents >= (1 << 21) else 1
+        elif n == 2:
+            chains = 1
+        else:
+            chains = {4: 3}.get(n, 2) if agents >= (1 << 18) else 1
     chains = max(1, min(int(chains), blocks))
     cuts = [(blocks * r // chains) * 256 for r in range(chains)] + [int(n_envs)]
     return [(cuts[r], cuts[r + 1] - cuts[r]) for r in range(chains)]

@@ -139,8 +139,8 @@ def test_chain_ranges_partition_the_batch_in_256_game_blocks():
             assert all(r[i][0] + r[i][1] == r[i + 1][0] for i in range(len(r) - 1)) and len(r) == min(P, -(-E // 256))
             assert max(c for _, c in r) - min(c for _, c in r[:-1] or r) <= 256 + 255     # balanced to a block (the last range takes the ragged rest)
     auto = lambda E, n: len(sh.chain_ranges(E, n, "auto"))   # noqa: E731
-    assert auto(65536, 1) == 1 and auto(131072, 1) == 1 and auto(196608, 1) == 2 and auto(1048576, 1) == 2   # 1v1: from 196 608 games (profiles/r06_chains_1v1.json)
-    assert auto(65536, 2) == 2 and auto(65536, 3) == 2 and auto(65536, 4) == 3 and auto(16384, 16) == 2
+    assert auto(65536, 1) == 1 and auto(196608, 1) == 1 and auto(1048576, 1) == 2   # 1v1: from 1 M games -- below, a synchronised replay of the chained graph loses (profiles/r06_chains_1v1.json)
+    assert auto(65536, 2) == 1 and auto(65536, 3) == 2 and auto(65536, 4) == 3 and auto(16384, 16) == 2     # (2v2: gains only when replays are queued back to back)
     assert auto(16384, 4) == 1 and auto(8192, 2) == 1 and auto(100, 8) == 1   # short launches: the branches cost more than they hide
 
 

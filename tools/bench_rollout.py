@@ -15,6 +15,8 @@ ap.add_argument("--noise", type=float, default=0.1); ap.add_argument("--torch-ac
 ap.add_argument("--one-launch", action="store_true", help="all T ticks in one kernel (bsx_rollout_discrete; 1v1)")
 ap.add_argument("--precision", default="f32", choices=("f32", "bf16x3", "bf16x6"), help="the actor's 64 x 64 layer")
 ap.add_argument("--rollout-only", action="store_true", help="skip the env-alone and actor-alone graphs (counter passes: only the rollout's kernels run)")
+ap.add_argument("--chains", default="1", help="graph form: the batch as this many chains of (actor -> step) pairs over game ranges, or 'auto' "
+                                           "(PolicyRollout's default); 1 = one pair per tick over the whole batch: what the kernel-stats and traffic tools profile")
 ap.add_argument("--scripted-blue", action="store_true", help="blue is the scripted opponent (instinct.Team), red the actor: main.py:119-122")
 args = ap.parse_args()
 E, n, T = args.envs, args.n_agents, args.T
@@ -30,7 +32,7 @@ if args.scripted_blue:
     from deep_rl_battlespace_amd import instinct
     opp = instinct.Team(env.possible_blue, env.possible_red, env)
 ro = PolicyRollout(env, actor, T, noise_std=args.noise, fused=not args.torch_actor, one_launch=args.one_launch, precision=args.precision,
-                   opponent=opp)
+                   opponent=opp, chains=1 if args.one_launch or args.torch_actor or opp is not None else (args.chains if args.chains == "auto" else int(args.chains)))
 ro.start(); ro.capture()
 
 

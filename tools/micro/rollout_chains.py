@@ -1,56 +1,39 @@
-"""PolicyRollout's graph form (two kernels per tick: bsx_actor_forward -> bsx_step_*) with the games as P chains (chains=P):
-µs per tick of the whole batch for 1v1 ... 4v4, both teams on actors.  The one-launch form is printed beside it where it exists."""
-import argparse
-import importlib
-import statistics
-import sys
-import time
-from pathlib import Path
-
+#!/usr/bin/env python3
+"""GPU box: the configs[4] rollout as the graph of (actor -> step) kernel pairs, with the batch as 1 / 2 / 3 chains over game ranges
+(PolicyRollout(chains=P)): does one range's kernel boundary hide behind the other's kernels at 1v1 too?  us per tick (wall clock over
+`reps` replays of a T-tick graph, synchronised at both ends), forms alternating, medians.
+    python tools/micro/rollout_chains.py [E] [n] [precision]"""
+import json, os, statistics, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import torch
+import deep_rl_battlespace_amd as bsx
+from deep_rl_battlespace_amd.rollout import PolicyRollout, StackedActor
 
-sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
-bsx = importlib.import_module("deep-rl-battlespace_amd")
-ro_mod = importlib.import_module("deep-rl-battlespace_amd.rollout")
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--envs", type=int, default=65536)
-    ap.add_argument("--teams", type=int, nargs="+", default=[1, 2, 4])
-    ap.add_argument("--chains", type=int, nargs="+", default=[1, 2, 3])
-    ap.add_argument("--precision", default="f32")
-    ap.add_argument("--ticks", type=int, default=32)
-    ap.add_argument("--continuous", action="store_true")
-    ap.add_argument("--only-one-launch", action="store_true")
-    args = ap.parse_args()
-    dev, E, T = torch.device("cuda:0"), args.envs, args.ticks
-    for n in args.teams:
-        forms = ([] if args.only_one_launch else [("graph", P) for P in args.chains]) + [("one_launch", 1)]
-        for form, P in forms:
-            env = bsx.parallel_env(n_agents=n, n_envs=E, auto_reset=True, seed=1234, device=dev, continuous_actions=args.continuous)
-            env.reset()
-            torch.manual_seed(0)
-            actor = ro_mod.StackedActor(2 * n, 3 * n + 2, 3 if args.continuous else 4, device=dev)
-            with torch.no_grad():
-                actor.w3.mul_(100.0)
-            ro = ro_mod.PolicyRollout(env, actor, T, noise_std=0.1, precision=args.precision, one_launch=form == "one_launch", chains=P)
-            ro.start(); ro.capture()
-            for _ in range(8):
-                ro.run()
-            samples = []
-            for _ in range(5):
-                torch.cuda.synchronize(dev); t0 = time.perf_counter()
-                for _ in range(10):
-                    ro.run()
-                torch.cuda.synchronize(dev)
-                samples.append((time.perf_counter() - t0) / (10 * T) * 1e6)
-            us = statistics.median(samples)
-            print(f"n={n} {form} chains={P} precision={args.precision}: us_per_tick={us:.3f} agent_steps_per_s={E * 2 * n / us * 1e6:.3e} "
-                  f"samples={[round(x, 2) for x in samples]}", flush=True)
-            del ro, env, actor
-            torch.cuda.empty_cache()
-
-
-if __name__ == "__main__":
-    main()
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+prec = sys.argv[3] if len(sys.argv) > 3 else "f32"
+A, D, T = 2 * n, 3 * n + 2, 32
+torch.manual_seed(0)
+actor = StackedActor(A, D, 4, device="cuda")
+with torch.no_grad():
+    actor.w3.mul_(100.0)
+ros = {}
+for P in (1, 2, 3):
+    env = bsx.parallel_env(n_agents=n, n_envs=E, auto_reset=True, seed=1234)
+    env.reset()
+    ro = PolicyRollout(env, actor, T, noise_std=0.1, precision=prec, chains=P)
+    ro.start(); ro.capture()
+    for _ in range(10):
+        ro.run()
+    ros[P] = ro
+torch.cuda.synchronize()
+res = {P: [] for P in ros}
+for rep in range(7):
+    for P, ro in ros.items():
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(20):
+            ro.run()
+        torch.cuda.synchronize()
+        res[P].append((time.perf_counter() - t0) / 20 / T * 1e6)
+print(json.dumps({"workload": f"{E} x {n}v{n}, graph of (actor -> step) pairs, {prec}, T = {T}", "us_per_tick_median": {P: round(statistics.median(v), 2) for P, v in res.items()},
+                  "runs": {P: [round(x, 2) for x in v] for P, v in res.items()}}))
